@@ -1,0 +1,197 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when it has been built, the real
+reference compiled in place (oracle/_ref/libzpaqref.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _build():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    src = os.path.join(ORACLE_DIR, "zpaq_oracle.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "liboracle.so"])
+    return so
+
+
+_L = C.CDLL(_build())
+_u8p = C.POINTER(C.c_ubyte)
+for name in ("orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block"):
+    getattr(_L, name).restype = C.c_long
+
+
+def _buf(b):
+    return (C.c_ubyte * max(1, len(b))).from_buffer_copy(bytes(b) + (b"\0" if len(b) == 0 else b""))
+
+
+def sha1(b):
+    out = (C.c_ubyte * 20)()
+    _L.orc_sha1(_buf(b), C.c_long(len(b)), out)
+    return bytes(out)
+
+
+def sha256(b):
+    out = (C.c_ubyte * 32)()
+    _L.orc_sha256(_buf(b), C.c_long(len(b)), out)
+    return bytes(out)
+
+
+def chunk(b, fragment=6, min_frag=4096, max_frag=520192):
+    cap = len(b) // max(1, min_frag) + 2
+    lens = (C.c_uint32 * cap)()
+    n = _L.orc_chunk(_buf(b), C.c_long(len(b)), fragment, C.c_uint32(min_frag), C.c_uint32(max_frag), lens, C.c_long(cap))
+    assert n <= cap
+    return list(lens[:n])
+
+
+def e8e9(b):
+    x = _buf(b)
+    _L.orc_e8e9(x, C.c_long(len(b)))
+    return bytes(x)[: len(b)]
+
+
+def e8e9_inverse(b):
+    x = _buf(b)
+    _L.orc_e8e9_inverse(x, C.c_long(len(b)))
+    return bytes(x)[: len(b)]
+
+
+def lz77_encode(b, args, trace=False):
+    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
+    cap = len(b) + len(b) // 8 + 1024
+    out = (C.c_ubyte * cap)()
+    tcap = len(b) // 4 + 16 if trace else 0
+    tr = (C.c_uint32 * (3 * tcap))() if trace else None
+    nt = C.c_long(0)
+    r = _L.orc_lz77_encode(_buf(b), C.c_long(len(b)), a, out, C.c_long(cap), tr, C.c_long(tcap), C.byref(nt))
+    if r < 0:
+        raise RuntimeError("orc_lz77_encode failed: %d" % r)
+    if trace:
+        t = [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(nt.value)]
+        return bytes(out[:r]), t
+    return bytes(out[:r])
+
+
+def lz77_decode(b, cap, rb=0):
+    out = (C.c_ubyte * max(1, cap))()
+    r = _L.orc_lz77_decode(_buf(b), C.c_long(len(b)), rb, out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("orc_lz77_decode failed: %d" % r)
+    return bytes(out[:r])
+
+
+def compress_block(b, method, filename=None, comment=None, dosha1=True):
+    cap = len(b) + len(b) // 8 + 4096
+    out = (C.c_ubyte * cap)()
+    args = (C.c_int * 9)()
+    r = _L.orc_compress_block(_buf(b), C.c_long(len(b)), method.encode(), filename.encode() if filename is not None else None,
+                              comment if comment is None else (comment if isinstance(comment, bytes) else comment.encode()),
+                              int(dosha1), out, C.c_long(cap), args)
+    if r < 0:
+        raise RuntimeError("orc_compress_block failed: %d" % r)
+    return bytes(out[:r]), list(args)
+
+
+def decompress_block(arc, cap):
+    out = (C.c_ubyte * max(1, cap))()
+    meta = (C.c_long * 3)()
+    r = _L.orc_decompress_block(_buf(arc), C.c_long(len(arc)), out, C.c_long(cap), meta)
+    if r < 0:
+        raise RuntimeError("orc_decompress_block failed: %d" % r)
+    return bytes(out[:r]), list(meta)
+
+
+# ---------------------------------------------------------------------------------------------
+# the real reference (optional)
+# ---------------------------------------------------------------------------------------------
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libzpaqref.so")
+_R = None
+if os.path.exists(REF_SO):
+    _R = C.CDLL(REF_SO)
+    for name in ("ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode"):
+        getattr(_R, name).restype = C.c_long
+    _R.ref_last_error.restype = C.c_char_p
+
+
+def have_ref():
+    return _R is not None
+
+
+def ref_sha1(b):
+    out = (C.c_ubyte * 20)()
+    _R.ref_sha1(_buf(b), C.c_long(len(b)), out)
+    return bytes(out)
+
+
+def ref_sha256(b):
+    out = (C.c_ubyte * 32)()
+    _R.ref_sha256(_buf(b), C.c_long(len(b)), out)
+    return bytes(out)
+
+
+def ref_e8e9(b):
+    x = _buf(b)
+    _R.ref_e8e9(x, C.c_int(len(b)))
+    return bytes(x)[: len(b)]
+
+
+def ref_lzbuffer(b, args):
+    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
+    cap = len(b) + len(b) // 8 + 1024
+    out = (C.c_ubyte * cap)()
+    r = _R.ref_lzbuffer(_buf(b), C.c_long(len(b)), a, out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("ref_lzbuffer: %s" % _R.ref_last_error())
+    return bytes(out[:r])
+
+
+def ref_decompress(arc, cap):
+    out = (C.c_ubyte * max(1, cap))()
+    r = _R.ref_decompress(_buf(arc), C.c_long(len(arc)), out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("ref_decompress: %s" % _R.ref_last_error())
+    return bytes(out[:r])
+
+
+def ref_decompress_block(arc, cap):
+    out = (C.c_ubyte * max(1, cap))()
+    meta = (C.c_long * 5)()
+    fn = C.create_string_buffer(4096)
+    cm = C.create_string_buffer(4096)
+    sh = (C.c_ubyte * 21)()
+    r = _R.ref_decompress_block(_buf(arc), C.c_long(len(arc)), out, C.c_long(cap), meta, fn, C.c_long(4096), cm, C.c_long(4096), sh)
+    if r < 0:
+        raise RuntimeError("ref_decompress_block: %s" % _R.ref_last_error())
+    return dict(data=bytes(out[:r]), consumed=meta[0], segments=meta[1], sha1_ok=meta[2],
+                filename=fn.raw[: meta[3]], comment=cm.raw[: meta[4]], sha1=bytes(sh))
+
+
+def ref_compile(config, args):
+    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
+    h = (C.c_ubyte * 70000)()
+    p = (C.c_ubyte * 70000)()
+    hl, pl = C.c_long(0), C.c_long(0)
+    r = _R.ref_compile(config.encode(), a, h, C.c_long(70000), C.byref(hl), p, C.c_long(70000), C.byref(pl))
+    if r < 0:
+        raise RuntimeError("ref_compile: %s" % _R.ref_last_error())
+    return bytes(h[: hl.value]), bytes(p[: pl.value])
+
+
+def ref_postprocess(stream, ph, pm, cap):
+    out = (C.c_ubyte * max(1, cap))()
+    r = _R.ref_postprocess(_buf(stream), C.c_long(len(stream)), ph, pm, out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("ref_postprocess: %s" % _R.ref_last_error())
+    return bytes(out[:r])
+
+
+def ref_cm_encode(header, data):
+    cap = len(data) + len(data) // 2 + 4096
+    out = (C.c_ubyte * cap)()
+    r = _R.ref_cm_encode(_buf(header), C.c_long(len(header)), _buf(data), C.c_long(len(data)), out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("ref_cm_encode: %s" % _R.ref_last_error())
+    return bytes(out[:r])

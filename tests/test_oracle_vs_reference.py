@@ -1,0 +1,92 @@
+"""Cross-checks the restated oracle against the REAL reference compiled in place
+(oracle/_ref/libzpaqref.so <- /root/reference/ZSFX/libzpaq.cpp).  Skipped where that build is absent."""
+import numpy as np
+import pytest
+
+import datagen
+import orc
+
+pytestmark = pytest.mark.ref
+
+# every LZ77 level-1 argument set compressBlock emits for method "1x" (SURVEY.md Appendix C.3),
+# at block sizes arg0 = 0 (1 MiB), 2 and 4 (16 MiB: the -m1 default "14")
+def _argsets():
+    out = []
+    for a0 in (0, 2, 4):
+        htsz = 19 + a0 + (a0 <= 6)
+        out += [[a0, 1, 4, 0, 1, 15], [a0, 1, 4, 0, 2, 16], [a0, 1, 4, 0, 2, htsz], [a0, 1, 5, 0, 3, htsz], [a0, 1, 6, 0, 3, htsz]]
+    return out
+
+
+INPUTS = {
+    "empty": b"",
+    "one": b"a",
+    "short": b"abcabcabcabcabcabcabc",
+    "zeros": bytes(70000),
+    "text": datagen.text_like(300000, 1),
+    "binary": datagen.binary_like(300000, 2),
+    "mixed": datagen.mixed(400000, 3),
+    "random": datagen.random_bytes(100000, 4),
+    "runs": (b"ab" * 3000 + b"x" + b"ab" * 30000 + bytes(range(256)) * 40),
+}
+
+
+@pytest.mark.parametrize("name", list(INPUTS))
+def test_sha1_sha256(name):
+    b = INPUTS[name]
+    assert orc.sha1(b) == orc.ref_sha1(b)
+    assert orc.sha256(b) == orc.ref_sha256(b)
+
+
+@pytest.mark.parametrize("n", [0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, 1000])
+def test_sha_padding_edges(n):
+    b = datagen.random_bytes(n, n)
+    assert orc.sha1(b) == orc.ref_sha1(b)
+    assert orc.sha256(b) == orc.ref_sha256(b)
+
+
+@pytest.mark.parametrize("args", _argsets(), ids=lambda a: ",".join(map(str, a)))
+@pytest.mark.parametrize("name", list(INPUTS))
+def test_lz77_stream_identical_to_lzbuffer(name, args):
+    b = INPUTS[name]
+    ours = orc.lz77_encode(b, args)
+    assert ours == orc.ref_lzbuffer(b, args)
+    assert orc.lz77_decode(ours, len(b), rb=0) == b
+
+
+def test_lz77_long_match_and_literal_limits():
+    # maxMatch = 49152 and maxLiteral = 4096 (ZSFX/libzpaq.cpp:6275-6276)
+    rng = np.random.default_rng(9)
+    unit = rng.integers(0, 256, size=60000, dtype=np.uint8).tobytes()
+    b = unit + unit + unit[:100] + datagen.random_bytes(20000, 5) + unit
+    for args in ([0, 1, 5, 0, 3, 20], [4, 1, 5, 0, 3, 24]):
+        ours = orc.lz77_encode(b, args)
+        assert ours == orc.ref_lzbuffer(b, args)
+        assert orc.lz77_decode(ours, len(b)) == b
+
+
+def test_e8e9_forward_and_inverse():
+    rng = np.random.default_rng(11)
+    b = bytearray(rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes())
+    for i in range(0, len(b) - 8, 7):      # dense, overlapping E8/E9 patterns
+        b[i] = 0xE8 + (i & 1)
+        b[i + 4] = 0xFF if i & 2 else 0
+    b = bytes(b)
+    f = orc.e8e9(b)
+    assert f == orc.ref_e8e9(b)
+    assert orc.e8e9_inverse(f) == b
+
+
+@pytest.mark.parametrize("method", ["0", "1", "14,220,0", "14,100,0", "14,30,0", "14,20,1", "14,255,1", "10,5,0", "x0,0"])
+@pytest.mark.parametrize("name", ["empty", "short", "text", "binary", "zeros"])
+def test_blocks_decode_with_reference_decompresser(name, method):
+    """Every block the oracle frames must be a valid ZPAQ block for the reference Decompresser
+    (ZSFX/libzpaq.cpp:2239-2366), restore the input and carry a matching SHA-1."""
+    b = INPUTS[name]
+    blk, args = orc.compress_block(b, method, "jDC20240101000000d0000000001", "jDC\x01", True)
+    r = orc.ref_decompress_block(blk, len(b) + 16)
+    assert r["data"] == b and r["sha1_ok"] == 1 and r["consumed"] == len(blk)
+    assert r["filename"] == b"jDC20240101000000d0000000001"
+    assert r["comment"] == b"%d jDC\x01" % len(b)
+    mine, meta = orc.decompress_block(blk, len(b) + 16)
+    assert mine == b and meta[1] == 1
