@@ -1,0 +1,175 @@
+/* zpaqhip.h -- C ABI of the MI355X (gfx950) engine for zpaqfranz's block compress/decompress
+ * hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * What it replaces (paths relative to the reference tree /root/reference):
+ *   - the fragment loop of Jidac::add (rolling hash + SHA-1 per fragment; source file
+ *     zpaqfranz.cpp is absent from the snapshot, algorithm in SURVEY.md Appendix C.4, the
+ *     records it produces are parsed back at ZSFX/zsfx.cpp:1463-1500)      -> zpq_fragment_*
+ *   - libzpaq::SHA1 / SHA256 (ZSFX/libzpaq.h:934-979, ZSFX/libzpaq.cpp:96-304)   -> zpq_sha1_*, zpq_sha256_*
+ *   - the dedup index over HT{sha1,usize} (ZSFX/zsfx.cpp:651-659)                 -> zpq_dedup_*
+ *   - libzpaq::compressBlock (ZSFX/libzpaq.h:1505) for the stored / LZ77 level-1 family that
+ *     "-m0" and "-m1" expand to: LZBuffer (ZSFX/libzpaq.cpp:6140-6552), Encoder stored mode and
+ *     Compressor framing (ZSFX/libzpaq.h:1273-1286,1340-1371)                     -> zpq_lz77_*, zpq_compress_blocks*
+ *   - libzpaq::Decompresser for the same family (ZSFX/libzpaq.cpp:2239-2366; the LZ77 inverse is
+ *     the 302-byte PCOMP program run by PostProcessor, :2178-2233)                -> zpq_decompress_blocks*
+ *
+ * Conventions
+ *   - Every function returns ZPQ_OK (0) or a negative zpq_status; nothing throws or longjmps
+ *     across the ABI.  zpq_last_error(ctx) gives a human-readable detail string.
+ *   - "_dev" entry points take DEVICE pointers (HBM-resident data, the fast path); the others
+ *     take host pointers and stage through the context's stream.
+ *   - All work is enqueued on the context's HIP stream; functions that return results to the
+ *     host synchronise that stream before returning.
+ *   - A context is bound to one GPU and must be used by one host thread at a time (the
+ *     reference's rule: one Compressor/Decompresser per thread, ZSFX/libzpaq.h:57-59).
+ *   - There is NO CPU fallback: if no gfx950 device is present zpq_create fails with
+ *     ZPQ_ERR_NO_DEVICE.
+ */
+#ifndef ZPAQHIP_H
+#define ZPAQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum zpq_status {
+  ZPQ_OK = 0,
+  ZPQ_ERR_NO_DEVICE = -1,   /* no HIP device / not gfx950 */
+  ZPQ_ERR_HIP = -2,         /* a HIP runtime call failed (see zpq_last_error) */
+  ZPQ_ERR_ARG = -3,         /* invalid argument */
+  ZPQ_ERR_CAPACITY = -4,    /* caller-provided output capacity too small */
+  ZPQ_ERR_METHOD = -5,      /* method string outside the family this engine implements */
+  ZPQ_ERR_FORMAT = -6,      /* malformed ZPAQ block on the decode side */
+  ZPQ_ERR_CHECKSUM = -7,    /* stored SHA-1 does not match the decoded data */
+  ZPQ_ERR_NOMEM = -8        /* device or host allocation failed */
+} zpq_status;
+
+typedef struct zpq_ctx zpq_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int zpq_create(int device_ordinal, zpq_ctx** out);
+void zpq_destroy(zpq_ctx* ctx);
+const char* zpq_strerror(int status);
+const char* zpq_last_error(const zpq_ctx* ctx);
+int zpq_sync(zpq_ctx* ctx);
+/* The context's hipStream_t (as void*), so a host that owns device buffers (e.g. torch) can
+ * order its own work against the engine's. */
+void* zpq_stream(zpq_ctx* ctx);
+/* Device properties the benchmark reports: [0]=CU count, [1]=max clock kHz, [2]=memory clock
+ * kHz, [3]=memory bus width bits, [4]=L2 bytes, [5]=total HBM bytes (low 32 bits in MiB). */
+int zpq_device_info(zpq_ctx* ctx, int64_t info[6], char* name, size_t name_cap);
+
+/* ---- device memory helpers (for hosts without their own allocator) ------------------------ */
+int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr);
+int zpq_dev_free(zpq_ctx* ctx, void* dptr);
+int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* ---- SHA-1 / SHA-256 over many extents (rows a2, a18) ------------------------------------- */
+/* digest[i] = SHA-1(base[off[i] .. off[i]+len[i])), 20 bytes each (32 for SHA-256).
+ * base must stay readable for 16 bytes past the last extent (pad the allocation). */
+int zpq_sha1_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off,
+                         const uint32_t* d_len, size_t n, uint8_t* d_digests);
+int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off,
+                           const uint64_t* d_len, size_t n, uint8_t* d_digests);
+/* Host convenience: n independent host buffers -> n digests. */
+int zpq_sha1_many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n,
+                  uint8_t* digests /* n*20 */);
+int zpq_sha256_many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n,
+                    uint8_t* digests /* n*32 */);
+
+/* ---- content-defined fragmenter (row a1) --------------------------------------------------- */
+typedef struct zpq_fragment_params {
+  uint32_t fragment_log2;  /* zpaqfranz -fragment N, default 6: cut when hash < 2^(22-N) */
+  uint32_t min_fragment;   /* default 64<<N   = 4096   */
+  uint32_t max_fragment;   /* default 8128<<N = 520192 (capped at blocksize-12 by the caller) */
+} zpq_fragment_params;
+void zpq_fragment_params_default(zpq_fragment_params* p);
+
+/* Files are the extents [file_off[f], file_off[f+1]) of one device buffer (file_off has
+ * nfiles+1 entries, HOST pointer).  Produces, in file order then position order, one record per
+ * fragment: absolute offset into d_base, length, owning file.  The three output arrays are
+ * DEVICE pointers with room for frag_cap records; *nfrags receives the count (host).
+ * frag_cap >= zpq_fragment_capacity(...) always suffices. */
+size_t zpq_fragment_capacity(const uint64_t* file_off, size_t nfiles, const zpq_fragment_params* p);
+int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                     const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len,
+                     uint32_t* d_frag_file, size_t frag_cap, size_t* nfrags);
+
+/* ---- dedup index (row a3) ------------------------------------------------------------------ */
+/* first[i] = smallest j <= i with digest[j] == digest[i] (20-byte SHA-1 keys): fragment i is new
+ * iff first[i] == i.  Deterministic regardless of scheduling. */
+int zpq_dedup_dev(zpq_ctx* ctx, const uint8_t* d_digests, size_t n, uint32_t* d_first);
+
+/* ---- LZ77 level-1 code stream (row a8) ----------------------------------------------------- */
+/* One job = one ZPAQ block's input.  args[9] are LZBuffer's (ZSFX/libzpaq.cpp:6128-6138):
+ * args[0]=log2 MiB, args[1]=1, args[2]=min match 4..31, args[3]=0, args[4]=log2 bucket 0..3,
+ * args[5]=log2 hash size <= 26 (and < args[0]+21), args[6]=0.  Output: the exact byte stream
+ * LZBuffer::read() yields.  d_out capacity per job must be >= zpq_lz77_bound(n). */
+typedef struct zpq_lz77_job {
+  const uint8_t* d_in;   /* device; readable for 16 bytes past n */
+  uint32_t n;            /* <= 2^(20+args[0]) */
+  int32_t args[9];
+  uint8_t* d_out;        /* device */
+  uint32_t out_cap;
+  uint32_t out_len;      /* result */
+  uint32_t n_matches;    /* result (diagnostic) */
+} zpq_lz77_job;
+size_t zpq_lz77_bound(size_t n);
+int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs);
+/* Inverse (what the level-1 PCOMP does): d_in/n = code stream, rb = max(args[0]-4,0). */
+typedef struct zpq_lz77_dec_job {
+  const uint8_t* d_in;
+  uint32_t n;
+  uint32_t rb;
+  uint8_t* d_out;
+  uint32_t out_cap;
+  uint32_t out_len;      /* result */
+  int32_t status;        /* result: ZPQ_OK / ZPQ_ERR_FORMAT / ZPQ_ERR_CAPACITY */
+} zpq_lz77_dec_job;
+int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t njobs);
+
+/* ---- compressBlock / Decompresser for the stored + LZ77 family (rows a5, a10, a11, a15-a17) - */
+/* Mirrors libzpaq::compressBlock(in, out, method, filename, comment, dosha1)
+ * (ZSFX/libzpaq.h:1505): method is "0", "1", "LB,R,t" with L in {0,1}, or an explicit
+ * "x<N1>,0" / "x<N1>,1,<minmatch>,0,<bucket>,<hashbits>".  The framed block (13-byte tag, zPQ
+ * header, segment, stored sub-blocks, SHA-1 trailer, 255) is written to out. */
+typedef struct zpq_block_job {
+  const uint8_t* in;      /* block input: device pointer for *_dev, host pointer otherwise */
+  uint32_t n;
+  const char* method;     /* host C string */
+  const char* filename;   /* host C string or NULL */
+  const char* comment;    /* host C string or NULL (the decimal size is always prepended) */
+  int32_t dosha1;
+  uint8_t* out;           /* device (dev variant) or host */
+  uint32_t out_cap;       /* >= zpq_block_bound(n, filename, comment) */
+  uint32_t out_len;       /* result */
+  int32_t status;         /* result, per block */
+} zpq_block_job;
+size_t zpq_block_bound(size_t n, const char* filename, const char* comment);
+int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs);
+int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs);
+
+/* One framed block (first segment) in, original bytes out; status ZPQ_ERR_CHECKSUM if the stored
+ * SHA-1 does not match and verify != 0.  Blocks with context-model components or an unknown
+ * PCOMP program give ZPQ_ERR_METHOD. */
+typedef struct zpq_unblock_job {
+  const uint8_t* in;      /* framed block bytes (device for *_dev, else host) */
+  uint32_t n;
+  uint8_t* out;
+  uint32_t out_cap;
+  uint32_t out_len;       /* result */
+  uint32_t consumed;      /* result: bytes of `in` that made up the block */
+  int32_t status;         /* result */
+  uint8_t sha1[20];       /* result: SHA-1 of the decoded bytes */
+} zpq_unblock_job;
+int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZPAQHIP_H */

@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+include/zpaqhip.h declares, and refuses to run without a gfx950 device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from zpaqfranz_amd import build, engine
+    build.build(verbose=False)
+    return engine.load()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "zpaqhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(zpq_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_status_strings(lib):
+    assert lib.zpq_strerror(0) == b"ok"
+    for code in range(-8, 0):
+        assert lib.zpq_strerror(code) not in (b"", b"unknown status")
+
+
+def test_bounds_are_monotone(lib):
+    assert lib.zpq_lz77_bound(0) >= 16
+    assert lib.zpq_lz77_bound(1 << 24) >= (1 << 24) + (1 << 24) // 4096 * 4
+    assert lib.zpq_block_bound(1000, b"name", b"c") > lib.zpq_lz77_bound(1000)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU zpq_create must fail loudly; with one, this test is skipped."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = ctypes.c_void_p()
+    rc = lib.zpq_create(0, ctypes.byref(ctx))
+    assert rc == -1 and not ctx.value
+    from zpaqfranz_amd import Engine, ZpqError
+    with pytest.raises(ZpqError):
+        Engine(0)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under zpaqfranz_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("zpaqfranz_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep):
+                continue
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="replace").read()
+                    if re.search(r"liboracle|libzpaqref|oracle/|import orc|from orc", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,252 @@
+"""GPU parity tests: every result of the HIP engine (through the C ABI, include/zpaqhip.h) must be
+bit-identical to the CPU oracle (oracle/zpaq_oracle.cpp, itself pinned to the reference) and to the
+reference's golden fixture.  Run on the MI355X box: python -m pytest tests -m gpu"""
+import ctypes as C
+import json
+import lzma
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import datagen
+import orc
+
+pytestmark = pytest.mark.gpu
+G = orc.GOLDEN
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zpaqfranz_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def dplain():
+    return lzma.decompress(open(os.path.join(G, "dblock_plain.xz"), "rb").read())
+
+
+# ---------------------------------------------------------------------------------------------------
+# rows a2 / a18: SHA-1, SHA-256
+# ---------------------------------------------------------------------------------------------------
+def test_sha_padding_edges(eng):
+    bufs = [datagen.random_bytes(n, n + 1) for n in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1000, 4096, 65537)]
+    assert eng.sha1_many(bufs) == [orc.sha1(b) for b in bufs]
+    assert eng.sha256_many(bufs) == [orc.sha256(b) for b in bufs]
+
+
+def test_sha_many_ragged(eng):
+    rng = np.random.default_rng(5)
+    bufs = [datagen.random_bytes(int(rng.integers(0, 300000)), 100 + i) for i in range(700)]
+    assert eng.sha1_many(bufs) == [orc.sha1(b) for b in bufs]
+    assert eng.sha256_many(bufs[:200]) == [orc.sha256(b) for b in bufs[:200]]
+
+
+def test_sha256_fixture_known_answers(eng, dplain):
+    """AUTOTEST/README.txt:42-297: 256 files of 37 000 bytes named by their SHA-256."""
+    names = []
+    for k in (1, 2, 3):
+        ib = open(os.path.join(G, "iblock%d.bin" % k), "rb").read()
+        p = 0
+        while p < len(ib):
+            date = struct.unpack("<q", ib[p:p + 8])[0]; p += 8
+            e = ib.index(b"\0", p); name = ib[p:e]; p = e + 1
+            if date:
+                na = struct.unpack("<I", ib[p:p + 4])[0]; p += 4 + na
+                ni = struct.unpack("<I", ib[p:p + 4])[0]; p += 4 + 4 * ni
+                names.append(os.path.basename(name.decode("latin1")).split(".")[0].lower())
+    files = [dplain[i * 37000:(i + 1) * 37000] for i in range(256)]
+    got = sorted(d.hex() for d in eng.sha256_many(files))
+    assert got == sorted(names)
+
+
+# ---------------------------------------------------------------------------------------------------
+# row a1: fragmenter
+# ---------------------------------------------------------------------------------------------------
+def _oracle_frags(files, fragment=6, minf=4096, maxf=520192):
+    out = []
+    for fi, f in enumerate(files):
+        off = 0
+        for ln in orc.chunk(f, fragment, minf, maxf):
+            out.append((fi, off, ln))
+            off += ln
+    return out
+
+
+def test_fragmenter_fixture(eng, dplain):
+    """All 388 fragment records of the golden h block (sizes AND SHA-1s), 256 files in one call."""
+    h = open(os.path.join(G, "hblock_plain.bin"), "rb").read()
+    want = [(h[4 + 24 * i: 24 + 24 * i], struct.unpack("<I", h[24 + 24 * i: 28 + 24 * i])[0]) for i in range(388)]
+    files = [dplain[i * 37000:(i + 1) * 37000] for i in range(256)]
+    frags = eng.fragment_files(files)
+    assert [ln for _, _, ln in frags] == [u for _, u in want]
+    digs = eng.sha1_many([files[f][o:o + ln] for f, o, ln in frags])
+    assert digs == [s for s, _ in want]
+
+
+def test_fragmenter_edge_cases(eng):
+    files = [b"", b"a", bytes(5000), bytes(3 << 20), datagen.text_like(70000, 1), b"", datagen.random_bytes(4096, 2),
+             datagen.random_bytes(4097, 3), b"ab" * 400000, datagen.binary_like(1 << 20, 4), b"x" * 4095,
+             datagen.mixed((1 << 20) + 12345, 5), datagen.mixed(3 * (1 << 20), 6), datagen.text_like((1 << 20) - 1, 7),
+             datagen.text_like(1 << 20, 8), datagen.random_bytes((2 << 20) + 1, 9)]
+    assert eng.fragment_files(files) == _oracle_frags(files)
+
+
+def test_fragmenter_multi_segment_file(eng):
+    """A 24 MiB file spans 24 speculative segments: the stitcher must reproduce the serial chain."""
+    f = datagen.mixed(24 << 20, 11)
+    assert eng.fragment_files([f]) == _oracle_frags([f])
+
+
+def test_fragmenter_never_synchronising_input(eng):
+    """Zeros cut only at MAX: speculative and true chains never meet (worst case, still exact)."""
+    f = bytes(5 * (1 << 20) + 777)
+    assert eng.fragment_files([f]) == _oracle_frags([f])
+
+
+@pytest.mark.parametrize("fragment,minf,maxf", [(0, 64, 8128), (3, 512, 65024), (6, 4096, 520192), (8, 16384, 2080768)])
+def test_fragmenter_other_fragment_settings(eng, fragment, minf, maxf):
+    files = [datagen.mixed(3 << 20, 21), datagen.text_like(200000, 22), datagen.binary_like(1500000, 23)]
+    p = eng.fragment_params(fragment, minf, maxf)
+    assert eng.fragment_files(files, p) == _oracle_frags(files, fragment, minf, maxf)
+
+
+# ---------------------------------------------------------------------------------------------------
+# row a3: dedup
+# ---------------------------------------------------------------------------------------------------
+def test_dedup_first_occurrence(eng):
+    rng = np.random.default_rng(3)
+    uniq = [orc.sha1(struct.pack("<I", i)) for i in range(5000)]
+    idx = rng.integers(0, 5000, size=60000)
+    dig = b"".join(uniq[i] for i in idx)
+    d_dig = eng.upload(dig)
+    d_first = eng.alloc(4 * len(idx))
+    eng.dedup_dev(d_dig.ptr, len(idx), d_first.ptr)
+    eng.sync()
+    got = struct.unpack("<%dI" % len(idx), d_first.download(4 * len(idx)))
+    seen, want = {}, []
+    for k, i in enumerate(idx):
+        want.append(seen.setdefault(int(i), k))
+    d_dig.free(); d_first.free()
+    assert list(got) == want
+
+
+# ---------------------------------------------------------------------------------------------------
+# row a8: LZ77 level 1
+# ---------------------------------------------------------------------------------------------------
+LZ_INPUTS = {
+    "empty": b"", "one": b"a", "tiny": b"abcabcabcabcabcabcabcabc", "nine": b"123456789",
+    "zeros": bytes(200000), "text": datagen.text_like(400000, 1), "binary": datagen.binary_like(400000, 2),
+    "mixed": datagen.mixed(600000, 3), "random": datagen.random_bytes(150000, 4),
+    "runs": b"ab" * 3000 + b"x" + b"ab" * 30000 + bytes(range(256)) * 40,
+}
+
+
+def _argsets():
+    out = []
+    for a0 in (0, 4):
+        htsz = 19 + a0 + (a0 <= 6)
+        out += [[a0, 1, 4, 0, 1, 15], [a0, 1, 4, 0, 2, 16], [a0, 1, 4, 0, 2, htsz], [a0, 1, 5, 0, 3, htsz], [a0, 1, 6, 0, 3, htsz]]
+    return out
+
+
+@pytest.mark.parametrize("args", _argsets(), ids=lambda a: ",".join(map(str, a)))
+def test_lz77_streams_bit_identical(eng, args):
+    names = list(LZ_INPUTS)
+    got = eng.lz77_encode([LZ_INPUTS[k] for k in names], [args] * len(names))
+    for k, g in zip(names, got):
+        want, trace = orc.lz77_encode(LZ_INPUTS[k], args, trace=True)
+        assert len(g) == len(want), (k, len(g), len(want))
+        assert g == want, k
+
+
+def test_lz77_long_matches_and_literal_limit(eng):
+    rng = np.random.default_rng(9)
+    unit = rng.integers(0, 256, size=60000, dtype=np.uint8).tobytes()
+    b = unit + unit + unit[:100] + datagen.random_bytes(20000, 5) + unit
+    for args in ([0, 1, 5, 0, 3, 20], [4, 1, 5, 0, 3, 24]):
+        assert eng.lz77_encode([b], [args])[0] == orc.lz77_encode(b, args)
+
+
+def test_lz77_full_16mib_block(eng):
+    """The -m1 default block: 2^24-4096 bytes, args 4,1,5,0,3,24 (hash table 2^24)."""
+    b = datagen.mixed((1 << 24) - 4096, 77)
+    args = [4, 1, 5, 0, 3, 24]
+    got = eng.lz77_encode([b], [args])[0]
+    assert got == orc.lz77_encode(b, args)
+    st, back = eng.lz77_decode([got], [len(b)])[0]
+    assert st == 0 and back == b
+
+
+def test_lz77_decode(eng):
+    names = list(LZ_INPUTS)
+    streams = [orc.lz77_encode(LZ_INPUTS[k], [0, 1, 5, 0, 3, 20]) for k in names]
+    res = eng.lz77_decode(streams, [len(LZ_INPUTS[k]) + 8 for k in names])
+    for k, (st, data) in zip(names, res):
+        assert st == 0 and data == LZ_INPUTS[k], k
+
+
+def test_lz77_decode_fixture_iblocks(eng):
+    arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()
+    blocks = json.load(open(os.path.join(G, "blocks.json")))
+    res = eng.decompress_blocks([arc[b["offset"]:b["offset"] + b["size"]] for b in blocks if b["filename"][17] != "d"],
+                                [1 << 16] * 5)
+    plains = [struct.pack("<q", blocks[1]["size"]), open(os.path.join(G, "hblock_plain.bin"), "rb").read()] + \
+             [open(os.path.join(G, "iblock%d.bin" % k), "rb").read() for k in (1, 2, 3)]
+    for r, want, b in zip(res, plains, [b for b in blocks if b["filename"][17] != "d"]):
+        assert r["status"] == 0 and r["data"] == want and r["consumed"] == b["size"]
+        assert r["sha1"].hex() == b["sha1"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# rows a5 / a10 / a11: compressBlock framing
+# ---------------------------------------------------------------------------------------------------
+def test_compress_block_reproduces_fixture_blocks(eng):
+    arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()
+    blocks = json.load(open(os.path.join(G, "blocks.json")))
+    plains = {0: struct.pack("<q", blocks[1]["size"]), 2: open(os.path.join(G, "hblock_plain.bin"), "rb").read(),
+              3: open(os.path.join(G, "iblock1.bin"), "rb").read(), 4: open(os.path.join(G, "iblock2.bin"), "rb").read(),
+              5: open(os.path.join(G, "iblock3.bin"), "rb").read()}
+    ks = sorted(plains)
+    res = eng.compress_blocks([plains[k] for k in ks], ["1" if blocks[k]["filename"][17] == "i" else "0" for k in ks],
+                              [blocks[k]["filename"] for k in ks], ["jDC\x01"] * len(ks), True)
+    for k, (st, out) in zip(ks, res):
+        assert st == 0
+        assert out == arc[blocks[k]["offset"]:blocks[k]["offset"] + blocks[k]["size"]], blocks[k]["filename"]
+
+
+@pytest.mark.parametrize("method", ["0", "1", "14,220,0", "14,100,0", "14,30,0", "14,20,1", "14,255,1", "10,5,0", "x0,0", "x2,1,4,0,2,16"])
+def test_compress_block_equals_oracle(eng, method):
+    ins = [b"", b"abc", datagen.text_like(300000, 1), datagen.binary_like(200000, 2), bytes(100000), datagen.mixed(70000, 3)]
+    fns = ["jDC20240101000000d%010d" % (i + 1) for i in range(len(ins))]
+    res = eng.compress_blocks(ins, [method] * len(ins), fns, ["jDC\x01"] * len(ins), True)
+    for b, fn, (st, out) in zip(ins, fns, res):
+        want, _ = orc.compress_block(b, method, fn, "jDC\x01", True)
+        assert st == 0 and out == want
+    back = eng.decompress_blocks([o for _, o in res], [len(b) + 8 for b in ins])
+    for b, r in zip(ins, back):
+        assert r["status"] == 0 and r["data"] == b and r["sha1"] == orc.sha1(b)
+
+
+def test_compress_block_without_sha1_and_comment(eng):
+    b = datagen.text_like(50000, 9)
+    (st, out), = eng.compress_blocks([b], ["1"], None, None, False)
+    want, _ = orc.compress_block(b, "1", None, None, False)
+    assert st == 0 and out == want
+
+
+def test_unsupported_methods_are_refused_not_approximated(eng):
+    res = eng.compress_blocks([b"hello world" * 100] * 3, ["3", "14,100,2", "x4,3ci1"], None, None, True)
+    assert [st for st, _ in res] == [-5, -5, -5]
+
+
+def test_corrupt_block_is_detected(eng):
+    b = datagen.text_like(50000, 10)
+    (st, out), = eng.compress_blocks([b], ["1"], ["f"], None, True)
+    bad = bytearray(out); bad[len(bad) // 2] ^= 0x55
+    r, = eng.decompress_blocks([bytes(bad)], [len(b) + 64])
+    assert r["status"] != 0 or r["data"] != b

@@ -1,0 +1,49 @@
+"""Builds libzpaqhip.so (the C-ABI engine, include/zpaqhip.h) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but ships to the GPU box with
+the gpurun snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libzpaqhip.so")
+SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "dedup.hip", "lz77.hip", "block.hip"]
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(ROOT, "include", "zpaqhip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return SO
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+               "-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    subprocess.check_call(cmd)
+    if verbose:
+        print("built", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

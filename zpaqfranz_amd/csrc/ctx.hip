@@ -1,0 +1,143 @@
+// Context, error reporting and device-memory helpers of the C ABI (include/zpaqhip.h).
+#include <stdarg.h>
+
+#include "zpq_internal.h"
+
+int zpq_fail(zpq_ctx* ctx, int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return status;
+}
+
+void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes) {
+  if (bytes <= ctx->scratch_cap[slot] && ctx->scratch[slot]) return ctx->scratch[slot];
+  if (ctx->scratch[slot]) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipFree(ctx->scratch[slot]); }
+  size_t cap = bytes + bytes / 4 + 4096;
+  void* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) { ctx->scratch[slot] = nullptr; ctx->scratch_cap[slot] = 0; return nullptr; }
+  ctx->scratch[slot] = p;
+  ctx->scratch_cap[slot] = cap;
+  return p;
+}
+
+void* zpq_pinned(zpq_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_cap && ctx->pinned) return ctx->pinned;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  size_t cap = bytes + bytes / 4 + 4096;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { ctx->pinned = nullptr; ctx->pinned_cap = 0; return nullptr; }
+  ctx->pinned = p;
+  ctx->pinned_cap = cap;
+  return p;
+}
+
+extern "C" {
+
+int zpq_create(int device_ordinal, zpq_ctx** out) {
+  if (!out) return ZPQ_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZPQ_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= ndev) return ZPQ_ERR_ARG;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return ZPQ_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return ZPQ_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZPQ_ERR_NO_DEVICE;  // kernels are gfx950-only
+  zpq_ctx* c = new zpq_ctx();
+  c->device = device_ordinal;
+  c->cu_count = prop.multiProcessorCount;
+  for (int i = 0; i < 12; ++i) c->scratch[i] = nullptr, c->scratch_cap[i] = 0;
+  c->pinned = nullptr;
+  c->pinned_cap = 0;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return ZPQ_ERR_HIP;
+  }
+  *out = c;
+  return ZPQ_OK;
+}
+
+void zpq_destroy(zpq_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream2);
+  for (int i = 0; i < 12; ++i)
+    if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipEventDestroy(ctx->ev);
+  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream2);
+  delete ctx;
+}
+
+const char* zpq_strerror(int status) {
+  switch (status) {
+    case ZPQ_OK: return "ok";
+    case ZPQ_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    case ZPQ_ERR_HIP: return "HIP runtime error";
+    case ZPQ_ERR_ARG: return "invalid argument";
+    case ZPQ_ERR_CAPACITY: return "output capacity too small";
+    case ZPQ_ERR_METHOD: return "method not implemented by this engine";
+    case ZPQ_ERR_FORMAT: return "malformed ZPAQ block";
+    case ZPQ_ERR_CHECKSUM: return "SHA-1 mismatch";
+    case ZPQ_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char* zpq_last_error(const zpq_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int zpq_sync(zpq_ctx* ctx) {
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  return ZPQ_OK;
+}
+
+void* zpq_stream(zpq_ctx* ctx) { return (void*)ctx->stream; }
+
+int zpq_device_info(zpq_ctx* ctx, int64_t info[6], char* name, size_t name_cap) {
+  hipDeviceProp_t prop;
+  ZPQ_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  info[0] = prop.multiProcessorCount;
+  info[1] = prop.clockRate;
+  info[2] = prop.memoryClockRate;
+  info[3] = prop.memoryBusWidth;
+  info[4] = prop.l2CacheSize;
+  info[5] = (int64_t)(prop.totalGlobalMem >> 20);
+  if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  return ZPQ_OK;
+}
+
+int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr) {
+  ZPQ_HIP(ctx, hipSetDevice(ctx->device));
+  if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", bytes);
+  return ZPQ_OK;
+}
+int zpq_dev_free(zpq_ctx* ctx, void* dptr) {
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZPQ_HIP(ctx, hipFree(dptr));
+  return ZPQ_OK;
+}
+int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  ZPQ_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZPQ_OK;
+}
+int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  ZPQ_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZPQ_OK;
+}
+int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+  ZPQ_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+  return ZPQ_OK;
+}
+
+}  // extern "C"

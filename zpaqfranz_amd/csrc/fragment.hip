@@ -1,0 +1,334 @@
+// Content-defined fragmenter: the per-byte loop of Jidac::add
+//     h = (h + c + 1) * (c == o1[c1] ? 314159265 : 271828182);  o1[c1] = c;  c1 = c;
+//     cut when sz >= MAX || (h < 2^(22-fragment) && sz >= MIN) || EOF       (state reset per fragment)
+// (reference: zpaqfranz.cpp is absent from the snapshot; algorithm per SURVEY.md Appendix C.4, its
+// output records are read back at ZSFX/zsfx.cpp:1463-1500 and pinned by AUTOTEST/sha256.zpaq).
+//
+// MI355X formulation -- exact, no heuristics:
+//  * Inside a fragment a WAVE evaluates 64 consecutive bytes per step.  The order-1 prediction
+//    o1[c1] of lane l is the successor of the latest earlier occurrence of its predecessor byte:
+//    either an earlier lane of the same window (found with one 64-bit LDS atomic-OR mask per byte
+//    value) or the 256-entry LDS table as of the window start.  The hash recurrence is the affine
+//    map h -> m*h + (c+1)*m (mod 2^32); a wave-wide inclusive scan composes the 64 maps, so all 64
+//    hash values, and therefore the first cut in the window, come out of ~6 shuffle steps.
+//  * Across a file the chain "cut k decides where fragment k+1 starts" is serial.  Files are split
+//    into 1 MiB segments; every segment is fragmented speculatively from its own start
+//    (fragment_spec_kernel, one wave per segment), then one wave per file walks the true chain
+//    (fragment_stitch_kernel): it evaluates exactly until one of its cuts coincides with a
+//    speculative cut -- from there on both chains are in the same (reset) state, so the rest of
+//    that segment's speculative cuts are adopted verbatim.  Worst case (never coinciding, e.g. a
+//    file of zeros) degrades to one wave per file, still exact.
+// Integer-only byte work; bound by VALU/LDS issue, traffic = input read ~1.1x (seam re-reads).
+#include <algorithm>
+
+#include "zpq_internal.h"
+
+namespace {
+
+constexpr u64 kSegBytes = 1ull << 20;
+constexpr u64 kNone = ~0ull;
+
+struct FragP {
+  u32 minf, maxf, thresh;  // thresh = 2^(22-fragment) or 0 when fragment > 22
+};
+
+struct WaveLds {
+  unsigned long long M[256];  // per predecessor value: mask of lanes (this window) having it
+  u32 O[64];                  // o1[] packed 4 entries per word
+};
+
+// Streams a byte range through three 256-byte register chunks (one aligned dword per lane each),
+// prefetched two chunks ahead; get() hands lane l the byte at pos+l.
+struct ByteReader {
+  const u8* data;
+  u64 readable;  // bytes of `data` that may be touched (multiple of 4)
+  u64 cb;        // offset of chunk r0 (multiple of 4)
+  u32 r0, r1, r2;
+  __device__ __forceinline__ u32 load(u64 off) const {
+    u64 a = off + 4u * (u32)lane_id();
+    return a + 4 <= readable ? *(const u32*)(data + a) : 0u;
+  }
+  __device__ __forceinline__ void init(u64 pos) {
+    cb = pos & ~3ull;
+    r0 = load(cb); r1 = load(cb + 256); r2 = load(cb + 512);
+  }
+  __device__ __forceinline__ void advance_to(u64 pos) {
+    while (pos >= cb + 256) { r0 = r1; r1 = r2; cb += 256; r2 = load(cb + 512); }
+  }
+  __device__ __forceinline__ u32 get(u64 pos) const {  // requires cb <= pos < cb+256
+    u32 idx = (u32)(pos - cb) + (u32)lane_id();
+    u32 src = idx >> 2;
+    u32 v0 = __shfl(r0, (int)(src & 63)), v1 = __shfl(r1, (int)(src & 63));
+    u32 v = src < 64 ? v0 : v1;
+    return (v >> ((idx & 3) * 8)) & 255u;
+  }
+};
+
+__device__ __forceinline__ void reset_o1(WaveLds& L) {
+  L.O[lane_id()] = 0;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Evaluates the fragment that starts at S (fresh state) and returns the offset E of its last byte,
+// or kNone if no cut was found before `stop` (speculative callers stop at their segment end).
+__device__ u64 eval_fragment(ByteReader& rd, WaveLds& L, u64 S, u64 file_end, u64 stop, const FragP P) {
+  const int lane = lane_id();
+  volatile unsigned long long* M = L.M;
+  volatile u8* O = (volatile u8*)L.O;
+  reset_o1(L);
+  u64 pos = S;
+  u32 hin = 0, c1in = 0;
+  for (;;) {
+    if (pos >= stop) return kNone;
+    rd.advance_to(pos);
+    const u64 q = pos + (u64)lane;
+    const bool valid = q < file_end;
+    const u32 craw = rd.get(pos);  // shuffles inside: must run with the whole wave active
+    const u32 c = valid ? craw : 0u;
+    u32 p = __shfl_up(c, 1);
+    if (lane == 0) p = c1in;
+    if (valid) atomicOr((unsigned long long*)&L.M[p], 1ull << lane);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mask = valid ? M[p] : 0ull;
+    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+    const int k = lower ? 63 - __builtin_clzll(lower) : 0;
+    const u32 pc = __shfl(c, k);
+    const u32 pred = lower ? pc : (u32)O[p];
+    const u32 m = (valid && c == pred) ? 314159265u : 271828182u;
+    // affine map of this byte: h -> a*h + b; invalid lanes are the identity
+    u32 a = valid ? m : 1u, b = valid ? (c + 1u) * m : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      u32 alo = __shfl_up(a, d), blo = __shfl_up(b, d);
+      if (lane >= d) { b = a * blo + b; a = a * alo; }
+    }
+    const u32 h = a * hin + b;
+    const u64 sz = q - S + 1;
+    const bool cut = valid && (sz >= P.maxf || (h < P.thresh && sz >= P.minf) || q + 1 == file_end);
+    const unsigned long long cm = __ballot(cut);
+    if (valid) M[p] = 0ull;  // leave the mask table clean for the next window
+    if (cm) {
+      __builtin_amdgcn_wave_barrier();
+      u64 E = pos + (u64)__builtin_ctzll(cm);
+      return E < stop ? E : kNone;
+    }
+    if (valid && (mask >> lane) == 1ull) O[p] = (u8)c;  // latest occurrence of p in the window
+    __builtin_amdgcn_wave_barrier();
+    hin = __shfl(h, 63);
+    c1in = __shfl(c, 63);
+    pos += 64;
+  }
+}
+
+// ---- speculative pass: one wave per 1 MiB segment ---------------------------------------------
+__global__ __launch_bounds__(256) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable,
+                                                             const u64* __restrict__ file_off,
+                                                             const u32* __restrict__ seg_file,
+                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
+                                                             u32 spec_cap, u32* __restrict__ spec_rel,
+                                                             u32* __restrict__ spec_cnt) {
+  __shared__ WaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const u64 s = (u64)blockIdx.x * 4 + wave;
+  lds[wave].M[lane] = 0; lds[wave].M[lane + 64] = 0; lds[wave].M[lane + 128] = 0; lds[wave].M[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (s >= nseg) return;
+  const u32 f = seg_file[s];
+  const u64 fs = file_off[f], fe = file_off[f + 1];
+  const u64 g = fs + (s - seg_base[f]) * kSegBytes;
+  const u64 ge = g + kSegBytes < fe ? g + kSegBytes : fe;
+  ByteReader rd{data, readable, 0, 0, 0, 0};
+  rd.init(g);
+  u32* out = spec_rel + s * (u64)spec_cap;
+  u32 cnt = 0;
+  u64 S = g;
+  while (S < ge) {
+    u64 E = eval_fragment(rd, lds[wave], S, fe, ge, P);
+    if (E == kNone) break;
+    if (lane == 0 && cnt < spec_cap) out[cnt] = (u32)(E - g);
+    ++cnt;
+    S = E + 1;
+  }
+  if (lane == 0) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;
+}
+
+// ---- exact chain: one wave per file -------------------------------------------------------------
+__global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restrict__ data, u64 readable,
+                                                               const u64* __restrict__ file_off, u32 nfiles,
+                                                               const u64* __restrict__ seg_base, FragP P, u32 spec_cap,
+                                                               const u32* __restrict__ spec_rel,
+                                                               const u32* __restrict__ spec_cnt,
+                                                               const u64* __restrict__ cut_base,
+                                                               u64* __restrict__ cuts, u32* __restrict__ cut_cnt) {
+  __shared__ WaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const u32 f = blockIdx.x * 4 + wave;
+  lds[wave].M[lane] = 0; lds[wave].M[lane + 64] = 0; lds[wave].M[lane + 128] = 0; lds[wave].M[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (f >= nfiles) return;
+  const u64 fs = file_off[f], fe = file_off[f + 1];
+  u64* out = cuts + cut_base[f];
+  u32 cnt = 0;
+  ByteReader rd{data, readable, 0, 0, 0, 0};
+  u64 S = fs;
+  bool sync = true, rd_ready = false;
+  while (S < fe) {
+    if (sync) {
+      // adopt the speculative cuts of S's segment that lie at or after S
+      const u64 k = (S - fs) / kSegBytes;
+      const u64 sidx = seg_base[f] + k;
+      const u64 g = fs + k * kSegBytes;
+      const u32 nk = spec_cnt[sidx];
+      const u32* rel = spec_rel + sidx * (u64)spec_cap;
+      u32 j0 = 0;
+      for (u32 j = lane; j < nk; j += 64) j0 += (g + rel[j] < S) ? 1u : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) j0 += __shfl_xor(j0, d);
+      for (u32 j = j0 + lane; j < nk; j += 64) out[cnt + (j - j0)] = g + rel[j];
+      if (nk > j0) { S = g + rel[nk - 1] + 1; cnt += nk - j0; }
+      sync = false;
+      if (S >= fe) break;
+      if ((S - fs) % kSegBytes == 0) { sync = true; continue; }
+      rd_ready = false;
+    }
+    if (!rd_ready) { rd.init(S); rd_ready = true; }
+    const u64 E = eval_fragment(rd, lds[wave], S, fe, kNone, P);
+    if (lane == 0) out[cnt] = E;
+    ++cnt;
+    S = E + 1;
+    if (S >= fe) break;
+    if ((S - fs) % kSegBytes == 0) { sync = true; continue; }
+    // does E coincide with a speculative cut of its segment?
+    const u64 k2 = (E - fs) / kSegBytes;
+    const u64 sidx2 = seg_base[f] + k2;
+    const u32 n2 = spec_cnt[sidx2];
+    const u32* rel2 = spec_rel + sidx2 * (u64)spec_cap;
+    const u32 want = (u32)(E - (fs + k2 * kSegBytes));
+    bool found = false;
+    for (u32 j = lane; j < n2; j += 64) found |= rel2[j] == want;
+    sync = __ballot(found) != 0ull;
+  }
+  if (lane == 0) cut_cnt[f] = cnt;
+}
+
+// ---- compaction: per-file cut lists -> global fragment records ----------------------------------
+__global__ __launch_bounds__(256) void fragment_emit_kernel(const u64* __restrict__ file_off, u32 nfiles,
+                                                             const u64* __restrict__ cut_base,
+                                                             const u64* __restrict__ cuts,
+                                                             const u32* __restrict__ cut_cnt,
+                                                             const u64* __restrict__ frag_base,
+                                                             u64* __restrict__ frag_off, u32* __restrict__ frag_len,
+                                                             u32* __restrict__ frag_file) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const u32 f = blockIdx.x * 4 + wave;
+  if (f >= nfiles) return;
+  const u64* c = cuts + cut_base[f];
+  const u32 n = cut_cnt[f];
+  const u64 fb = frag_base[f];
+  for (u32 j = lane; j < n; j += 64) {
+    const u64 start = j ? c[j - 1] + 1 : file_off[f];
+    frag_off[fb + j] = start;
+    frag_len[fb + j] = (u32)(c[j] + 1 - start);
+    frag_file[fb + j] = f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void zpq_fragment_params_default(zpq_fragment_params* p) {
+  p->fragment_log2 = 6;
+  p->min_fragment = 64u << 6;
+  p->max_fragment = 8128u << 6;
+}
+
+size_t zpq_fragment_capacity(const uint64_t* file_off, size_t nfiles, const zpq_fragment_params* p) {
+  size_t cap = 0;
+  const u64 minf = p->min_fragment ? p->min_fragment : 1;
+  for (size_t f = 0; f < nfiles; ++f) {
+    u64 len = file_off[f + 1] - file_off[f];
+    cap += (size_t)(len / minf + 1);
+  }
+  return cap;
+}
+
+int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                     const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
+                     size_t frag_cap, size_t* nfrags) {
+  if (!ctx || !file_off || !p || !nfrags) return ZPQ_ERR_ARG;
+  *nfrags = 0;
+  if (nfiles == 0) return ZPQ_OK;
+  if (nfiles > 0x7fffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many files");
+  if (((uintptr_t)d_base & 15) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "d_base must be 16-byte aligned");
+  if (p->min_fragment == 0 || p->max_fragment < p->min_fragment) return zpq_fail(ctx, ZPQ_ERR_ARG, "bad fragment limits");
+  FragP P;
+  P.minf = p->min_fragment; P.maxf = p->max_fragment;
+  P.thresh = p->fragment_log2 <= 22 ? 1u << (22 - p->fragment_log2) : 0u;
+  const u64 total = file_off[nfiles];
+  const u64 readable = (total + 3) & ~3ull;  // callers pad allocations by >= 16 bytes (see header)
+
+  // host-side segment and capacity tables
+  std::vector<u64> seg_base(nfiles + 1), cut_base(nfiles + 1);
+  u64 nseg = 0, ncut = 0;
+  for (size_t f = 0; f < nfiles; ++f) {
+    if (file_off[f + 1] < file_off[f]) return zpq_fail(ctx, ZPQ_ERR_ARG, "file_off not monotone");
+    u64 len = file_off[f + 1] - file_off[f];
+    seg_base[f] = nseg; cut_base[f] = ncut;
+    nseg += (len + kSegBytes - 1) / kSegBytes;
+    ncut += len / P.minf + 1;
+  }
+  seg_base[nfiles] = nseg; cut_base[nfiles] = ncut;
+  if (nseg == 0) return ZPQ_OK;
+  std::vector<u32> seg_file(nseg);
+  for (size_t f = 0; f < nfiles; ++f)
+    for (u64 s = seg_base[f]; s < seg_base[f + 1]; ++s) seg_file[s] = (u32)f;
+  const u32 spec_cap = (u32)(kSegBytes / P.minf + 2);
+
+  // device scratch: [file_off | seg_base | cut_base | frag_base | seg_file | spec_cnt | cut_cnt] , spec_rel, cuts
+  const size_t nf1 = nfiles + 1;
+  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 256;
+  u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
+  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4);
+  u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
+  if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
+  u64* d_file_off = (u64*)meta;
+  u64* d_seg_base = d_file_off + nf1;
+  u64* d_cut_base = d_seg_base + nf1;
+  u64* d_frag_base = d_cut_base + nf1;
+  u32* d_seg_file = (u32*)(d_frag_base + nf1);
+  u32* d_spec_cnt = d_seg_file + nseg;
+  u32* d_cut_cnt = d_spec_cnt + nseg;
+  hipStream_t st = ctx->stream;
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_file_off, file_off, nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_base, seg_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
+
+  hipLaunchKernelGGL(fragment_spec_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, d_base, readable,
+                     d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
+  ZPQ_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), 0, st, d_base, readable,
+                     d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cut_base, d_cuts,
+                     d_cut_cnt);
+  ZPQ_HIP(ctx, hipGetLastError());
+
+  // per-file counts -> exclusive prefix on the host (nfiles words; the data never leaves HBM)
+  std::vector<u32> cnt(nfiles);
+  ZPQ_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cut_cnt, nfiles * 4, hipMemcpyDeviceToHost, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  std::vector<u64> frag_base(nf1);
+  u64 nf = 0;
+  for (size_t f = 0; f < nfiles; ++f) { frag_base[f] = nf; nf += cnt[f]; }
+  frag_base[nfiles] = nf;
+  *nfrags = (size_t)nf;
+  if (nf > frag_cap) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "fragment capacity %zu < %llu", frag_cap, (unsigned long long)nf);
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_frag_base, frag_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fragment_emit_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), 0, st, d_file_off,
+                     (u32)nfiles, d_cut_base, d_cuts, d_cut_cnt, d_frag_base, d_frag_off, d_frag_len, d_frag_file);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  return ZPQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// SHA-1 / SHA-256 over many extents: one Merkle-Damgard chain per LANE, persistent lanes that pull
+// the next extent from a device counter when theirs is finished (fragments are 4 KiB..508 KiB, so a
+// static extent->lane map would idle most of a wave behind its longest fragment).
+//
+// Replaces libzpaq::SHA1 / SHA256 (reference ZSFX/libzpaq.h:934-979, ZSFX/libzpaq.cpp:96-304) as used
+// for fragment ids (ZSFX/zsfx.cpp:1463-1500, 1811-1834), segment checksums (ZSFX/libzpaq.cpp:2338-2366)
+// and file verification.  Integer-only (u32 adds, rotates, boolean functions): no MFMA applies.
+// Bound: VALU issue (~14 ops per input byte); traffic = each input byte read once.
+#include "zpq_internal.h"
+
+namespace {
+
+struct Sha1State { u32 a, b, c, d, e; };
+
+__device__ __forceinline__ void sha1_rounds(u32 (&w)[16], Sha1State& s) {
+  u32 a = s.a, b = s.b, c = s.c, d = s.d, e = s.e;
+#define W(t) (w[(t) & 15] = rotl32(w[((t) + 13) & 15] ^ w[((t) + 8) & 15] ^ w[((t) + 2) & 15] ^ w[(t) & 15], 1))
+#define R(f, k, wt)                                  \
+  {                                                  \
+    u32 tmp = rotl32(a, 5) + (f) + e + (k) + (wt);   \
+    e = d; d = c; c = rotl32(b, 30); b = a; a = tmp; \
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) R((b & c) | (~b & d), 0x5A827999u, w[t])
+#pragma unroll
+  for (int t = 16; t < 20; ++t) R((b & c) | (~b & d), 0x5A827999u, W(t))
+#pragma unroll
+  for (int t = 20; t < 40; ++t) R(b ^ c ^ d, 0x6ED9EBA1u, W(t))
+#pragma unroll
+  for (int t = 40; t < 60; ++t) R((b & c) | (b & d) | (c & d), 0x8F1BBCDCu, W(t))
+#pragma unroll
+  for (int t = 60; t < 80; ++t) R(b ^ c ^ d, 0xCA62C1D6u, W(t))
+#undef R
+#undef W
+  s.a += a; s.b += b; s.c += c; s.d += d; s.e += e;
+}
+
+// Builds the (at most two) closing blocks of a message: `rem` (<64) trailing data bytes at p, the
+// 0x80 marker unless already emitted, zero fill, and the 64-bit big-endian bit count when it fits.
+// Returns true when this block is the last one of the message.
+__device__ __forceinline__ bool tail_block(u32 (&w)[16], const u8* p, u32 rem, bool& marker_done, u64 total_bytes) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    u32 x = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      u32 j = 4 * t + b, v = 0;
+      if (j < rem) v = p[j];
+      else if (j == rem && !marker_done) v = 0x80;
+      x = (x << 8) | v;
+    }
+    w[t] = x;
+  }
+  bool fits = marker_done ? true : rem <= 55;
+  marker_done = true;
+  if (fits) {
+    u64 bits = total_bytes * 8;
+    w[14] = (u32)(bits >> 32);
+    w[15] = (u32)bits;
+  }
+  return fits;
+}
+
+__global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                            const u32* __restrict__ len, u32 n, u8* __restrict__ digests,
+                                                            u32* __restrict__ counter) {
+  // One flat loop: a lane that finishes its extent immediately pulls the next one while its
+  // neighbours keep hashing (no per-extent inner loop to re-converge on).
+  bool have = false, marker = false;
+  u32 idx = 0;
+  const u8* p = nullptr;
+  u64 total = 0, rem = 0;
+  Sha1State s = {0, 0, 0, 0, 0};
+  for (;;) {
+    if (!have) {
+      idx = atomicAdd(counter, 1u);
+      if (idx >= n) return;
+      p = base + off[idx];
+      total = rem = len[idx];
+      s = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+      marker = false;
+      have = true;
+    }
+    u32 w[16];
+    bool last = false;
+    if (rem >= 64) {
+      const u32x4_u* q = (const u32x4_u*)p;
+      u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+      w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+      w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+      w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+      p += 64; rem -= 64;
+    } else {
+      last = tail_block(w, p, (u32)rem, marker, total);
+      p += rem; rem = 0;
+    }
+    sha1_rounds(w, s);
+    if (last) {
+      u32* o = (u32*)(digests + (size_t)idx * 20);  // 20*idx is 4-byte aligned
+      o[0] = bswap32(s.a); o[1] = bswap32(s.b); o[2] = bswap32(s.c); o[3] = bswap32(s.d); o[4] = bswap32(s.e);
+      have = false;
+    }
+  }
+}
+
+__constant__ u32 K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ void sha256_rounds(u32 (&w)[16], u32 (&s)[8]) {
+  u32 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    u32 wt;
+    if (t < 16) wt = w[t];
+    else {
+      u32 w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+      u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wt = w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+    }
+    u32 t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + K256[t] + wt;
+    u32 t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  s[0] += a; s[1] += b; s[2] += c; s[3] += d; s[4] += e; s[5] += f; s[6] += g; s[7] += h;
+}
+
+__global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                              const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
+                                                              u32* __restrict__ counter) {
+  bool have = false, marker = false;
+  u32 idx = 0;
+  const u8* p = nullptr;
+  u64 total = 0, rem = 0;
+  u32 s[8];
+  for (;;) {
+    if (!have) {
+      idx = atomicAdd(counter, 1u);
+      if (idx >= n) return;
+      p = base + off[idx];
+      total = rem = len[idx];
+      s[0] = 0x6a09e667; s[1] = 0xbb67ae85; s[2] = 0x3c6ef372; s[3] = 0xa54ff53a;
+      s[4] = 0x510e527f; s[5] = 0x9b05688c; s[6] = 0x1f83d9ab; s[7] = 0x5be0cd19;
+      marker = false;
+      have = true;
+    }
+    u32 w[16];
+    bool last = false;
+    if (rem >= 64) {
+      const u32x4_u* q = (const u32x4_u*)p;
+      u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+      w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+      w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+      w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+      p += 64; rem -= 64;
+    } else {
+      last = tail_block(w, p, (u32)rem, marker, total);
+      p += rem; rem = 0;
+    }
+    sha256_rounds(w, s);
+    if (last) {
+      u32* o = (u32*)(digests + (size_t)idx * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = bswap32(s[i]);
+      have = false;
+    }
+  }
+}
+
+int persistent_grid(zpq_ctx* ctx, size_t n) {
+  size_t blocks = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
+  return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+}  // namespace
+
+int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
+                        u8* d_digests) {
+  if (n == 0) return ZPQ_OK;
+  if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
+  // one counter per stream so that the two streams never share it
+  u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + (s == ctx->stream2 ? 16 : 0);
+  if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
+  hipLaunchKernelGGL(sha1_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), 0, s, d_base, d_off, d_len, (u32)n,
+                     d_digests, counter);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
+
+extern "C" {
+
+int zpq_sha1_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off, const uint32_t* d_len, size_t n,
+                         uint8_t* d_digests) {
+  return zpq_sha1_extents_on(ctx, ctx->stream, d_base, d_off, d_len, n, d_digests);
+}
+
+int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off, const uint64_t* d_len, size_t n,
+                           uint8_t* d_digests) {
+  if (n == 0) return ZPQ_OK;
+  if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
+  u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + 32;
+  if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(sha256_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), 0, ctx->stream, d_base, d_off,
+                     d_len, (u32)n, d_digests, counter);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
+
+// Host convenience wrappers: pack the buffers into one staging area, run the device path.
+static int many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n, uint8_t* digests, int dsz) {
+  if (n == 0) return ZPQ_OK;
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) total += lens[i];
+  u8* d_data = (u8*)zpq_scratch(ctx, 0, total + 64);
+  u8* d_meta = (u8*)zpq_scratch(ctx, 1, n * (8 + 8 + 32) + 64);
+  if (!d_data || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+  u64* d_off = (u64*)d_meta;
+  u64* d_len64 = d_off + n;
+  u8* d_dig = (u8*)(d_len64 + n);
+  std::vector<u64> off(n), len64(n);
+  std::vector<u32> len32(n);
+  size_t o = 0;
+  for (size_t i = 0; i < n; ++i) {
+    off[i] = o; len64[i] = lens[i]; len32[i] = (u32)lens[i];
+    if (dsz == 20 && lens[i] > 0xffffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "SHA-1 extent > 4 GiB");
+    if (lens[i]) ZPQ_HIP(ctx, hipMemcpyAsync(d_data + o, bufs[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+    o += lens[i];
+  }
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_off, off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+  int rc;
+  if (dsz == 20) {
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_len64, len32.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = zpq_sha1_extents_dev(ctx, d_data, d_off, (const u32*)d_len64, n, d_dig);
+  } else {
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_len64, len64.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = zpq_sha256_extents_dev(ctx, d_data, d_off, d_len64, n, d_dig);
+  }
+  if (rc) return rc;
+  ZPQ_HIP(ctx, hipMemcpyAsync(digests, d_dig, n * dsz, hipMemcpyDeviceToHost, ctx->stream));
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZPQ_OK;
+}
+
+int zpq_sha1_many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n, uint8_t* digests) {
+  return many(ctx, bufs, lens, n, digests, 20);
+}
+int zpq_sha256_many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n, uint8_t* digests) {
+  return many(ctx, bufs, lens, n, digests, 32);
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+"""ctypes mirror of include/zpaqhip.h.  Names, argument meaning and error behaviour follow the C ABI
+one to one; nothing here computes anything on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libzpaqhip.so")
+
+
+class ZpqError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__("zpaqhip status %d: %s" % (status, detail))
+        self.status = status
+
+
+class FragmentParams(C.Structure):
+    _fields_ = [("fragment_log2", C.c_uint32), ("min_fragment", C.c_uint32), ("max_fragment", C.c_uint32)]
+
+
+class Lz77Job(C.Structure):
+    _fields_ = [("d_in", C.c_void_p), ("n", C.c_uint32), ("args", C.c_int32 * 9), ("d_out", C.c_void_p),
+                ("out_cap", C.c_uint32), ("out_len", C.c_uint32), ("n_matches", C.c_uint32)]
+
+
+class Lz77DecJob(C.Structure):
+    _fields_ = [("d_in", C.c_void_p), ("n", C.c_uint32), ("rb", C.c_uint32), ("d_out", C.c_void_p),
+                ("out_cap", C.c_uint32), ("out_len", C.c_uint32), ("status", C.c_int32)]
+
+
+class BlockJob(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("n", C.c_uint32), ("method", C.c_char_p), ("filename", C.c_char_p),
+                ("comment", C.c_char_p), ("dosha1", C.c_int32), ("out", C.c_void_p), ("out_cap", C.c_uint32),
+                ("out_len", C.c_uint32), ("status", C.c_int32)]
+
+
+class UnblockJob(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("n", C.c_uint32), ("out", C.c_void_p), ("out_cap", C.c_uint32),
+                ("out_len", C.c_uint32), ("consumed", C.c_uint32), ("status", C.c_int32), ("sha1", C.c_uint8 * 20)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libzpaqhip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError("libzpaqhip.so is missing: run `python -m zpaqfranz_amd.build` (hipcc, gfx950)")
+    L = C.CDLL(p)
+    L.zpq_strerror.restype = C.c_char_p
+    L.zpq_last_error.restype = C.c_char_p
+    L.zpq_last_error.argtypes = [C.c_void_p]
+    L.zpq_stream.restype = C.c_void_p
+    L.zpq_stream.argtypes = [C.c_void_p]
+    for name in ("zpq_fragment_capacity", "zpq_lz77_bound", "zpq_block_bound"):
+        getattr(L, name).restype = C.c_size_t
+    L.zpq_lz77_bound.argtypes = [C.c_size_t]
+    L.zpq_block_bound.argtypes = [C.c_size_t, C.c_char_p, C.c_char_p]
+    L.zpq_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.zpq_destroy.argtypes = [C.c_void_p]
+    L.zpq_destroy.restype = None
+    L.zpq_sync.argtypes = [C.c_void_p]
+    L.zpq_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.zpq_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.zpq_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zpq_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zpq_dev_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
+    L.zpq_device_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
+    L.zpq_sha1_extents_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_sha256_extents_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_sha1_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_sha256_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_fragment_params_default.argtypes = [C.POINTER(FragmentParams)]
+    L.zpq_fragment_params_default.restype = None
+    L.zpq_fragment_capacity.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FragmentParams)]
+    L.zpq_fragment_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FragmentParams), C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_dedup_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_lz77_encode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77Job), C.c_size_t]
+    L.zpq_lz77_decode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77DecJob), C.c_size_t]
+    L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
+    L.zpq_compress_blocks.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
+    L.zpq_decompress_blocks.argtypes = [C.c_void_p, C.POINTER(UnblockJob), C.c_size_t, C.c_int]
+    _lib = L
+    return L
+
+
+class DevBuf:
+    """A device allocation owned through zpq_dev_alloc (tests use this; bench.py uses torch tensors)."""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, nbytes
+        p = C.c_void_p()
+        eng._ck(eng.L.zpq_dev_alloc(eng.ctx, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, data, offset=0):
+        b = bytes(data)
+        if b:
+            self.eng._ck(self.eng.L.zpq_h2d(self.eng.ctx, self.ptr + offset, b, len(b)))
+        return self
+
+    def download(self, nbytes=None, offset=0):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = C.create_string_buffer(max(1, nbytes))
+        if nbytes:
+            self.eng._ck(self.eng.L.zpq_d2h(self.eng.ctx, out, self.ptr + offset, nbytes))
+        return out.raw[:nbytes]
+
+    def free(self):
+        if self.ptr:
+            self.eng.L.zpq_dev_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    PAD = 64  # every data buffer is padded so that the kernels' 8/16-byte reads stay in bounds
+
+    def __init__(self, device=0):
+        self.L = load()
+        ctx = C.c_void_p()
+        rc = self.L.zpq_create(device, C.byref(ctx))
+        if rc != 0:
+            raise ZpqError(rc, self.L.zpq_strerror(rc).decode())
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            self.L.zpq_destroy(self.ctx)
+            self.ctx = None
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise ZpqError(rc, "%s (%s)" % (self.L.zpq_strerror(rc).decode(), self.L.zpq_last_error(self.ctx).decode()))
+
+    def sync(self):
+        self._ck(self.L.zpq_sync(self.ctx))
+
+    def stream(self):
+        return self.L.zpq_stream(self.ctx)
+
+    def device_info(self):
+        info = (C.c_int64 * 6)()
+        name = C.create_string_buffer(256)
+        self._ck(self.L.zpq_device_info(self.ctx, info, name, 256))
+        return dict(name=name.value.decode(), cu=info[0], clock_khz=info[1], mem_clock_khz=info[2], bus_bits=info[3],
+                    l2_bytes=info[4], hbm_mib=info[5])
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes + self.PAD)
+
+    def upload(self, data):
+        return self.alloc(len(data)).upload(data)
+
+    # ---- hashing ------------------------------------------------------------------------------
+    def sha1_many(self, bufs):
+        return self._many(bufs, 20, self.L.zpq_sha1_many)
+
+    def sha256_many(self, bufs):
+        return self._many(bufs, 32, self.L.zpq_sha256_many)
+
+    def _many(self, bufs, dsz, fn):
+        n = len(bufs)
+        keep = [C.create_string_buffer(bytes(b), max(1, len(b))) for b in bufs]
+        ptrs = (C.c_void_p * max(1, n))(*[C.cast(k, C.c_void_p).value for k in keep])
+        lens = (C.c_size_t * max(1, n))(*[len(b) for b in bufs])
+        out = C.create_string_buffer(max(1, n * dsz))
+        self._ck(fn(self.ctx, ptrs, lens, n, out))
+        return [out.raw[i * dsz:(i + 1) * dsz] for i in range(n)]
+
+    def sha1_extents_dev(self, d_base, d_off, d_len, n, d_digests):
+        self._ck(self.L.zpq_sha1_extents_dev(self.ctx, d_base, d_off, d_len, n, d_digests))
+
+    def sha256_extents_dev(self, d_base, d_off, d_len, n, d_digests):
+        self._ck(self.L.zpq_sha256_extents_dev(self.ctx, d_base, d_off, d_len, n, d_digests))
+
+    # ---- fragmenter -----------------------------------------------------------------------------
+    def fragment_params(self, fragment=6, min_fragment=None, max_fragment=None):
+        p = FragmentParams()
+        p.fragment_log2 = fragment
+        p.min_fragment = (64 << fragment) if min_fragment is None else min_fragment
+        p.max_fragment = (8128 << fragment) if max_fragment is None else max_fragment
+        return p
+
+    def fragment_capacity(self, file_off, params):
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        return self.L.zpq_fragment_capacity(arr, len(file_off) - 1, C.byref(params))
+
+    def fragment_dev(self, d_base, file_off, params, d_frag_off, d_frag_len, d_frag_file, cap):
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        n = C.c_size_t(0)
+        self._ck(self.L.zpq_fragment_dev(self.ctx, d_base, arr, len(file_off) - 1, C.byref(params), d_frag_off, d_frag_len,
+                                         d_frag_file, cap, C.byref(n)))
+        return n.value
+
+    def fragment_files(self, files, params=None):
+        """Host convenience used by the tests: list of bytes -> [(file, offset_in_file, length)]."""
+        import struct
+        params = params or self.fragment_params()
+        file_off = [0]
+        for f in files:
+            file_off.append(file_off[-1] + len(f))
+        data = self.upload(b"".join(files))
+        cap = max(1, self.fragment_capacity(file_off, params))
+        fo, fl, ff = self.alloc(cap * 8), self.alloc(cap * 4), self.alloc(cap * 4)
+        try:
+            n = self.fragment_dev(data.ptr, file_off, params, fo.ptr, fl.ptr, ff.ptr, cap)
+            offs = struct.unpack("<%dQ" % n, fo.download(n * 8))
+            lens = struct.unpack("<%dI" % n, fl.download(n * 4))
+            fil = struct.unpack("<%dI" % n, ff.download(n * 4))
+        finally:
+            for b in (data, fo, fl, ff):
+                b.free()
+        return [(fil[i], offs[i] - file_off[fil[i]], lens[i]) for i in range(n)]
+
+    def dedup_dev(self, d_digests, n, d_first):
+        self._ck(self.L.zpq_dedup_dev(self.ctx, d_digests, n, d_first))
+
+    # ---- LZ77 -----------------------------------------------------------------------------------
+    def lz77_bound(self, n):
+        return self.L.zpq_lz77_bound(n)
+
+    def lz77_encode(self, blocks, argsets):
+        """Host convenience: list of bytes + list of args[<=9] -> list of code streams."""
+        n = len(blocks)
+        jobs = (Lz77Job * max(1, n))()
+        ins, outs = [], []
+        for i, (b, a) in enumerate(zip(blocks, argsets)):
+            d_in = self.upload(b)
+            cap = (self.lz77_bound(len(b)) + 15) & ~15
+            d_out = self.alloc(cap)
+            ins.append(d_in); outs.append(d_out)
+            jobs[i].d_in, jobs[i].n, jobs[i].d_out, jobs[i].out_cap = d_in.ptr, len(b), d_out.ptr, cap
+            for k, v in enumerate((list(a) + [0] * 9)[:9]):
+                jobs[i].args[k] = v
+        try:
+            self._ck(self.L.zpq_lz77_encode_dev(self.ctx, jobs, n))
+            res = [outs[i].download(jobs[i].out_len) for i in range(n)]
+            self.last_matches = [jobs[i].n_matches for i in range(n)]
+        finally:
+            for b in ins + outs:
+                b.free()
+        return res
+
+    def lz77_decode(self, streams, out_caps, rb=0):
+        n = len(streams)
+        jobs = (Lz77DecJob * max(1, n))()
+        ins, outs = [], []
+        for i, s in enumerate(streams):
+            d_in = self.upload(s)
+            d_out = self.alloc(out_caps[i])
+            ins.append(d_in); outs.append(d_out)
+            jobs[i].d_in, jobs[i].n, jobs[i].rb, jobs[i].d_out, jobs[i].out_cap = d_in.ptr, len(s), rb, d_out.ptr, out_caps[i]
+        try:
+            self._ck(self.L.zpq_lz77_decode_dev(self.ctx, jobs, n))
+            res = [(jobs[i].status, outs[i].download(jobs[i].out_len)) for i in range(n)]
+        finally:
+            for b in ins + outs:
+                b.free()
+        return res
+
+    # ---- compressBlock / Decompresser -------------------------------------------------------------
+    def block_bound(self, n, filename=None, comment=None):
+        return self.L.zpq_block_bound(n, filename, comment)
+
+    def compress_blocks(self, blocks, methods, filenames=None, comments=None, dosha1=True):
+        """Mirror of libzpaq::compressBlock for a batch of host buffers -> list of (status, framed bytes)."""
+        n = len(blocks)
+        jobs = (BlockJob * max(1, n))()
+        keep_in, keep_out = [], []
+        for i, b in enumerate(blocks):
+            fn = filenames[i] if filenames else None
+            cm = comments[i] if comments else None
+            fn = fn.encode("latin1") if isinstance(fn, str) else fn
+            cm = cm.encode("latin1") if isinstance(cm, str) else cm
+            cap = self.block_bound(len(b), fn, cm)
+            ib = C.create_string_buffer(bytes(b), max(1, len(b)))
+            ob = C.create_string_buffer(cap)
+            keep_in.append(ib); keep_out.append(ob)
+            jobs[i].in_ = C.cast(ib, C.c_void_p).value
+            jobs[i].n = len(b)
+            jobs[i].method = methods[i].encode()
+            jobs[i].filename, jobs[i].comment = fn, cm
+            jobs[i].dosha1 = int(dosha1)
+            jobs[i].out = C.cast(ob, C.c_void_p).value
+            jobs[i].out_cap = cap
+        rc = self.L.zpq_compress_blocks(self.ctx, jobs, n)
+        if rc != 0 and all(jobs[i].status == 0 for i in range(n)):
+            self._ck(rc)
+        return [(jobs[i].status, keep_out[i].raw[:jobs[i].out_len]) for i in range(n)]
+
+    def compress_blocks_dev(self, jobs, n):
+        rc = self.L.zpq_compress_blocks_dev(self.ctx, jobs, n)
+        if rc != 0:
+            self._ck(rc)
+
+    def decompress_blocks(self, framed, out_caps, verify=True):
+        n = len(framed)
+        jobs = (UnblockJob * max(1, n))()
+        keep_in, keep_out = [], []
+        for i, b in enumerate(framed):
+            ib = C.create_string_buffer(bytes(b), max(1, len(b)))
+            ob = C.create_string_buffer(max(1, out_caps[i]))
+            keep_in.append(ib); keep_out.append(ob)
+            jobs[i].in_, jobs[i].n = C.cast(ib, C.c_void_p).value, len(b)
+            jobs[i].out, jobs[i].out_cap = C.cast(ob, C.c_void_p).value, out_caps[i]
+        self.L.zpq_decompress_blocks(self.ctx, jobs, n, int(verify))
+        return [dict(status=jobs[i].status, data=keep_out[i].raw[:jobs[i].out_len], consumed=jobs[i].consumed,
+                     sha1=bytes(jobs[i].sha1)) for i in range(n)]
