@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""bench.py -- zpaqfranz "add -m1" hot path on MI355X: fragment -> SHA-1 -> dedup -> pack -> LZ77 level 1
+-> ZPAQ block framing, whole job per step, input resident in HBM.
+
+Workload (BASELINE.json configs[1]): the Silesia corpus replicated x256 (3072 files, 54 256 276 480
+bytes) at -m1 (16 MiB blocks, method "14" -> x4,1,5,0,3,24).  The real corpus cannot be fetched here, so
+a seeded synthetic corpus with Silesia's member names and sizes stands in ("data": "synthetic").
+
+One JSON line is printed by rank 0 (see the contract in the task statement).  metric/unit are
+BASELINE.json's: MB/s of compressed archive output; input-side GB/s is reported next to it because
+dedup collapses the x256 corpus to one copy before compression.
+
+N > 1 (torchrun, one rank per GPU, RCCL): weak scaling -- every rank owns its own x256 corpus (different
+seed), fragments and hashes it, the fragment tables are all-gathered over RCCL, every rank resolves the
+global first-occurrence dedup identically, blocks are packed by the one deterministic global packer and
+owned by the rank that holds their first fragment (seam fragments travel peer to peer), and the
+compressed blocks are all-gathered so that rank 0 could stitch the archive in fixed block order."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BLOCK_LIMIT = (1 << 24) - 4096   # zpaqfranz -m1: method "14" -> 2^24 - 4096 byte blocks
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def pack_blocks(uniq_len):
+    """Deterministic block packer over the unique-fragment sequence (host logic, as in the reference's
+    Jidac::add): a block takes fragments while bytes + 4*(count+1) + 8 <= BLOCK_LIMIT.  Returns the
+    block id of every unique fragment.  (The exact cut rule lives in the missing zpaqfranz.cpp:
+    parity unpinned, see DESIGN.md.)"""
+    n = len(uniq_len)
+    blk = np.empty(n, dtype=np.int64)
+    cs = np.concatenate(([0], np.cumsum(uniq_len.astype(np.int64) + 4)))
+    i, b = 0, 0
+    while i < n:
+        j = int(np.searchsorted(cs, cs[i] + BLOCK_LIMIT - 8, side="right")) - 1
+        j = max(j, i + 1)
+        blk[i:j] = b
+        i, b = j, b + 1
+    return blk, b
+
+
+class Pipeline:
+    def __init__(self, eng, device, corpus, copies, rank, world):
+        from zpaqfranz_amd import engine as E
+        self.E, self.eng, self.dev, self.rank, self.world = E, eng, device, rank, world
+        base = b"".join(b for _, b in corpus)
+        sizes = [len(b) for _, b in corpus]
+        self.unit = len(base)
+        self.total = self.unit * copies
+        self.data = torch.empty(self.total + 64, dtype=torch.uint8, device=device)
+        hb = torch.frombuffer(bytearray(base), dtype=torch.uint8)
+        self.data[: self.unit].copy_(hb)
+        for c in range(1, copies):
+            self.data[c * self.unit:(c + 1) * self.unit].copy_(self.data[: self.unit])
+        self.data[self.total:].zero_()
+        off = [0]
+        for c in range(copies):
+            for s in sizes:
+                off.append(off[-1] + s)
+        self.file_off = off
+        self.nfiles = len(off) - 1
+        self.params = eng.fragment_params()
+        self.cap = eng.fragment_capacity(off, self.params)
+        i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+        self.frag_off = torch.empty(self.cap, dtype=i64, device=device)
+        self.frag_len = torch.empty(self.cap, dtype=i32, device=device)
+        self.frag_file = torch.empty(self.cap, dtype=i32, device=device)
+        self.digests = torch.empty(self.cap * 20 + 64, dtype=u8, device=device)
+        self.first = torch.empty(self.cap * max(1, world), dtype=i32, device=device)
+        torch.cuda.synchronize()
+
+    def step(self):
+        eng, E, dev = self.eng, self.E, self.dev
+        # 1. fragment + 2. SHA-1 of every fragment
+        nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
+                              self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
+        eng.sha1_extents_dev(self.data.data_ptr(), self.frag_off.data_ptr(), self.frag_len.data_ptr(), nf,
+                             self.digests.data_ptr())
+        eng.sync()
+        dig, flen = self.digests[: nf * 20], self.frag_len[:nf]
+        my_lo = 0
+        if self.world > 1:
+            # exchange: fragment tables (20-byte id + length) of every rank, order-preserving
+            cnt = torch.tensor([nf], dtype=torch.int64, device=dev)
+            cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+            dist.all_gather(cnts, cnt)
+            cnts = [int(c.item()) for c in cnts]
+            mx = max(cnts)
+            pad_d = torch.zeros(mx * 20, dtype=torch.uint8, device=dev); pad_d[: nf * 20] = dig
+            pad_l = torch.zeros(mx, dtype=torch.int32, device=dev); pad_l[:nf] = flen
+            gd = [torch.empty_like(pad_d) for _ in range(self.world)]
+            gl = [torch.empty_like(pad_l) for _ in range(self.world)]
+            dist.all_gather(gd, pad_d); dist.all_gather(gl, pad_l)
+            dig = torch.cat([gd[r][: cnts[r] * 20] for r in range(self.world)] + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+            flen = torch.cat([gl[r][: cnts[r]] for r in range(self.world)])
+            my_lo = sum(cnts[: self.rank])
+            ntot = sum(cnts)
+            torch.cuda.synchronize()
+        else:
+            cnts, ntot = [nf], nf
+        # 3. dedup (global first occurrence)
+        eng.dedup_dev(dig.data_ptr(), ntot, self.first.data_ptr())
+        eng.sync()
+        first = self.first[:ntot].cpu().numpy()
+        lens = flen.cpu().numpy().astype(np.int64)
+        is_new = first == np.arange(ntot, dtype=first.dtype)
+        uniq_idx = np.nonzero(is_new)[0]
+        # 4. pack (host: which unique fragment goes to which block)
+        blk, nblk = pack_blocks(lens[uniq_idx])
+        owner_of_frag = np.searchsorted(np.cumsum(cnts), uniq_idx, side="right")
+        first_in_blk = np.concatenate(([0], np.nonzero(np.diff(blk))[0] + 1))
+        blk_owner = owner_of_frag[first_in_blk]
+        mine = np.nonzero(blk_owner == self.rank)[0]
+        # block buffers of the blocks this rank owns: fragments + size table + 0 + count
+        starts = np.concatenate((first_in_blk, [len(uniq_idx)]))
+        blk_n, src_off, src_len, dst_off, trailers, foreign = [], [], [], [], [], []
+        pos = 0
+        for b in mine:
+            u = uniq_idx[starts[b]:starts[b + 1]]
+            l = lens[u]
+            o = pos + np.concatenate(([0], np.cumsum(l)[:-1]))
+            own = owner_of_frag[starts[b]:starts[b + 1]] == self.rank
+            src_off.append(u[own] - my_lo); src_len.append(l[own]); dst_off.append(o[own])
+            if not own.all():
+                foreign.append((b, u[~own], l[~own], o[~own]))
+            size = int(l.sum())
+            tr = np.concatenate((l.astype("<u4"), np.array([0, len(l)], dtype="<u4"))).tobytes()
+            trailers.append((pos + size, tr))
+            blk_n.append(size + len(tr))
+            pos += (size + len(tr) + 63 + 64) & ~63
+        blocks_buf = torch.empty(max(pos, 64), dtype=torch.uint8, device=dev)
+        if mine.size:
+            so = torch.from_numpy(np.concatenate(src_off).astype(np.int64)).to(dev)
+            sl = torch.from_numpy(np.concatenate(src_len).astype(np.int32)).to(dev)
+            do = torch.from_numpy(np.concatenate(dst_off).astype(np.int64)).to(dev)
+            abs_off = self.frag_off[:nf][so]
+            torch.cuda.synchronize()
+            eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
+                           blocks_buf.data_ptr())
+            for p, tr in trailers:
+                blocks_buf[p:p + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
+        if self.world > 1:
+            self._exchange_seams(uniq_idx, lens, blk, owner_of_frag, blk_owner, starts, cnts, nf, foreign, blocks_buf)
+        eng.sync(); torch.cuda.synchronize()
+        # 5. compressBlock on every owned block ("14": LZ77 x4,1,5,0,3,24 + framing + SHA-1)
+        nb = len(mine)
+        out_bytes = 0
+        outs = None
+        if nb:
+            jobs = (E.BlockJob * nb)()
+            caps = [eng.block_bound(n, b"jDC20240101000000d0000000001", b"jDC\x01") for n in blk_n]
+            ocap = [(c + 63) & ~63 for c in caps]
+            outs = torch.empty(sum(ocap), dtype=torch.uint8, device=dev)
+            p_in, p_out = 0, 0
+            names = []
+            for k, b in enumerate(mine):
+                first_id = int(starts[b]) + 1   # 1-based id of the block's first (new) fragment
+                names.append(("jDC20240101000000d%010d" % first_id).encode())
+                jobs[k].in_ = blocks_buf.data_ptr() + p_in
+                jobs[k].n = blk_n[k]
+                jobs[k].method = b"14"
+                jobs[k].filename = names[-1]
+                jobs[k].comment = b"jDC\x01"
+                jobs[k].dosha1 = 1
+                jobs[k].out = outs.data_ptr() + p_out
+                jobs[k].out_cap = ocap[k]
+                p_in += (blk_n[k] + 63 + 64) & ~63
+                p_out += ocap[k]
+            torch.cuda.synchronize()
+            eng.compress_blocks_dev(jobs, nb)
+            out_bytes = sum(jobs[k].out_len for k in range(nb))
+            self.last_blocks = [(int(mine[k]), jobs[k].out_len) for k in range(nb)]
+            # kept for --verify (outside the timed region): input and framed output of the first block
+            self.verify_sample = (blocks_buf[: blk_n[0]], outs[: jobs[0].out_len], names[0])
+        if self.world > 1:
+            # the archive is stitched on rank 0 in block order: gather the compressed streams
+            t = torch.tensor([out_bytes], dtype=torch.int64, device=dev)
+            ts = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(ts, t)
+            mx = max(int(x.item()) for x in ts)
+            buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
+            if outs is not None:
+                q = 0; p_out = 0
+                for k in range(nb):
+                    buf[q:q + jobs[k].out_len] = outs[p_out:p_out + jobs[k].out_len]
+                    q += jobs[k].out_len; p_out += ocap[k]
+            gathered = [torch.empty_like(buf) for _ in range(self.world)]
+            dist.all_gather(gathered, buf)
+            out_bytes = sum(int(x.item()) for x in ts)
+            torch.cuda.synchronize()
+        self.stats = dict(fragments=int(ntot), unique_fragments=int(len(uniq_idx)), blocks=int(nblk),
+                          unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
+        return out_bytes
+
+    def _exchange_seams(self, uniq_idx, lens, blk, owner_of_frag, blk_owner, starts, cnts, nf, foreign, blocks_buf):
+        """Fragments of a block that live on another rank (only at rank seams) travel peer to peer."""
+        dev = self.dev
+        lo = np.concatenate(([0], np.cumsum(cnts)))
+        sends, recvs = [], []
+        # what I must send: my fragments inside blocks owned by someone else
+        theirs = np.nonzero((owner_of_frag == self.rank) & (blk_owner[blk] != self.rank))[0]
+        for dstrank in np.unique(blk_owner[blk[theirs]]):
+            sel = theirs[blk_owner[blk[theirs]] == dstrank]
+            idx = torch.from_numpy((uniq_idx[sel] - lo[self.rank]).astype(np.int64)).to(dev)
+            parts = [self.data[int(o):int(o) + int(l)] for o, l in zip(self.frag_off[:nf][idx].tolist(), lens[uniq_idx[sel]].tolist())]
+            payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+            sends.append(dist.isend(payload, int(dstrank)))
+        for b, u, l, o in foreign:
+            for srcrank in np.unique(np.searchsorted(lo[1:], u, side="right")):
+                m = np.searchsorted(lo[1:], u, side="right") == srcrank
+                buf = torch.empty(int(l[m].sum()), dtype=torch.uint8, device=dev)
+                recvs.append((dist.irecv(buf, int(srcrank)), buf, o[m], l[m]))
+        for r, buf, o, l in recvs:
+            r.wait()
+            q = 0
+            for oo, ll in zip(o.tolist(), l.tolist()):
+                blocks_buf[oo:oo + ll] = buf[q:q + ll]; q += ll
+        for s in sends:
+            s.wait()
+
+
+def cpu_baseline(corpus, copies):
+    """The CPU oracle (a port of the reference's path) on this host's cores, single thread, on a bounded
+    sample: fragment+SHA-1 of one Silesia-sized copy, compressBlock of its first two 16 MiB blocks;
+    extrapolated to the x256 job (256 x fragment/hash + 1 x compress of the unique copy)."""
+    import orc
+    t0 = time.time()
+    nbytes = 0
+    budget = 12.0
+    for _, b in corpus:
+        off = 0
+        for ln in orc.chunk(b):
+            orc.sha1(b[off:off + ln]); off += ln
+        nbytes += len(b)
+        if time.time() - t0 > budget:
+            break
+    t_fh = (time.time() - t0) / max(1, nbytes)          # s per input byte, fragment + SHA-1
+    blob = b"".join(b for _, b in corpus)[: 2 * BLOCK_LIMIT]
+    t1 = time.time(); cin = cout = 0
+    for i in range(0, len(blob), BLOCK_LIMIT):
+        blk = blob[i:i + BLOCK_LIMIT]
+        out, _ = orc.compress_block(blk, "14", "jDC20240101000000d0000000001", "jDC\x01", True)
+        cin += len(blk); cout += len(out)
+    t_c = (time.time() - t1) / max(1, cin)
+    unit = sum(len(b) for _, b in corpus)
+    est_time = t_fh * unit * copies + t_c * unit
+    est_out = unit * (cout / max(1, cin))
+    return {"value": round(est_out / 1e6 / est_time, 3), "unit": "MB/s compressed output", "cores": 1, "kind": "port",
+            "input_GBps": round(unit * copies / 1e9 / est_time, 4),
+            "sample": "oracle/liboracle.so, 1 thread: fragment+SHA-1 of %d MB and compressBlock('14') of %d MB "
+                      "(ratio %.3f), extrapolated to 256 x fragment/hash + 1 x compress" % (nbytes >> 20, cin >> 20, cout / max(1, cin))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import datagen
+    from zpaqfranz_amd import Engine
+    eng = Engine(local)
+    corpus = datagen.silesia_like(seed=rank, scale=a.scale)
+    pipe = Pipeline(eng, dev, corpus, a.copies, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); eng.sync()
+
+    for _ in range(a.warmup):
+        pipe.step()
+    eng.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    out_bytes = 0
+    for _ in range(a.steps):
+        out_bytes = pipe.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_report()
+    eng.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        sec = dt / a.steps
+        in_bytes = pipe.total * world
+        # algorithmic bytes per launch of each input-scanning kernel: every input byte read once
+        alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total + pipe.stats["unique_bytes"]}
+        dom = max(kern, key=lambda k: kern[k][1]) if kern else None
+        roof = None
+        if dom:
+            cnt, ms = kern[dom]
+            per = ms / cnt
+            launches_per_step = cnt / a.steps
+            ab = alg.get(dom, pipe.stats["unique_bytes"]) / max(1.0, launches_per_step if dom in alg else 1.0)
+            ach = ab / 1e9 / (per / 1e3)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(per, 4),
+                    "algorithmic_bytes_per_launch": int(ab)}
+        res = {"metric": "MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x256", "value": round(out_bytes / 1e6 / sec, 3),
+               "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "silesia_x%d_m1" % a.copies, "files": pipe.nfiles * world, "input_bytes": in_bytes,
+                          "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **pipe.stats},
+               "input_GBps": round(in_bytes / 1e9 / sec, 3),
+               "kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(corpus, a.copies)
+        if not a.no_verify and getattr(pipe, "verify_sample", None) is not None:
+            import orc
+            bin_, bout, nm = pipe.verify_sample
+            want, _ = orc.compress_block(bytes(bin_.cpu().numpy()), "14", nm.decode(), "jDC\x01", True)
+            res["verified_block0_bit_identical"] = bool(want == bytes(bout.cpu().numpy()))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,13 @@ void* zpq_stream(zpq_ctx* ctx);
  * kHz, [3]=memory bus width bits, [4]=L2 bytes, [5]=total HBM bytes (low 32 bits in MiB). */
 int zpq_device_info(zpq_ctx* ctx, int64_t info[6], char* name, size_t name_cap);
 
+/* ---- per-kernel timing (HIP events on the launch stream) ---------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the stream it is launched on.
+ * zpq_profile_report synchronises, writes one line per kernel "name count total_ms" into buf
+ * (NUL-terminated, truncated to cap) and clears the records. */
+int zpq_profile_enable(zpq_ctx* ctx, int on);
+int zpq_profile_report(zpq_ctx* ctx, char* buf, size_t cap);
+
 /* ---- device memory helpers (for hosts without their own allocator) ------------------------ */
 int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr);
 int zpq_dev_free(zpq_ctx* ctx, void* dptr);
@@ -104,6 +111,13 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
 /* first[i] = smallest j <= i with digest[j] == digest[i] (20-byte SHA-1 keys): fragment i is new
  * iff first[i] == i.  Deterministic regardless of scheduling. */
 int zpq_dedup_dev(zpq_ctx* ctx, const uint8_t* d_digests, size_t n, uint32_t* d_first);
+
+/* ---- block packer data movement (row a4) ---------------------------------------------------- */
+/* Copies n extents: d_dst_base[dst_off[i] .. +len[i]) = d_src_base[src_off[i] .. +len[i]).
+ * The host-side packer (which fragments go to which block, in which order) stays host logic as in
+ * the reference; only the bytes move, HBM to HBM.  All index arrays are DEVICE pointers. */
+int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uint64_t* d_src_off,
+                   const uint32_t* d_len, const uint64_t* d_dst_off, size_t n, uint8_t* d_dst_base);
 
 /* ---- LZ77 level-1 code stream (row a8) ----------------------------------------------------- */
 /* One job = one ZPAQ block's input.  args[9] are LZBuffer's (ZSFX/libzpaq.cpp:6128-6138):

@@ -200,19 +200,20 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   std::vector<u64> sha_off; std::vector<u32> sha_len; std::vector<size_t> sha_job;
   for (size_t i = 0; i < njobs; ++i)
     if (jobs[i].status == ZPQ_OK && jobs[i].dosha1) { sha_off.push_back((u64)(uintptr_t)jobs[i].in); sha_len.push_back(jobs[i].n); sha_job.push_back(i); }
-  u8* d_aux = (u8*)zpq_scratch(ctx, 3, prefix_total + njobs * (sizeof(FrameDev) + 8 + 4 + 20) + 256);
+  u8* d_aux = (u8*)zpq_scratch(ctx, 3, prefix_total + njobs * (sizeof(FrameDev) + 8 + 4 + 20) + 512);
   u8* d_lz = (u8*)zpq_scratch(ctx, 4, lz_out_total + 64);
   if (!d_aux || !d_lz) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "block scratch");
   u64* d_sha_off = (u64*)d_aux;
   u32* d_sha_len = (u32*)(d_sha_off + njobs);
-  u8* d_dig = (u8*)(d_sha_len + njobs);
+  u8* d_dig = (u8*)(d_sha_len + ((njobs + 3) & ~(size_t)3));
   FrameDev* d_frames = (FrameDev*)(d_dig + ((njobs * 20 + 15) & ~(size_t)15));
   u8* d_prefix = (u8*)(d_frames + njobs);
   if (!sha_job.empty()) {
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_off, sha_off.data(), sha_off.size() * 8, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_len, sha_len.data(), sha_len.size() * 4, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
-    int rc = zpq_sha1_extents_on(ctx, ctx->stream2, (const u8*)0, d_sha_off, d_sha_len, sha_job.size(), d_dig);
+    int rc = zpq_sha1_extents_on(ctx, ctx->stream2, (const u8*)0, d_sha_off, d_sha_len, sha_job.size(), d_dig,
+                                  "sha1_extents_kernel(block chains)");
     if (rc) return rc;
     ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
   }
@@ -253,7 +254,7 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     ZPQ_HIP(ctx, hipMemcpyAsync(d_prefix, pre_all.data(), po, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_frames, fr.data(), nfr * sizeof(FrameDev), hipMemcpyHostToDevice, st));
     if (!sha_job.empty()) ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev, 0));
-    hipLaunchKernelGGL(frame_kernel, dim3((maxP + 255) / 256, (unsigned)nfr), dim3(256), 0, st, d_frames);
+    ZPQ_LAUNCH(ctx, "frame_kernel", st, frame_kernel, dim3((maxP + 255) / 256, (unsigned)nfr), dim3(256), d_frames);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   ZPQ_HIP(ctx, hipStreamSynchronize(st));

@@ -53,6 +53,7 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
   for (int i = 0; i < 12; ++i) c->scratch[i] = nullptr, c->scratch_cap[i] = 0;
   c->pinned = nullptr;
   c->pinned_cap = 0;
+  c->profiling = false;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
@@ -112,6 +113,32 @@ int zpq_device_info(zpq_ctx* ctx, int64_t info[6], char* name, size_t name_cap) 
   info[4] = prop.l2CacheSize;
   info[5] = (int64_t)(prop.totalGlobalMem >> 20);
   if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  return ZPQ_OK;
+}
+
+int zpq_profile_enable(zpq_ctx* ctx, int on) {
+  ctx->profiling = on != 0;
+  return ZPQ_OK;
+}
+
+int zpq_profile_report(zpq_ctx* ctx, char* buf, size_t cap) {
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  struct Acc { const char* name; int count; double ms; };
+  std::vector<Acc> acc;
+  for (auto& r : ctx->prof) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    bool found = false;
+    for (auto& a : acc) if (strcmp(a.name, r.name) == 0) { a.count++; a.ms += ms; found = true; break; }
+    if (!found) acc.push_back({r.name, 1, ms});
+  }
+  ctx->prof.clear();
+  std::string out;
+  char line[256];
+  for (auto& a : acc) { snprintf(line, sizeof line, "%s %d %.6f\n", a.name, a.count, a.ms); out += line; }
+  if (buf && cap) { size_t k = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), k); buf[k] = 0; }
   return ZPQ_OK;
 }
 

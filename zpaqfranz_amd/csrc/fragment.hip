@@ -305,10 +305,10 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
 
-  hipLaunchKernelGGL(fragment_spec_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, d_base, readable,
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), d_base, readable,
                      d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), 0, st, d_base, readable,
+  ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base, readable,
                      d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cut_base, d_cuts,
                      d_cut_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
@@ -324,7 +324,7 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   *nfrags = (size_t)nf;
   if (nf > frag_cap) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "fragment capacity %zu < %llu", frag_cap, (unsigned long long)nf);
   ZPQ_HIP(ctx, hipMemcpyAsync(d_frag_base, frag_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(fragment_emit_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), 0, st, d_file_off,
+  ZPQ_LAUNCH(ctx, "fragment_emit_kernel", st, fragment_emit_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_file_off,
                      (u32)nfiles, d_cut_base, d_cuts, d_cut_cnt, d_frag_base, d_frag_off, d_frag_len, d_frag_file);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_HIP(ctx, hipStreamSynchronize(st));

@@ -557,17 +557,17 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
     ZPQ_HIP(ctx, hipStreamSynchronize(st));  // `sub` is pageable host memory
     dim3 grid((unsigned)idx.size()), blk(64);
     switch (nbits) {
-      case 0: hipLaunchKernelGGL(lz77_parse_kernel<1>, grid, blk, 0, st, d_sub); break;
-      case 1: hipLaunchKernelGGL(lz77_parse_kernel<2>, grid, blk, 0, st, d_sub); break;
-      case 2: hipLaunchKernelGGL(lz77_parse_kernel<4>, grid, blk, 0, st, d_sub); break;
-      default: hipLaunchKernelGGL(lz77_parse_kernel<8>, grid, blk, 0, st, d_sub); break;
+      case 0: ZPQ_LAUNCH(ctx, "lz77_parse_kernel", st, lz77_parse_kernel<1>, grid, blk, d_sub); break;
+      case 1: ZPQ_LAUNCH(ctx, "lz77_parse_kernel", st, lz77_parse_kernel<2>, grid, blk, d_sub); break;
+      case 2: ZPQ_LAUNCH(ctx, "lz77_parse_kernel", st, lz77_parse_kernel<4>, grid, blk, d_sub); break;
+      default: ZPQ_LAUNCH(ctx, "lz77_parse_kernel", st, lz77_parse_kernel<8>, grid, blk, d_sub); break;
     }
     ZPQ_HIP(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(lz77_pack_tokens_kernel, dim3((unsigned)njobs), dim3(1024), 0, st, d_jobs);
+  ZPQ_LAUNCH(ctx, "lz77_pack_tokens_kernel", st, lz77_pack_tokens_kernel, dim3((unsigned)njobs), dim3(1024), d_jobs);
   ZPQ_HIP(ctx, hipGetLastError());
   if (max_n) {
-    hipLaunchKernelGGL(lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)njobs), dim3(256), 0, st, d_jobs);
+    ZPQ_LAUNCH(ctx, "lz77_pack_literals_kernel", st, lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)njobs), dim3(256), d_jobs);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   std::vector<u32> res(njobs * 4);
@@ -596,7 +596,7 @@ extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, h.data(), njobs * sizeof(LzDecDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  hipLaunchKernelGGL(lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), 0, st, d_jobs);
+  ZPQ_LAUNCH(ctx, "lz77_decode_kernel", st, lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), d_jobs);
   ZPQ_HIP(ctx, hipGetLastError());
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));

@@ -184,14 +184,14 @@ int persistent_grid(zpq_ctx* ctx, size_t n) {
 }  // namespace
 
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
-                        u8* d_digests) {
+                        u8* d_digests, const char* prof_name) {
   if (n == 0) return ZPQ_OK;
   if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
   // one counter per stream so that the two streams never share it
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + (s == ctx->stream2 ? 16 : 0);
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
-  hipLaunchKernelGGL(sha1_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), 0, s, d_base, d_off, d_len, (u32)n,
+  ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), d_base, d_off, d_len, (u32)n,
                      d_digests, counter);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
@@ -211,7 +211,7 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + 32;
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(sha256_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), 0, ctx->stream, d_base, d_off,
+  ZPQ_LAUNCH(ctx, "sha256_extents_kernel", ctx->stream, sha256_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), d_base, d_off,
                      d_len, (u32)n, d_digests, counter);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;

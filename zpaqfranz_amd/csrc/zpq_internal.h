@@ -21,7 +21,29 @@ struct zpq_ctx {
   size_t scratch_cap[12];
   void* pinned;             // pinned host staging
   size_t pinned_cap;
+  // optional per-kernel event timing
+  bool profiling;
+  struct ProfRec { const char* name; hipEvent_t a, b; };
+  std::vector<ProfRec> prof;
 };
+
+// Brackets one kernel launch with events on its stream when profiling is on.
+struct ZpqProfScope {
+  zpq_ctx* c; hipStream_t s; hipEvent_t a, b; bool on;
+  ZpqProfScope(zpq_ctx* ctx, const char* name, hipStream_t st) : c(ctx), s(st), on(ctx->profiling) {
+    if (on) {
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, s);
+      c->prof.push_back({name, a, b});
+    }
+  }
+  ~ZpqProfScope() { if (on) (void)hipEventRecord(b, s); }
+};
+#define ZPQ_LAUNCH(ctx, name, st, kernel, grid, block, ...)                        \
+  do {                                                                             \
+    ZpqProfScope prof_scope_((ctx), (name), (st));                                 \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (st), __VA_ARGS__);                 \
+  } while (0)
 
 // Returns a device scratch buffer of at least `bytes` in slot `slot` (grow-only).
 void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes);
@@ -55,4 +77,4 @@ static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63)
 
 // internal cross-TU entry points
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off,
-                        const u32* d_len, size_t n, u8* d_digests);
+                        const u32* d_len, size_t n, u8* d_digests, const char* prof_name = "sha1_extents_kernel");

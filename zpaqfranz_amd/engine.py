@@ -82,6 +82,9 @@ def load():
     L.zpq_fragment_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FragmentParams), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zpq_dedup_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_gather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.zpq_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.zpq_profile_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.zpq_lz77_encode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77Job), C.c_size_t]
     L.zpq_lz77_decode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77DecJob), C.c_size_t]
     L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
@@ -218,6 +221,21 @@ class Engine:
             for b in (data, fo, fl, ff):
                 b.free()
         return [(fil[i], offs[i] - file_off[fil[i]], lens[i]) for i in range(n)]
+
+    def gather_dev(self, d_src_base, d_src_off, d_len, d_dst_off, n, d_dst_base):
+        self._ck(self.L.zpq_gather_dev(self.ctx, d_src_base, d_src_off, d_len, d_dst_off, n, d_dst_base))
+
+    def profile(self, on):
+        self._ck(self.L.zpq_profile_enable(self.ctx, int(on)))
+
+    def profile_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.zpq_profile_report(self.ctx, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            nm, cnt, ms = line.split()
+            out[nm] = (int(cnt), float(ms))
+        return out
 
     def dedup_dev(self, d_digests, n, d_first):
         self._ck(self.L.zpq_dedup_dev(self.ctx, d_digests, n, d_first))
