@@ -78,7 +78,8 @@ int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes);
 
 /* ---- SHA-1 / SHA-256 over many extents (rows a2, a18) ------------------------------------- */
 /* digest[i] = SHA-1(base[off[i] .. off[i]+len[i])), 20 bytes each (32 for SHA-256).
- * base must stay readable for 16 bytes past the last extent (pad the allocation). */
+ * Every input buffer handed to this library (here and below) must stay readable for 64 bytes past
+ * its last byte (pad the allocation): the kernels use 8/16-byte vector reads. */
 int zpq_sha1_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off,
                          const uint32_t* d_len, size_t n, uint8_t* d_digests);
 int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off,
@@ -125,7 +126,7 @@ int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uint64_t* d_sr
  * args[5]=log2 hash size <= 26 (and < args[0]+21), args[6]=0.  Output: the exact byte stream
  * LZBuffer::read() yields.  d_out capacity per job must be >= zpq_lz77_bound(n). */
 typedef struct zpq_lz77_job {
-  const uint8_t* d_in;   /* device; readable for 16 bytes past n */
+  const uint8_t* d_in;   /* device; readable for 64 bytes past n */
   uint32_t n;            /* <= 2^(20+args[0]) */
   int32_t args[9];
   uint8_t* d_out;        /* device */

@@ -1,0 +1,782 @@
+// LZ77 level-1 ("lazy2") encoder -- the codec behind zpaqfranz -m1.
+// Reference: LZBuffer::LZBuffer/fill/write_literal/write_match/putb/flush, ZSFX/libzpaq.cpp:6140-6552
+// (code format :6211-6222).  The output is bit-identical to LZBuffer's.  What makes that possible:
+//  * Every input position is inserted into the hash table whatever the parse chose
+//    (ZSFX/libzpaq.cpp:6432-6447); slot and value are pure functions of the input and the value
+//    carries the position in its high bits, so "the table as LZBuffer sees it at position X" is the
+//    per-slot maximum over all positions < X -- buildable with atomicMax, in any order.  The rolling
+//    hash h1 has a finite window ((5<<shift1)^minMatch == 0 mod table size): recomputed from bytes.
+//  * A wave walks its range in windows of 64 positions: all lanes look their position up at once
+//    (vector table loads, candidate compares batched 16+16 bytes), inserts of earlier lanes of the
+//    same window are forwarded through an LDS collision mask, and each lane precomputes the
+//    reference's decision (:6396-6421) for both values of the (lit>0) score term.  Only the greedy
+//    chain "take the match and skip blen, or emit literals" is serial: a wave-uniform loop over
+//    v_readlane'd results that jumps over literal runs with one ballot.  Positions whose candidates
+//    hit the 32-byte compare cap are re-evaluated exactly with 512-bytes-per-step whole-wave compares.
+//  * Blocks are cut into segments of 1 MiB.  The table state at every segment start is built up
+//    front (copy + atomicMax scatter), every segment is parsed speculatively from its own start
+//    (lz77_spec_kernel, one wave per segment), and one wave per block walks the true chain
+//    (lz77_stitch_kernel): it re-parses from where the previous segment really ended until one of
+//    its matches ends exactly where a speculative match ends -- both chains are then in the same
+//    state (lit == 0), so the rest of that segment's speculative tokens are adopted verbatim.
+//  * Tokens -> bits: a workgroup scan gives every token its bit offset; code bits and literal
+//    bytes are OR-ed into the zeroed output in parallel (LSB-first, :6171-6186).
+// Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
+// n bytes: n read + r*n written (r = LZ ratio); the hash tables are implementation traffic.
+#include <algorithm>
+
+#include "zpq_internal.h"
+
+namespace {
+
+constexpr u32 kMaxMatch = (1u << 14) * 3;   // ZSFX/libzpaq.cpp:6258 (BUFSIZE*3)
+constexpr u32 kMaxLiteral = (1u << 14) / 4;  // :6259
+constexpr u32 kCap = 32;                     // speculative compare cap (bytes)
+constexpr u32 kNoCand = 0xffffffffu;
+constexpr u32 kSegBytes = 1u << 20;          // speculation segment
+constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB blocks at most)
+
+struct LzCfg {
+  const u8* in;
+  u32 n;
+  u32 minMatch, bucket, htbits, checkbits, shift1, rb;
+  u32 upd_limit;   // positions < upd_limit are inserted (i + minMatchBoth < n)
+};
+
+// per (block, segment)
+struct LzSegDev {
+  LzCfg c;
+  u32 x0, x1;        // segment range [x0, x1)
+  u32* work;         // table as of x0, mutated by the speculative parse
+  u32* pristine;     // table as of x0, mutated by the stitcher's re-parse
+  u32* tpos; u32* tlen; u32* toff;  // speculative tokens
+  u32 tcap;
+  u32* state;        // [0]=ntok [1]=end cur [2]=end lit [3]=overflow
+};
+
+// per block (also what the pack kernels read)
+struct LzJobDev {
+  const u8* in;
+  u32 n;
+  u32 rb;
+  u32 nseg, seg0;    // segments seg0 .. seg0+nseg-1 in the segment array
+  u32* tok_pos; u32* tok_len; u32* tok_off; u32* tok_bit;   // final token list
+  u32 tok_cap;
+  u32* result;       // [0]=ntok, [1]=out_len bytes, [2]=overflow flag
+  u8* out; u32 out_cap;
+};
+
+__device__ __forceinline__ int lg32(u32 x) { return x ? 32 - __builtin_clz(x) : 0; }  // lg(), :6224-6233
+__device__ __forceinline__ u64 load8(const u8* p) { return *(const u64_u*)p; }
+__device__ __forceinline__ u32x4 load16(const u8* p) { return *(const u32x4_u*)p; }
+
+// h1 as LZBuffer holds it when it reaches position q (:6444): the rolling hash over the last
+// minMatch update steps, i.e. over in[U..U+minMatch-1] with U = min(q, upd_limit); partial for U < minMatch.
+__device__ __forceinline__ u32 hash_at(const LzCfg& C, u32 q) {
+  const u32 U = q < C.upd_limit ? q : C.upd_limit;
+  const u32 mm = C.minMatch;
+  const u32 F = 5u << C.shift1;
+  u32 h = 0;
+  const u32 t0 = U > mm ? U - mm : 0;
+  for (u32 t = t0; t < U; ++t) h = h * F + (C.in[t + mm] + 1u) * 123456791u;
+  return h & ((1u << C.htbits) - 1u);
+}
+
+// Same value from 8 bytes already in registers (qb = in[q..q+7]); valid for minMatch <= q <= upd_limit, minMatch <= 8.
+__device__ __forceinline__ u32 hash_fast(const LzCfg& C, u64 qb) {
+  const u32 F = 5u << C.shift1;
+  u32 h = 0;
+  for (u32 j = 0; j < C.minMatch; ++j) h = h * F + ((u32)((qb >> (8 * j)) & 255u) + 1u) * 123456791u;
+  return h & ((1u << C.htbits) - 1u);
+}
+
+// first differing byte index of two 16-byte vectors (16 if equal)
+__device__ __forceinline__ u32 mismatch16(u32x4 a, u32x4 b) {
+  const u64 x0 = ((u64)(a.y ^ b.y) << 32) | (u64)(a.x ^ b.x);
+  const u64 x1 = ((u64)(a.w ^ b.w) << 32) | (u64)(a.z ^ b.z);
+  if (x0) return (u32)(__builtin_ctzll(x0) >> 3);
+  if (x1) return 8u + (u32)(__builtin_ctzll(x1) >> 3);
+  return 16u;
+}
+
+// Whole-wave compare for long matches: 512 bytes per step.  All arguments wave-uniform.
+__device__ __forceinline__ u32 coop_match_len(const u8* in, u32 p, u32 q, u32 limit) {
+  const u32 lane = (u32)lane_id();
+  u32 base = 0;
+  while (base < limit) {
+    u32 o = base + lane * 8;
+    u64 x = o < limit ? (load8(in + p + o) ^ load8(in + q + o)) : 1ull;
+    unsigned long long m = __ballot(x != 0);
+    if (m) {
+      int fl = __builtin_ctzll(m);
+      u64 xf = (u64)__shfl((unsigned long long)x, fl);
+      u32 of = base + (u32)fl * 8;
+      u32 l = of < limit ? of + (u32)(__builtin_ctzll(xf) >> 3) : limit;
+      return l < limit ? l : limit;
+    }
+    base += 512;
+  }
+  return limit;
+}
+
+template <int NB> struct GroupLoad;
+template <> struct GroupLoad<1> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[1]) { e[0] = __builtin_nontemporal_load(p); } };
+template <> struct GroupLoad<2> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[2]) {
+  u64 v = __builtin_nontemporal_load((const u64*)p); e[0] = (u32)v; e[1] = (u32)(v >> 32); } };
+template <> struct GroupLoad<4> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[4]) {
+  u32x4 v = __builtin_nontemporal_load((const u32x4*)p); e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; } };
+template <> struct GroupLoad<8> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[8]) {
+  u32x4 v = __builtin_nontemporal_load((const u32x4*)p), w = __builtin_nontemporal_load((const u32x4*)p + 1);
+  e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w; } };
+
+struct TokSink { u32* pos; u32* len; u32* off; u32 cap; u32 n; };
+
+// Speculative tokens of one segment, consulted by the stitcher after each of its own tokens.
+struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
+
+// Walks positions [wbase, x1) of a block in windows of 64: inserts every position into `ht`
+// (which must hold exactly the inserts of all positions < wbase) and continues the greedy parse
+// from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
+// matches ends where a speculative match ends and returns that token's index (else -1).
+template <int NB>
+__device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
+                       SpecList* spec, unsigned long long* T) {
+  const u32 lane = (u32)lane_id();
+  const u8* in = C.in;
+  const u32 n = C.n;
+  const u32 mask = (1u << C.checkbits) - 1u;
+  const u32 mm = C.minMatch;
+  volatile unsigned long long* Tv = T;
+  const bool fast_hash = mm <= 8;
+  const u32 hfrozen = hash_at(C, C.upd_limit);   // h1 once updates have stopped (q > upd_limit)
+
+  for (u32 base = wbase; base < x1 && base < n; base += 64) {
+    const u32 q = base + lane;
+    const bool inb = q < n && q < x1;
+    u32 wend = base + 64 < x1 ? base + 64 : x1;
+    if (wend > n) wend = n;
+    // ---- per-position hash, slot, value --------------------------------------------------------
+    const u64 qb = load8(in + (q < n ? q : 0));           // in[q..q+7] (buffers are padded)
+    u32 h;
+    if (fast_hash && q >= mm && q <= C.upd_limit) h = hash_fast(C, qb);
+    else if (q > C.upd_limit) h = hfrozen;
+    else h = inb ? hash_at(C, q) : 0u;
+    const bool ins = inb && q < C.upd_limit;
+    const u32 ih = ((q * 1234547u) >> 19) & C.bucket;                     // :6435
+    const u32 slot = h ^ ih;
+    const u32 b3 = (inb && q + 3 < n) ? (u32)((qb >> 24) & 255u) : 0u;
+    const u32 val = (q << C.checkbits) | (b3 & mask);                      // :6436
+    const u32 grp = h & ~C.bucket;
+    const bool look = inb && cur < wend;   // windows swallowed by a match only insert
+
+    u32 ent[NB];
+    if (look) GroupLoad<NB>::ld(ht + grp, ent);   // bypasses L1: the table is rewritten by this wave
+    else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) ent[j] = 0;
+    }
+    // ---- forward inserts of earlier lanes in this window; find superseded stores ---------------
+    bool superseded = false;
+    {
+      const u32 tk = (grp >> 3) & 255u;
+      if (inb) atomicOr((unsigned long long*)&T[tk], 1ull << lane);
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long cm = inb ? Tv[tk] : 0ull;
+      cm &= ~(1ull << lane);
+      while (__ballot(cm != 0)) {
+        const int k = cm ? __builtin_ctzll(cm) : 0;  // ascending: later lanes overwrite earlier ones
+        const u32 sk = __shfl(slot, k), vk = __shfl(val, k);
+        const bool ik = __shfl((int)ins, k) != 0;
+        if (cm) {
+          if (ik && (u32)k < lane && (sk & ~C.bucket) == grp) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              if ((sk & C.bucket) == (u32)j) ent[j] = vk;
+          }
+          if (ik && (u32)k > lane && sk == slot) superseded = true;
+          cm &= cm - 1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (inb) Tv[tk] = 0ull;
+    }
+    // ---- reorder the group into probe order ht[h1^k], k = 0..bucket (:6397) ---------------------
+    {
+      const u32 hb = h & C.bucket;
+#pragma unroll
+      for (int bit = 1; bit < NB; bit <<= 1) {
+        const bool sw = (hb & (u32)bit) != 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (!(j & bit)) {
+            u32 a = ent[j], b = ent[j | bit];
+            ent[j] = sw ? b : a;
+            ent[j | bit] = sw ? a : b;
+          }
+      }
+    }
+    // ---- speculative candidate evaluation (lanes at or after the chain head) -------------------
+    // All first 16-byte loads are issued before any is used: one memory round trip for the group.
+    u32 cp[NB], cl[NB];
+    bool slow = false;
+    const u32 limit = inb ? (n - q < kMaxMatch ? n - q : kMaxMatch) : 0u;
+    const bool evalp = look && q >= cur;
+    u32x4 ca[NB];
+    const u32x4 qa = load16(in + (q < n ? q : 0)), qc = load16(in + (q < n ? q : 0) + 16);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      cp[k] = kNoCand; cl[k] = 0;
+      const u32 e = ent[k];
+      if (evalp && e && q + 3 < n && (e & mask) == (b3 & mask)) {           // :6398
+        const u32 p = e >> C.checkbits;
+        if (p < q) cp[k] = p;
+      }
+      ca[k] = load16(in + (cp[k] != kNoCand ? cp[k] : 0u));
+    }
+    u32x4 cb[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      u32 l = 0;
+      if (cp[k] != kNoCand) l = mismatch16(ca[k], qa);
+      cl[k] = l;
+      cb[k] = load16(in + ((cp[k] != kNoCand && l == 16) ? cp[k] + 16u : 0u));
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if (cp[k] != kNoCand) {
+        u32 l = cl[k];
+        if (l == 16) l = 16 + mismatch16(cb[k], qc);
+        if (l >= limit) l = limit;                       // never beyond the input / maxMatch
+        else if (l == kCap) slow = true;                 // may extend further: resolve exactly when reached
+        cl[k] = l;
+      }
+    }
+    // ---- the reference's decision for both values of (lit>0) (:6396-6421) -----------------------
+    u32 rlen[2] = {0, 0}, roff[2] = {0, 0};
+    if (evalp && !slow) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        u32 blen = mm - 1, bp = 0; int bscore = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (blen < 128 && cp[k] != kNoCand) {
+            const u32 p = cp[k], l = cl[k];
+            bool ok = false;
+            if (q + blen <= n) {
+              const u32 idx = blen - 1;
+              if (idx < l) ok = true;
+              else if (idx == l) ok = false;  // first mismatch (l < limit here because q+blen<=n)
+              else ok = in[p + idx] == in[q + idx];
+            }
+            if (ok) {
+              const int score = (int)(l * 8) - lg32(q - p) - 2 * f - 11;
+              if (score > bscore) { blen = l; bp = p; bscore = score; }
+            }
+          }
+        }
+        const u32 off = q - bp;
+        if (off > 0 && bscore > 0 && blen >= mm) { rlen[f] = blen; roff[f] = off; }
+      }
+    }
+    // ---- serial greedy chain over this window (wave-uniform) -----------------------------------
+    const unsigned long long slowmask = __ballot(slow);
+    const unsigned long long stop1 = __ballot(rlen[1] != 0) | slowmask;  // where a lit>0 run must stop
+    while (cur < wend) {
+      const u32 j = cur - base;
+      if (lit > 0) {                                   // inside a literal run: jump to its end
+        const unsigned long long m = stop1 >> j;
+        u32 skip = m ? (u32)__builtin_ctzll(m) : 64u;
+        if (skip > wend - cur) skip = wend - cur;
+        if (skip) {
+          if (lit + skip >= kMaxLiteral) { skip = kMaxLiteral - lit; lit = 0; }   // forced flush (:6450-6451)
+          else lit += skip;
+          cur += skip;
+          continue;
+        }
+      }
+      const u32 f = lit > 0 ? 1u : 0u;
+      u32 tlen, toff;
+      if ((slowmask >> j) & 1ull) {
+        // exact re-evaluation of position cur, replicating :6396-6408 with whole-wave compares
+        const u32 i = cur;
+        const u32 lim_i = n - i < kMaxMatch ? n - i : kMaxMatch;
+        const u32 bi3 = in[i + 3];
+        u32 blen = mm - 1, bp = 0; int bscore = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const u32 e = __builtin_amdgcn_readlane(ent[k], j);
+          if (blen < 128 && e && i + 3 < n && (e & mask) == (bi3 & mask)) {
+            const u32 p = e >> C.checkbits;
+            if (p < i && i + blen <= n && in[p + blen - 1] == in[i + blen - 1]) {
+              const u32 l = coop_match_len(in, p, i, lim_i);
+              const int score = (int)(l * 8) - lg32(i - p) - 2 * (int)f - 11;
+              if (score > bscore) { blen = l; bp = p; bscore = score; }
+            }
+          }
+        }
+        const u32 off = i - bp;
+        const bool take = off > 0 && bscore > 0 && blen >= mm;
+        tlen = take ? blen : 0u; toff = off;
+      } else {
+        const u32 l0 = __builtin_amdgcn_readlane(rlen[0], j), l1 = __builtin_amdgcn_readlane(rlen[1], j);
+        const u32 o0 = __builtin_amdgcn_readlane(roff[0], j), o1 = __builtin_amdgcn_readlane(roff[1], j);
+        tlen = f ? l1 : l0; toff = f ? o1 : o0;
+      }
+      if (tlen) {
+        if (lane == 0 && sink.n < sink.cap) { sink.pos[sink.n] = cur; sink.len[sink.n] = tlen; sink.off[sink.n] = toff; }
+        ++sink.n;
+        lit = 0;
+        cur += tlen;
+        if (spec) {
+          // does this match end where a speculative match of the segment ends?
+          const u32 E = cur;
+          int found = -1;
+          for (;;) {
+            const u32 jj = spec->j + lane;
+            const u32 e = jj < spec->n ? spec->pos[jj] + spec->len[jj] : 0xffffffffu;
+            const unsigned long long lt = __ballot(e < E), eq = __ballot(e == E);
+            if (eq) { found = (int)(spec->j + (u32)__builtin_ctzll(eq)); break; }
+            const u32 adv = (u32)__builtin_popcountll(lt);
+            spec->j += adv;
+            if (adv < 64) break;
+          }
+          if (found >= 0) {
+            // positions of this window not yet inserted: the caller's table is not used again
+            return found;
+          }
+        }
+      } else {
+        ++lit; ++cur;
+        if (lit >= kMaxLiteral) lit = 0;  // forced literal flush (:6450-6451); runs are positional
+      }
+    }
+    // ---- insert this window's positions (latest writer of a slot wins) --------------------------
+    if (ins && !superseded) ht[slot] = val;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return -1;
+}
+
+// ---- table state at every segment start --------------------------------------------------------------
+struct CopyJob { const u32* src; u32* dst; u32 words; };   // src == nullptr: zero fill
+
+__global__ __launch_bounds__(256) void lz77_table_copy_kernel(const CopyJob* __restrict__ jobs) {
+  const CopyJob J = jobs[blockIdx.y];
+  const u32 nvec = J.words >> 2;
+  u32x4* d = (u32x4*)J.dst;
+  const u32x4* s = (const u32x4*)J.src;
+  const u32x4 z = {0, 0, 0, 0};
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nvec; i += gridDim.x * 256u) d[i] = s ? s[i] : z;
+}
+
+struct ScatterJob { LzCfg c; u32 x0, x1; u32* dst; };
+
+// dst[slot] = max(dst[slot], value) for every inserted position of [x0, x1): the value carries the
+// position in its high bits, so the maximum is the latest insert -- what LZBuffer's table holds.
+__global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJob* __restrict__ jobs) {
+  const ScatterJob J = jobs[blockIdx.y];
+  const LzCfg& C = J.c;
+  const u32 mask = (1u << C.checkbits) - 1u;
+  const u32 hi = J.x1 < C.upd_limit ? J.x1 : C.upd_limit;
+  for (u32 q = J.x0 + blockIdx.x * 256u + threadIdx.x; q < hi; q += gridDim.x * 256u) {
+    const u64 qb = load8(C.in + q);
+    const u32 h = (C.minMatch <= 8 && q >= C.minMatch) ? hash_fast(C, qb) : hash_at(C, q);
+    const u32 ih = ((q * 1234547u) >> 19) & C.bucket;
+    const u32 val = (q << C.checkbits) | ((u32)((qb >> 24) & 255u) & mask);
+    if (val) atomicMax(J.dst + (h ^ ih), val);
+  }
+}
+
+// ---- speculative parse: one wave per segment ------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
+  const LzSegDev S = segs[list[blockIdx.x]];
+  __shared__ unsigned long long T[256];
+  const u32 lane = (u32)lane_id();
+  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
+  u32 cur = S.x0, lit = 0;
+  lz_walk<NB>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
+  if (lane == 0) {
+    S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
+    S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
+  }
+}
+
+// ---- true chain: one wave per block ----------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
+                                                         const u32* __restrict__ list) {
+  const LzJobDev J = jobs[list[blockIdx.x]];
+  __shared__ unsigned long long T[256];
+  const u32 lane = (u32)lane_id();
+  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  TokSink out{J.tok_pos, J.tok_len, J.tok_off, J.tok_cap, 0};
+  u32 cur = 0, lit = 0, overflow = 0;
+  for (u32 k = 0; k < J.nseg; ++k) {
+    const LzSegDev S = segs[J.seg0 + k];
+    const u32 ns = S.state[0];
+    overflow |= S.state[3];
+    int from = -1;   // adopt speculative tokens from this index on (-1: none)
+    if (cur >= S.x1) continue;                          // a match swallowed the whole segment
+    if (cur == S.x0 && lit == 0) from = 0;               // the speculation started in the true state
+    else {
+      SpecList sl{S.tpos, S.tlen, ns, 0};
+      const int hit = lz_walk<NB>(S.c, S.pristine, S.x0, S.x1, cur, lit, out, &sl, T);
+      if (hit >= 0) from = hit + 1;
+      // clean the collision masks a mid-window return may have left behind
+      T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (from >= 0) {
+      for (u32 t = (u32)from + lane; t < ns; t += 64) {
+        const u32 o = out.n + (t - (u32)from);
+        if (o < out.cap) { out.pos[o] = S.tpos[t]; out.len[o] = S.tlen[t]; out.off[o] = S.toff[t]; }
+      }
+      out.n += ns - (u32)from;
+      cur = S.state[1]; lit = S.state[2];
+    }
+  }
+  if (lane == 0) {
+    J.result[0] = out.n < out.cap ? out.n : out.cap;
+    if (out.n > out.cap || overflow) J.result[2] = 1;
+  }
+}
+
+// ---- bit costs ---------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lit_run_header_bits(u32 len) { return 3u + 2u * (u32)(lg32(len) - 1); }  // :6464-6476
+__device__ __forceinline__ u64 lit_gap_bits(u32 g) {
+  const u32 full = g / kMaxLiteral, r = g % kMaxLiteral;
+  u64 bits = (u64)full * (lit_run_header_bits(kMaxLiteral) + 8ull * kMaxLiteral);
+  if (r) bits += lit_run_header_bits(r) + 8ull * r;
+  return bits;
+}
+__device__ __forceinline__ u32 match_bits(u32 len, u32 off, u32 rb) {  // :6494-6516
+  const u32 o = off + (1u << rb) - 1u;
+  const u32 lo = (u32)lg32(o) - 1u - rb;
+  return 5u + 2u * (u32)(lg32(len) - 3) + 1u + 2u + rb + lo;
+}
+
+__device__ __forceinline__ void or_bits(u32* out, u64 bitpos, u64 value, u32 nbits) {
+  // value occupies the low nbits (<= 57); LSB-first packing (putb, :6171-6179)
+  if (!nbits) return;
+  const u64 w = bitpos >> 5; const u32 sh = (u32)(bitpos & 31);
+  const u64 lo = value << sh;
+  if ((u32)lo) atomicOr(out + w, (u32)lo);
+  if ((u32)(lo >> 32)) atomicOr(out + w + 1, (u32)(lo >> 32));
+  if (sh && nbits + sh > 64) { const u32 hi = (u32)(value >> (64 - sh)); if (hi) atomicOr(out + w + 2, hi); }
+}
+
+__device__ __forceinline__ void put_lit_header(u32* out, u64 bitpos, u32 len) {
+  // 00, then the bits of len below its leading one each preceded by a 1, then 0 (:6469-6476)
+  u64 v = 0; u32 k = 2;
+  for (int b = lg32(len) - 2; b >= 0; --b) { v |= 1ull << k; ++k; v |= (u64)((len >> b) & 1u) << k; ++k; }
+  ++k;
+  or_bits(out, bitpos, v, k);
+}
+
+__device__ __forceinline__ void put_match(u32* out, u64 bitpos, u32 len, u32 off, u32 rb) {
+  const u32 o = off + (1u << rb) - 1u;
+  const u32 lo = (u32)lg32(o) - 1u - rb;
+  u64 v = ((lo + 8u) >> 3) | ((u64)(lo & 7u) << 2);
+  u32 k = 5;
+  for (int b = lg32(len) - 2; b >= 2; --b) { v |= 1ull << k; ++k; v |= (u64)((len >> b) & 1u) << k; ++k; }
+  ++k;                                    // terminating 0
+  v |= (u64)(len & 3u) << k; k += 2;
+  or_bits(out, bitpos, v, k);             // k <= 5 + 26 + 1 + 2 = 34
+  const u64 tail = (u64)(o & ((1u << rb) - 1u)) | ((u64)((o >> rb) & ((1u << lo) - 1u)) << rb);
+  or_bits(out, bitpos + k, tail, rb + lo);
+}
+
+// One workgroup per block: scans token costs, records each token's start bit and writes run
+// headers and match codes.  Literal bytes are written by lz77_pack_literals_kernel.
+__global__ __launch_bounds__(1024) void lz77_pack_tokens_kernel(const LzJobDev* __restrict__ jobs) {
+  const LzJobDev J = jobs[blockIdx.x];
+  const u32 ntok = J.result[0];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  u32* out32 = (u32*)J.out;
+  // items 0..ntok-1 = (gap before match t, match t); item ntok = trailing literal gap
+  for (u32 t0 = 0; t0 <= ntok; t0 += 1024) {
+    const u32 t = t0 + tid;
+    u64 cost = 0; u32 gap = 0, gstart = 0, pos = 0, len = 0, off = 0;
+    if (t <= ntok) {
+      gstart = t ? J.tok_pos[t - 1] + J.tok_len[t - 1] : 0u;
+      if (t < ntok) { pos = J.tok_pos[t]; len = J.tok_len[t]; off = J.tok_off[t]; } else pos = J.n;
+      gap = pos - gstart;
+      cost = lit_gap_bits(gap) + (t < ntok ? match_bits(len, off, J.rb) : 0u);
+    }
+    // inclusive scan within the workgroup
+    u64 x = cost;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u64 y = __shfl_up((unsigned long long)x, d); if (lane >= (u32)d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u64 wbase = 0;
+    for (u32 w = 0; w < wave; ++w) wbase += wsum[w];
+    const u64 carry = carry_s;
+    const u64 start = carry + wbase + x - cost;
+    if (t <= ntok) {
+      if (t < ntok) J.tok_bit[t] = (u32)start; else J.tok_bit[ntok] = (u32)start;
+      // literal run headers of the gap
+      u64 bp = start; u32 g = gap;
+      while (g) {
+        const u32 r = g < kMaxLiteral ? g : kMaxLiteral;
+        put_lit_header(out32, bp, r);
+        bp += lit_run_header_bits(r) + 8ull * r; g -= r;
+      }
+      if (t < ntok) put_match(out32, bp, len, off, J.rb);
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const u64 bits = carry_s;
+    const u64 bytes = (bits + 7) >> 3;
+    J.result[1] = (u32)bytes;
+    if (bytes > J.out_cap) J.result[2] = 1;
+  }
+}
+
+// Literal bytes: one thread per input position.
+__global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev* __restrict__ jobs) {
+  const LzJobDev J = jobs[blockIdx.y];
+  const u32 x = blockIdx.x * 256u + threadIdx.x;
+  const u32 ntok = J.result[0];
+  // wave-uniform lower bound for the first position of this wave, then a short per-lane search
+  const u32 x0 = __builtin_amdgcn_readfirstlane(x);
+  if (x0 >= J.n) return;
+  u32 lo = 0, hi = ntok;  // first token with tok_pos > x0
+  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (J.tok_pos[mid] > x0) hi = mid; else lo = mid + 1; }
+  if (x >= J.n) return;
+  u32 t = lo;
+  while (t < ntok && J.tok_pos[t] <= x) ++t;  // <= 16 steps: matches are >= 4 bytes apart
+  const u32 gstart = t ? J.tok_pos[t - 1] + J.tok_len[t - 1] : 0u;
+  if (x < gstart) return;  // inside match t-1
+  const u32 gend = t < ntok ? J.tok_pos[t] : J.n;
+  const u32 g = gend - gstart, r = x - gstart;
+  const u32 run = r / kMaxLiteral, within = r % kMaxLiteral;
+  const u32 runlen = (run < g / kMaxLiteral) ? kMaxLiteral : g % kMaxLiteral;
+  const u64 bp = (u64)J.tok_bit[t] + (u64)run * (lit_run_header_bits(kMaxLiteral) + 8ull * kMaxLiteral) +
+                 lit_run_header_bits(runlen) + 8ull * within;
+  or_bits((u32*)J.out, bp, J.in[x], 8);
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------
+extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 512 + 64; }
+
+static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
+  if ((a[1] & 3) != 1 || a[1] > 5) return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 level %d not implemented", a[1]);
+  if (a[3] != 0 || a[6] != 0) return zpq_fail(ctx, ZPQ_ERR_METHOD, "secondary context not implemented");
+  if (a[2] < 4 || a[2] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
+  if (a[4] < 0 || a[4] > 3) return zpq_fail(ctx, ZPQ_ERR_METHOD, "bucket 2^%d not implemented", a[4]);
+  if (a[0] < 0 || a[0] > 6 || a[5] - a[0] >= 21 || a[5] < 4 || a[5] > 26 || a[5] <= a[4])
+    return zpq_fail(ctx, ZPQ_ERR_METHOD, "hash table 2^%d out of range", a[5]);
+  if ((u64)n > (1ull << (20 + a[0]))) return zpq_fail(ctx, ZPQ_ERR_ARG, "block of %u bytes exceeds 2^%d", n, 20 + a[0]);
+  return ZPQ_OK;
+}
+
+template <typename T>
+static T* carve(u8*& p, size_t count) {
+  T* r = (T*)p;
+  p += (count * sizeof(T) + 255) & ~(size_t)255;
+  return r;
+}
+
+// Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
+static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) {
+  hipStream_t st = ctx->stream;
+  const size_t nj = hi - lo;
+  std::vector<LzJobDev> hj(nj);
+  std::vector<LzSegDev> hs;
+  size_t table_words = 0, tok_words = 0;
+  u32 max_n = 0, max_seg = 1;
+  for (size_t i = 0; i < nj; ++i) {
+    const zpq_lz77_job& z = jobs[lo + i];
+    const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
+    const size_t words = (size_t)1 << z.args[5];
+    table_words += words * (2 * (size_t)nseg - 1);
+    tok_words += ((size_t)z.n / 4 + 2) * 4;                 // final pos/len/off/bit
+    for (u32 k = 0; k < nseg; ++k) {
+      const u32 x0 = k * kSegBytes, x1 = std::min<u64>((u64)x0 + kSegBytes, z.n);
+      tok_words += ((size_t)(x1 - x0) / 4 + 2) * 3;
+    }
+    max_seg = std::max(max_seg, nseg);
+  }
+  size_t nseg_total = 0;
+  for (size_t i = 0; i < nj; ++i) nseg_total += std::max<u32>(1, (jobs[lo + i].n + kSegBytes - 1) / kSegBytes);
+  u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
+  u32* d_tok = (u32*)zpq_scratch(ctx, 1, tok_words * 4 + 256);
+  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4) + nseg_total * (sizeof(LzSegDev) + 16 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
+  u8* d_meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
+  if (!d_tab || !d_tok || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 scratch (%zu MiB of tables)", table_words >> 18);
+  u8* mp = d_meta;
+  LzJobDev* d_jobs = carve<LzJobDev>(mp, nj);
+  LzSegDev* d_segs = carve<LzSegDev>(mp, nseg_total);
+  u32* d_res = carve<u32>(mp, nj * 4);
+  u32* d_state = carve<u32>(mp, nseg_total * 4);
+  u32* d_lists = carve<u32>(mp, (nj + nseg_total) * 4);      // per bucket width: job list, segment list
+  CopyJob* d_copy = carve<CopyJob>(mp, nseg_total * 2);
+  ScatterJob* d_scat = carve<ScatterJob>(mp, nseg_total);
+  ZPQ_HIP(ctx, hipMemsetAsync(d_res, 0, nj * 16, st));
+
+  size_t to = 0, tabo = 0;
+  std::vector<std::vector<CopyJob>> copy_step(max_seg);      // step k: build pristine[k]
+  std::vector<std::vector<ScatterJob>> scat_step(max_seg);
+  std::vector<CopyJob> copy_work;
+  for (size_t i = 0; i < nj; ++i) {
+    zpq_lz77_job& z = jobs[lo + i];
+    const int32_t* a = z.args;
+    LzCfg c;
+    c.in = z.d_in; c.n = z.n; c.minMatch = a[2]; c.bucket = (1u << a[4]) - 1; c.htbits = a[5]; c.checkbits = 12 - a[0];
+    c.shift1 = (a[5] - 1) / a[2] + 1; c.rb = a[0] > 4 ? a[0] - 4 : 0;
+    const u32 mmb = a[2] + 4;
+    c.upd_limit = z.n > mmb ? z.n - mmb : 0;
+    const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
+    const size_t words = (size_t)1 << a[5];
+    LzJobDev& J = hj[i];
+    J.in = z.d_in; J.n = z.n; J.rb = c.rb; J.nseg = nseg; J.seg0 = (u32)hs.size();
+    const u32 cap = z.n / 4 + 2;
+    J.tok_pos = d_tok + to; J.tok_len = J.tok_pos + cap; J.tok_off = J.tok_len + cap; J.tok_bit = J.tok_off + cap;
+    J.tok_cap = cap - 1; to += (size_t)cap * 4;
+    J.result = d_res + 4 * i; J.out = z.d_out; J.out_cap = z.out_cap;
+    ZPQ_HIP(ctx, hipMemsetAsync(J.out, 0, J.out_cap, st));
+    // tables: work[0..nseg-1], pristine[1..nseg-1]
+    u32* work0 = d_tab + tabo;
+    u32* prist0 = work0 + words * nseg - words;   // pristine[k] = prist0 + k*words, k >= 1
+    tabo += words * (2 * (size_t)nseg - 1);
+    copy_step[0].push_back({nullptr, work0, (u32)words});
+    for (u32 k = 0; k < nseg; ++k) {
+      LzSegDev S;
+      S.c = c; S.x0 = k * kSegBytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + kSegBytes, z.n);
+      S.work = work0 + words * k;
+      S.pristine = k ? prist0 + words * k : nullptr;
+      const u32 scap = (S.x1 - S.x0) / 4 + 2;
+      S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap - 1; to += (size_t)scap * 3;
+      S.state = d_state + 4 * hs.size();
+      if (k) {
+        copy_step[k].push_back({k == 1 ? nullptr : prist0 + words * (k - 1), S.pristine, (u32)words});
+        scat_step[k].push_back({c, (k - 1) * kSegBytes, k * kSegBytes, S.pristine});
+        copy_work.push_back({S.pristine, S.work, (u32)words});
+      }
+      hs.push_back(S);
+    }
+    max_n = std::max(max_n, z.n);
+  }
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), nj * sizeof(LzJobDev), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_segs, hs.data(), hs.size() * sizeof(LzSegDev), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  // 1. table states at the segment starts: pristine[k] = pristine[k-1] + inserts of segment k-1
+  {
+    std::vector<CopyJob> cj; std::vector<ScatterJob> sj;
+    std::vector<std::pair<size_t, size_t>> crange(max_seg), srange(max_seg);
+    for (u32 k = 0; k < max_seg; ++k) {
+      crange[k] = {cj.size(), copy_step[k].size()}; cj.insert(cj.end(), copy_step[k].begin(), copy_step[k].end());
+      srange[k] = {sj.size(), scat_step[k].size()}; sj.insert(sj.end(), scat_step[k].begin(), scat_step[k].end());
+    }
+    const size_t work_at = cj.size();
+    cj.insert(cj.end(), copy_work.begin(), copy_work.end());
+    if (!cj.empty()) ZPQ_HIP(ctx, hipMemcpyAsync(d_copy, cj.data(), cj.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st));
+    if (!sj.empty()) ZPQ_HIP(ctx, hipMemcpyAsync(d_scat, sj.data(), sj.size() * sizeof(ScatterJob), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    for (u32 k = 0; k < max_seg; ++k) {
+      if (crange[k].second) {
+        ZPQ_LAUNCH(ctx, "lz77_table_copy_kernel", st, lz77_table_copy_kernel, dim3(256, (unsigned)crange[k].second), dim3(256),
+                   d_copy + crange[k].first);
+        ZPQ_HIP(ctx, hipGetLastError());
+      }
+      if (srange[k].second) {
+        ZPQ_LAUNCH(ctx, "lz77_table_scatter_kernel", st, lz77_table_scatter_kernel, dim3(kSegBytes / 1024, (unsigned)srange[k].second),
+                   dim3(256), d_scat + srange[k].first);
+        ZPQ_HIP(ctx, hipGetLastError());
+      }
+    }
+    if (!copy_work.empty()) {
+      ZPQ_LAUNCH(ctx, "lz77_table_copy_kernel", st, lz77_table_copy_kernel, dim3(256, (unsigned)copy_work.size()), dim3(256),
+                 d_copy + work_at);
+      ZPQ_HIP(ctx, hipGetLastError());
+    }
+  }
+  // 2. speculative parse of every segment, 3. the true chain per block -- one launch per bucket width
+  std::vector<u32> lists;
+  struct Rng { size_t joff, jn, soff, sn; } rng[4];
+  for (int nb = 0; nb <= 3; ++nb) {
+    rng[nb].joff = lists.size();
+    for (size_t i = 0; i < nj; ++i) if (jobs[lo + i].args[4] == nb) lists.push_back((u32)i);
+    rng[nb].jn = lists.size() - rng[nb].joff;
+    rng[nb].soff = lists.size();
+    for (size_t i = 0; i < nj; ++i)
+      if (jobs[lo + i].args[4] == nb) for (u32 k = 0; k < hj[i].nseg; ++k) lists.push_back(hj[i].seg0 + k);
+    rng[nb].sn = lists.size() - rng[nb].soff;
+  }
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  for (int nb = 0; nb <= 3; ++nb) {
+    if (!rng[nb].sn) continue;
+    dim3 gs((unsigned)rng[nb].sn), gj((unsigned)rng[nb].jn), blk(64);
+    const u32* sl = d_lists + rng[nb].soff; const u32* jl = d_lists + rng[nb].joff;
+    switch (nb) {
+      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl);
+               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+    }
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  // 4. tokens -> bits
+  ZPQ_LAUNCH(ctx, "lz77_pack_tokens_kernel", st, lz77_pack_tokens_kernel, dim3((unsigned)nj), dim3(1024), d_jobs);
+  ZPQ_HIP(ctx, hipGetLastError());
+  if (max_n) {
+    ZPQ_LAUNCH(ctx, "lz77_pack_literals_kernel", st, lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)nj), dim3(256), d_jobs);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  std::vector<u32> res(nj * 4);
+  ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  for (size_t i = 0; i < nj; ++i) {
+    jobs[lo + i].n_matches = res[4 * i];
+    jobs[lo + i].out_len = res[4 * i + 1];
+    if (res[4 * i + 2]) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: token or output capacity exceeded", lo + i);
+  }
+  return ZPQ_OK;
+}
+
+extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs) {
+  if (njobs == 0) return ZPQ_OK;
+  for (size_t i = 0; i < njobs; ++i) {
+    int rc = check_args(ctx, jobs[i].args, jobs[i].n);
+    if (rc) return rc;
+    if (jobs[i].out_cap < zpq_lz77_bound(jobs[i].n)) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: out_cap too small", i);
+    if (((uintptr_t)jobs[i].d_out & 3) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: d_out must be 4-byte aligned", i);
+  }
+  // batches whose hash tables (2*segments-1 copies each) fit a fixed HBM budget
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t budget = std::max<size_t>((size_t)2 << 30, std::min<size_t>((size_t)48 << 30, (free_b + ctx->scratch_cap[0]) / 3));
+  size_t lo = 0;
+  while (lo < njobs) {
+    size_t hi = lo, bytes = 0;
+    while (hi < njobs) {
+      const u32 nseg = std::max<u32>(1, (jobs[hi].n + kSegBytes - 1) / kSegBytes);
+      const size_t b = ((size_t)4 << jobs[hi].args[5]) * (2 * (size_t)nseg - 1);
+      if (hi > lo && bytes + b > budget) break;
+      bytes += b; ++hi;
+    }
+    int rc = encode_batch(ctx, jobs, lo, hi);
+    if (rc) return rc;
+    lo = hi;
+  }
+  return ZPQ_OK;
+}
