@@ -212,8 +212,7 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_off, sha_off.data(), sha_off.size() * 8, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_len, sha_len.data(), sha_len.size() * 4, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
-    int rc = zpq_sha1_extents_on(ctx, ctx->stream2, (const u8*)0, d_sha_off, d_sha_len, sha_job.size(), d_dig,
-                                  "sha1_extents_kernel[block_chains]");
+    int rc = zpq_sha1_chains_on(ctx, ctx->stream2, (const u8*)0, d_sha_off, d_sha_len, sha_job.size(), d_dig);
     if (rc) return rc;
     ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
   }

@@ -12,26 +12,35 @@ namespace {
 
 struct Sha1State { u32 a, b, c, d, e; };
 
+// gfx950 three-operand integer ops; hipcc does not form them reliably from C, and the SHA round
+// count is what bounds these kernels (VALU issue), so they are spelled out.
+__device__ __forceinline__ u32 add3(u32 a, u32 b, u32 c) { u32 r; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }   // no v_xor3_b32 on gfx950
+// (x & m) | (y & ~m)
+__device__ __forceinline__ u32 bfi(u32 m, u32 x, u32 y) { u32 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(x), "v"(y)); return r; }
+
+#define SHA1_W(t) (w[(t) & 15] = rotl32(xor3(w[((t) + 13) & 15], w[((t) + 8) & 15], w[((t) + 2) & 15]) ^ w[(t) & 15], 1))
+#define SHA1_R(f, k, wt)                                          \
+  {                                                               \
+    const u32 t1 = add3(e, (k), (wt));                            \
+    const u32 tmp = add3(rotl32(a, 5), (f), t1);                  \
+    e = d; d = c; c = rotl32(b, 30); b = a; a = tmp;              \
+  }
+#define SHA1_80_ROUNDS(WT0, WT)                                                       \
+  _Pragma("unroll") for (int t = 0; t < 16; ++t) SHA1_R(bfi(b, c, d), K0, WT0(t))     \
+  _Pragma("unroll") for (int t = 16; t < 20; ++t) SHA1_R(bfi(b, c, d), K0, WT(t))     \
+  _Pragma("unroll") for (int t = 20; t < 40; ++t) SHA1_R(xor3(b, c, d), K1, WT(t))    \
+  _Pragma("unroll") for (int t = 40; t < 60; ++t) SHA1_R(bfi(b ^ c, d, c), K2, WT(t)) \
+  _Pragma("unroll") for (int t = 60; t < 80; ++t) SHA1_R(xor3(b, c, d), K3, WT(t))
+
 __device__ __forceinline__ void sha1_rounds(u32 (&w)[16], Sha1State& s) {
   u32 a = s.a, b = s.b, c = s.c, d = s.d, e = s.e;
-#define W(t) (w[(t) & 15] = rotl32(w[((t) + 13) & 15] ^ w[((t) + 8) & 15] ^ w[((t) + 2) & 15] ^ w[(t) & 15], 1))
-#define R(f, k, wt)                                  \
-  {                                                  \
-    u32 tmp = rotl32(a, 5) + (f) + e + (k) + (wt);   \
-    e = d; d = c; c = rotl32(b, 30); b = a; a = tmp; \
-  }
-#pragma unroll
-  for (int t = 0; t < 16; ++t) R((b & c) | (~b & d), 0x5A827999u, w[t])
-#pragma unroll
-  for (int t = 16; t < 20; ++t) R((b & c) | (~b & d), 0x5A827999u, W(t))
-#pragma unroll
-  for (int t = 20; t < 40; ++t) R(b ^ c ^ d, 0x6ED9EBA1u, W(t))
-#pragma unroll
-  for (int t = 40; t < 60; ++t) R((b & c) | (b & d) | (c & d), 0x8F1BBCDCu, W(t))
-#pragma unroll
-  for (int t = 60; t < 80; ++t) R(b ^ c ^ d, 0xCA62C1D6u, W(t))
-#undef R
-#undef W
+  // round constants in VGPRs: v_add3_u32 takes one literal/SGPR at most, registers are cheaper
+  u32 K0 = 0x5A827999u, K1 = 0x6ED9EBA1u, K2 = 0x8F1BBCDCu, K3 = 0xCA62C1D6u;
+  asm volatile("" : "+v"(K0), "+v"(K1), "+v"(K2), "+v"(K3));
+#define WT0(t) w[t]
+  SHA1_80_ROUNDS(WT0, SHA1_W)
+#undef WT0
   s.a += a; s.b += b; s.c += c; s.d += d; s.e += e;
 }
 
@@ -183,12 +192,85 @@ __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restric
   }
 }
 
+// ---- one long chain per WAVE ------------------------------------------------------------------------
+// A ZPAQ segment checksum covers a whole block (up to 16 MiB and more): a single Merkle-Damgard
+// chain that no amount of lanes can split.  What can be taken off the chain is everything that does
+// not depend on the running state: the 64 lanes of a wave load, byte-swap and expand the message
+// schedule of the next 64 blocks in parallel (80 words per lane), and the 80 serial rounds of each
+// block then run on wave-uniform values -- the state lives in SGPRs, W[t] arrives by v_readlane.
+// All lanes run the 80 rounds on their own block's schedule from the same (uniform) input state;
+// only lane b holds the true successor state, which is then broadcast with five v_readlane.
+__device__ __forceinline__ void sha1_rounds_lane(const u32 (&w)[80], int blk, Sha1State& s) {
+  u32 a = s.a, b = s.b, c = s.c, d = s.d, e = s.e;
+  u32 K0 = 0x5A827999u, K1 = 0x6ED9EBA1u, K2 = 0x8F1BBCDCu, K3 = 0xCA62C1D6u;
+  asm volatile("" : "+v"(K0), "+v"(K1), "+v"(K2), "+v"(K3));
+#define WT(t) w[t]
+  SHA1_80_ROUNDS(WT, WT)
+#undef WT
+  s.a += __builtin_amdgcn_readlane(a, blk); s.b += __builtin_amdgcn_readlane(b, blk);
+  s.c += __builtin_amdgcn_readlane(c, blk); s.d += __builtin_amdgcn_readlane(d, blk);
+  s.e += __builtin_amdgcn_readlane(e, blk);
+}
+
+__global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                        const u32* __restrict__ len, u8* __restrict__ digests) {
+  const u32 idx = blockIdx.x;
+  const int lane = lane_id();
+  const u8* p = base + off[idx];
+  const u64 total = len[idx];
+  const u64 nfull = total >> 6;   // whole 64-byte blocks
+  Sha1State s = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+  for (u64 b0 = 0; b0 < nfull; b0 += 64) {
+    const u64 mine = b0 + (u64)lane;
+    u32 w[80];
+    if (mine < nfull) {
+      const u32x4_u* q = (const u32x4_u*)(p + mine * 64);
+      const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+      w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+      w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+      w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) w[t] = 0;
+    }
+#pragma unroll
+    for (int t = 16; t < 80; ++t) w[t] = rotl32(xor3(w[t - 3], w[t - 8], w[t - 14]) ^ w[t - 16], 1);
+    const int cnt = nfull - b0 < 64 ? (int)(nfull - b0) : 64;
+    for (int b = 0; b < cnt; ++b) sha1_rounds_lane(w, b, s);
+  }
+  // closing block(s): every lane computes the same thing, lane 0 stores
+  {
+    const u8* q = p + nfull * 64;
+    u32 rem = (u32)(total & 63);
+    bool marker = false, last = false;
+    while (!last) {
+      u32 w[16];
+      last = tail_block(w, q, rem, marker, total);
+      q += rem; rem = 0;
+      sha1_rounds(w, s);
+    }
+  }
+  if (lane == 0) {
+    u32* o = (u32*)(digests + (size_t)idx * 20);
+    o[0] = bswap32(s.a); o[1] = bswap32(s.b); o[2] = bswap32(s.c); o[3] = bswap32(s.d); o[4] = bswap32(s.e);
+  }
+}
+
 int persistent_grid(zpq_ctx* ctx, size_t n) {
   size_t blocks = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
   return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
 }  // namespace
+
+int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
+                       u8* d_digests) {
+  if (n == 0) return ZPQ_OK;
+  ZPQ_LAUNCH(ctx, "sha1_chain_kernel", s, sha1_chain_kernel, dim3((unsigned)n), dim3(64), d_base, d_off, d_len, d_digests);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
 
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                         u8* d_digests, const char* prof_name) {

@@ -76,5 +76,8 @@ static __device__ __forceinline__ u32 rotr32(u32 x, int k) { return __builtin_ro
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // internal cross-TU entry points
+// one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
+int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
+                       u8* d_digests);
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off,
                         const u32* d_len, size_t n, u8* d_digests, const char* prof_name = "sha1_extents_kernel");
