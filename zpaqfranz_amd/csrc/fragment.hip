@@ -4,21 +4,23 @@
 // (reference: zpaqfranz.cpp is absent from the snapshot; algorithm per SURVEY.md Appendix C.4, its
 // output records are read back at ZSFX/zsfx.cpp:1463-1500 and pinned by AUTOTEST/sha256.zpaq).
 //
-// MI355X formulation -- exact, no heuristics:
-//  * Inside a fragment a WAVE evaluates 64 consecutive bytes per step.  The order-1 prediction
-//    o1[c1] of lane l is the successor of the latest earlier occurrence of its predecessor byte:
-//    either an earlier lane of the same window (found with one 64-bit LDS atomic-OR mask per byte
-//    value) or the 256-entry LDS table as of the window start.  The hash recurrence is the affine
-//    map h -> m*h + (c+1)*m (mod 2^32); a wave-wide inclusive scan composes the 64 maps, so all 64
-//    hash values, and therefore the first cut in the window, come out of ~6 shuffle steps.
-//  * Across a file the chain "cut k decides where fragment k+1 starts" is serial.  Files are split
-//    into 1 MiB segments; every segment is fragmented speculatively from its own start
-//    (fragment_spec_kernel, one wave per segment), then one wave per file walks the true chain
-//    (fragment_stitch_kernel): it evaluates exactly until one of its cuts coincides with a
-//    speculative cut -- from there on both chains are in the same (reset) state, so the rest of
-//    that segment's speculative cuts are adopted verbatim.  Worst case (never coinciding, e.g. a
-//    file of zeros) degrades to one wave per file, still exact.
-// Integer-only byte work; bound by VALU/LDS issue, traffic = input read ~1.1x (seam re-reads).
+// MI355X formulation -- exact, no heuristics.  The recurrence is serial per fragment and "cut k
+// decides where fragment k+1 starts" is serial per file, so the parallelism is speculative:
+//  1. fragment_spec_kernel: files are split into 1 MiB segments and EVERY LANE fragments one segment
+//     from its own start, as if a fragment began there.  Lane-serial is the instruction-efficient
+//     shape for this loop (~12 VALU per byte-step of 64 lanes): each lane owns a 256-entry o1[] table
+//     in LDS (bank = lane, conflict free) and streams its segment 16 bytes per load; the 16 LDS
+//     read/write pairs of a group are issued back to back, the multiply chain runs on registers, and
+//     only a group whose minimum hash falls under the threshold is re-walked byte by byte.
+//  2. fragment_seam_kernel: one lane per segment boundary continues from the last speculative cut of
+//     segment k across the boundary until one of its cuts coincides with a speculative cut of the
+//     next segment: from there both chains are in the same (reset) state.
+//  3. fragment_stitch_kernel: one wave per file glues the pieces: speculative cuts, seam cuts,
+//     speculative cuts ... -- every hand-over is verified (the seam must start where the previous
+//     piece ended), and anything that does not line up (never-synchronising data such as runs of
+//     zeros) is re-evaluated exactly by the wave-parallel evaluator below (64 bytes per step:
+//     in-window o1 forwarding through 64-bit LDS masks, affine-map scan for the hash).
+// Integer-only byte work; traffic = input read ~1.1x (seam re-reads); bound by VALU/LDS issue.
 #include <algorithm>
 
 #include "zpq_internal.h"
@@ -120,44 +122,191 @@ __device__ u64 eval_fragment(ByteReader& rd, WaveLds& L, u64 S, u64 file_end, u6
   }
 }
 
-// ---- speculative pass: one wave per 1 MiB segment ---------------------------------------------
-__global__ __launch_bounds__(256) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable,
-                                                             const u64* __restrict__ file_off,
-                                                             const u32* __restrict__ seg_file,
-                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
-                                                             u32 spec_cap, u32* __restrict__ spec_rel,
-                                                             u32* __restrict__ spec_cnt) {
-  __shared__ WaveLds lds[4];
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const u64 s = (u64)blockIdx.x * 4 + wave;
-  lds[wave].M[lane] = 0; lds[wave].M[lane + 64] = 0; lds[wave].M[lane + 128] = 0; lds[wave].M[lane + 192] = 0;
-  __builtin_amdgcn_wave_barrier();
-  if (s >= nseg) return;
-  const u32 f = seg_file[s];
-  const u64 fs = file_off[f], fe = file_off[f + 1];
-  const u64 g = fs + (s - seg_base[f]) * kSegBytes;
-  const u64 ge = g + kSegBytes < fe ? g + kSegBytes : fe;
-  ByteReader rd{data, readable, 0, 0, 0, 0};
-  rd.init(g);
-  u32* out = spec_rel + s * (u64)spec_cap;
-  u32 cnt = 0;
-  u64 S = g;
-  while (S < ge) {
-    u64 E = eval_fragment(rd, lds[wave], S, fe, ge, P);
-    if (E == kNone) break;
-    if (lane == 0 && cnt < spec_cap) out[cnt] = (u32)(E - g);
-    ++cnt;
-    S = E + 1;
+
+// ---- lane-serial evaluator ------------------------------------------------------------------------
+// o1[] of lane l lives at byte ((v>>2)*2 + (l>>5))*128 + (l&31)*4 + (v&3) of a 16 KiB per-wave block:
+// every lane of a 32-lane half hits its own bank whatever v is.
+struct LaneO1 {
+  volatile u8* t;
+  u32 lanebase;
+  __device__ __forceinline__ u32 addr(u32 v) const { return lanebase + (((v << 6) & 0xFF00u) | (v & 3u)); }
+  __device__ __forceinline__ void clear() {
+    volatile u32* w = (volatile u32*)(t + lanebase);
+#pragma unroll
+    for (int a = 0; a < 64; ++a) w[a * 64] = 0;
   }
-  if (lane == 0) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;
+};
+struct LaneState { u32 h, c1, sz; };
+
+__device__ __forceinline__ u32 byte_of(const u32x4& d, int j) {
+  const u32 w = j < 4 ? d.x : j < 8 ? d.y : j < 12 ? d.z : d.w;
+  return (w >> (8 * (j & 3))) & 255u;
 }
 
-// ---- exact chain: one wave per file -------------------------------------------------------------
+// Advances this lane's stream by one 16-byte group (or one byte near the end of [pos, lim)).
+// on_cut(E) is called for every cut; the lane is finished when pos >= lim.
+template <class OnCut>
+__device__ __forceinline__ void lane_step(const u8* __restrict__ data, u64& pos, const u64 lim, const u64 file_end,
+                                          const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
+  if (pos + 16 <= lim) {
+    const u32x4 d = *(const u32x4_u*)(data + pos);
+    u32 c[16], pr[16];
+    u32 prev = s.c1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {          // 16 in-order LDS read/write pairs, nothing waits in between
+      c[j] = byte_of(d, j);
+      const u32 a = o.addr(prev);
+      pr[j] = o.t[a];
+      o.t[a] = (u8)c[j];
+      prev = c[j];
+    }
+    u32 h = s.h, hmin = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      h = (h + c[j] + 1u) * (c[j] == pr[j] ? 314159265u : 271828182u);
+      hmin = hmin < h ? hmin : h;
+    }
+    const bool maybe = (hmin < P.thresh && s.sz + 16 >= P.minf) || s.sz + 16 >= P.maxf || pos + 16 == file_end;
+    if (!maybe) { s.h = h; s.c1 = prev; s.sz += 16; pos += 16; return; }
+    // rare: locate the first cut of this group exactly
+    u32 hh = s.h, sz = s.sz; int cutj = -1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      hh = (hh + c[j] + 1u) * (c[j] == pr[j] ? 314159265u : 271828182u);
+      ++sz;
+      if (cutj < 0 && (sz >= P.maxf || (hh < P.thresh && sz >= P.minf) || pos + j + 1 == file_end)) cutj = j;
+    }
+    if (cutj < 0) { s.h = h; s.c1 = prev; s.sz += 16; pos += 16; return; }
+    const u64 E = pos + (u64)cutj;
+    on_cut(E);
+    o.clear();            // also wipes what the bytes after the cut wrote: they are re-walked from E+1
+    s.h = 0; s.c1 = 0; s.sz = 0;
+    pos = E + 1;
+    return;
+  }
+  if (pos < lim) {        // fewer than 16 bytes left: one byte per call
+    const u32 c = data[pos];
+    const u32 a = o.addr(s.c1);
+    const u32 pr = o.t[a];
+    o.t[a] = (u8)c;
+    s.h = (s.h + c + 1u) * (c == pr ? 314159265u : 271828182u);
+    s.c1 = c; ++s.sz;
+    if (s.sz >= P.maxf || (s.h < P.thresh && s.sz >= P.minf) || pos + 1 == file_end) {
+      on_cut(pos);
+      o.clear();
+      s.h = 0; s.c1 = 0; s.sz = 0;
+    }
+    ++pos;
+  }
+}
+
+// ---- 1. speculative pass: one LANE per 1 MiB segment ----------------------------------------------
+__global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                                                            const u32* __restrict__ seg_file,
+                                                            const u64* __restrict__ seg_base, u64 nseg, FragP P,
+                                                            u32 spec_cap, u32* __restrict__ spec_rel,
+                                                            u32* __restrict__ spec_cnt) {
+  __shared__ u8 tab[16384];
+  const u32 lane = (u32)lane_id();
+  const u64 s = (u64)blockIdx.x * 64 + lane;
+  LaneO1 o{tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
+  o.clear();
+  bool active = s < nseg;
+  u64 pos = 0, lim = 0, fe = 0, g = 0;
+  if (active) {
+    const u32 f = seg_file[s];
+    const u64 fs = file_off[f];
+    fe = file_off[f + 1];
+    g = fs + (s - seg_base[f]) * kSegBytes;
+    lim = g + kSegBytes < fe ? g + kSegBytes : fe;
+    pos = g;
+  }
+  LaneState st{0, 0, 0};
+  u32 cnt = 0;
+  u32* out = spec_rel + s * (u64)spec_cap;
+  while (__any(active)) {
+    if (active) {
+      lane_step(data, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
+      active = pos < lim;
+    }
+  }
+  if (s < nseg) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;
+}
+
+// ---- 2. seams: one LANE per segment boundary ---------------------------------------------------------
+// seam k of a file continues from the last speculative cut of segment k until it is back in step with a
+// later segment's speculation (or has run past segment k+1 without meeting it).
+struct SeamOut { u64 start; u64 cont; u32 cnt; u32 sync_seg; u32 sync_from; u32 pad; };
+constexpr u32 kNoSync = 0xffffffffu;
+
+__global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                                                            const u32* __restrict__ seg_file,
+                                                            const u64* __restrict__ seg_base, u64 nseg, FragP P,
+                                                            u32 spec_cap, const u32* __restrict__ spec_rel,
+                                                            const u32* __restrict__ spec_cnt,
+                                                            SeamOut* __restrict__ seam, u32* __restrict__ seam_rel) {
+  __shared__ u8 tab[16384];
+  const u32 lane = (u32)lane_id();
+  const u64 s = (u64)blockIdx.x * 64 + lane;      // seam after segment s (within the same file)
+  LaneO1 o{tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
+  o.clear();
+  bool active = false;
+  u64 pos = 0, lim = 0, fe = 0, fs = 0, g = 0, sb = 0;
+  u32 k = 0, nsegf = 0;
+  SeamOut so{~0ull, 0, 0, kNoSync, 0, 0};
+  if (s < nseg) {
+    const u32 f = seg_file[s];
+    fs = file_off[f]; fe = file_off[f + 1]; sb = seg_base[f];
+    k = (u32)(s - sb);
+    nsegf = (u32)((fe - fs + kSegBytes - 1) / kSegBytes);
+    g = fs + (u64)k * kSegBytes;
+    const u32 nk = spec_cnt[s];
+    if (k + 1 < nsegf && nk > 0 && nk < spec_cap) {
+      so.start = g + spec_rel[s * (u64)spec_cap + nk - 1] + 1;
+      pos = so.start;
+      lim = g + 2 * kSegBytes < fe ? g + 2 * kSegBytes : fe;     // give up at the end of segment k+1
+      active = true;
+      if (pos == g + kSegBytes) { so.sync_seg = k + 1; so.sync_from = 0; active = false; }   // cut on the boundary
+    }
+  }
+  LaneState st{0, 0, 0};
+  u32* out = seam_rel + s * (u64)spec_cap;
+  while (__any(active)) {
+    if (active) {
+      bool synced = false;
+      lane_step(data, pos, lim, fe, P, o, st, [&](u64 E) {
+        if (so.cnt < spec_cap) out[so.cnt] = (u32)(E - g);
+        ++so.cnt;
+        if (E + 1 >= fe) { so.sync_seg = nsegf; so.sync_from = 0; synced = true; return; }   // reached EOF
+        const u32 k2 = (u32)((E - fs) / kSegBytes);
+        if ((E + 1 - fs) % kSegBytes == 0) { so.sync_seg = k2 + 1; so.sync_from = 0; synced = true; return; }
+        if (k2 > k) {                           // is E a speculative cut of its segment?
+          const u64 s2 = sb + k2;
+          const u32* rel = spec_rel + s2 * (u64)spec_cap;
+          const u32 want = (u32)(E - (fs + (u64)k2 * kSegBytes));
+          u32 lo = 0, hi = spec_cnt[s2];
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (rel[mid] < want) lo = mid + 1; else hi = mid; }
+          if (lo < spec_cnt[s2] && rel[lo] == want) { so.sync_seg = k2; so.sync_from = lo + 1; synced = true; }
+        }
+      });
+      active = !synced && pos < lim;
+    }
+  }
+  if (s < nseg) {
+    so.cont = pos;
+    if (so.cnt > spec_cap) { so.start = ~0ull; }      // overflow: never trusted
+    seam[s] = so;
+  }
+}
+
+// ---- 3. exact chain: one wave per file ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restrict__ data, u64 readable,
                                                                const u64* __restrict__ file_off, u32 nfiles,
                                                                const u64* __restrict__ seg_base, FragP P, u32 spec_cap,
                                                                const u32* __restrict__ spec_rel,
                                                                const u32* __restrict__ spec_cnt,
+                                                               const SeamOut* __restrict__ seam,
+                                                               const u32* __restrict__ seam_rel,
                                                                const u64* __restrict__ cut_base,
                                                                u64* __restrict__ cuts, u32* __restrict__ cut_cnt) {
   __shared__ WaveLds lds[4];
@@ -167,46 +316,53 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
   __builtin_amdgcn_wave_barrier();
   if (f >= nfiles) return;
   const u64 fs = file_off[f], fe = file_off[f + 1];
+  const u64 sb = seg_base[f];
+  const u32 nsegf = (u32)((fe - fs + kSegBytes - 1) / kSegBytes);
   u64* out = cuts + cut_base[f];
   u32 cnt = 0;
   ByteReader rd{data, readable, 0, 0, 0, 0};
-  u64 S = fs;
-  bool sync = true, rd_ready = false;
+  u64 S = fs;                 // start of the next fragment of the true chain
+  bool synced = true;         // true chain == speculation of segment k from its cut index `from`
+  u32 k = 0, from = 0;
   while (S < fe) {
-    if (sync) {
-      // adopt the speculative cuts of S's segment that lie at or after S
-      const u64 k = (S - fs) / kSegBytes;
-      const u64 sidx = seg_base[f] + k;
-      const u64 g = fs + k * kSegBytes;
+    if (synced) {
+      if (k >= nsegf) break;
+      const u64 sidx = sb + k;
+      const u64 g = fs + (u64)k * kSegBytes;
       const u32 nk = spec_cnt[sidx];
       const u32* rel = spec_rel + sidx * (u64)spec_cap;
-      u32 j0 = 0;
-      for (u32 j = lane; j < nk; j += 64) j0 += (g + rel[j] < S) ? 1u : 0u;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) j0 += __shfl_xor(j0, d);
-      for (u32 j = j0 + lane; j < nk; j += 64) out[cnt + (j - j0)] = g + rel[j];
-      if (nk > j0) { S = g + rel[nk - 1] + 1; cnt += nk - j0; }
-      sync = false;
+      for (u32 j = from + lane; j < nk; j += 64) out[cnt + (j - from)] = g + rel[j];
+      if (nk > from) { S = g + rel[nk - 1] + 1; cnt += nk - from; }
       if (S >= fe) break;
-      if ((S - fs) % kSegBytes == 0) { sync = true; continue; }
-      rd_ready = false;
+      const SeamOut so = seam[sidx];
+      if (so.start == S) {                      // the seam continued exactly this chain
+        const u32* srel = seam_rel + sidx * (u64)spec_cap;
+        for (u32 j = lane; j < so.cnt; j += 64) out[cnt + j] = g + srel[j];
+        if (so.cnt) S = g + srel[so.cnt - 1] + 1;
+        cnt += so.cnt;
+        if (so.sync_seg != kNoSync) { k = so.sync_seg; from = so.sync_from; continue; }
+        // else: the seam ran through segment k+1 without meeting its speculation; go on exactly from S
+      }
+      synced = false;
+      rd.init(S);
     }
-    if (!rd_ready) { rd.init(S); rd_ready = true; }
+    // exact evaluation of one fragment, then look for the speculation again
+    if ((S - fs) % kSegBytes == 0) { synced = true; k = (u32)((S - fs) / kSegBytes); from = 0; continue; }
     const u64 E = eval_fragment(rd, lds[wave], S, fe, kNone, P);
     if (lane == 0) out[cnt] = E;
     ++cnt;
     S = E + 1;
     if (S >= fe) break;
-    if ((S - fs) % kSegBytes == 0) { sync = true; continue; }
-    // does E coincide with a speculative cut of its segment?
-    const u64 k2 = (E - fs) / kSegBytes;
-    const u64 sidx2 = seg_base[f] + k2;
+    if ((S - fs) % kSegBytes == 0) { synced = true; k = (u32)((S - fs) / kSegBytes); from = 0; continue; }
+    const u32 k2 = (u32)((E - fs) / kSegBytes);
+    const u64 sidx2 = sb + k2;
     const u32 n2 = spec_cnt[sidx2];
     const u32* rel2 = spec_rel + sidx2 * (u64)spec_cap;
-    const u32 want = (u32)(E - (fs + k2 * kSegBytes));
-    bool found = false;
-    for (u32 j = lane; j < n2; j += 64) found |= rel2[j] == want;
-    sync = __ballot(found) != 0ull;
+    const u32 want = (u32)(E - (fs + (u64)k2 * kSegBytes));
+    u32 hit = 0xffffffffu;
+    for (u32 j = lane; j < n2; j += 64) if (rel2[j] == want) hit = j;
+    const unsigned long long hm = __ballot(hit != 0xffffffffu);
+    if (hm) { synced = true; k = k2; from = (u32)__shfl((int)hit, __builtin_ctzll(hm)) + 1; }
   }
   if (lane == 0) cut_cnt[f] = cnt;
 }
@@ -289,9 +445,11 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   const size_t nf1 = nfiles + 1;
   size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 256;
   u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
-  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4);
+  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 8 + nseg * sizeof(SeamOut) + 256);
   u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
   if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
+  u32* d_seam_rel = d_spec_rel + nseg * (size_t)spec_cap;
+  SeamOut* d_seam = (SeamOut*)(d_seam_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
   u64* d_file_off = (u64*)meta;
   u64* d_seg_base = d_file_off + nf1;
   u64* d_cut_base = d_seg_base + nf1;
@@ -305,12 +463,15 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
 
-  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), d_base, readable,
-                     d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
+             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
-  ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base, readable,
-                     d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cut_base, d_cuts,
-                     d_cut_cnt);
+  ZPQ_LAUNCH(ctx, "fragment_seam_kernel", st, fragment_seam_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
+             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
+             readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel,
+             d_cut_base, d_cuts, d_cut_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
 
   // per-file counts -> exclusive prefix on the host (nfiles words; the data never leaves HBM)
