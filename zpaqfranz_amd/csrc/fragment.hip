@@ -126,12 +126,14 @@ __device__ u64 eval_fragment(ByteReader& rd, WaveLds& L, u64 S, u64 file_end, u6
 // ---- lane-serial evaluator ------------------------------------------------------------------------
 // o1[] of lane l lives at byte ((v>>2)*2 + (l>>5))*128 + (l&31)*4 + (v&3) of a 16 KiB per-wave block:
 // every lane of a 32-lane half hits its own bank whatever v is.
+typedef __attribute__((address_space(3))) volatile u8 lds_u8;     // keeps the accesses ds_* (not flat_*)
+typedef __attribute__((address_space(3))) volatile u32 lds_u32;
 struct LaneO1 {
-  volatile u8* t;
+  lds_u8* t;
   u32 lanebase;
   __device__ __forceinline__ u32 addr(u32 v) const { return lanebase + (((v << 6) & 0xFF00u) | (v & 3u)); }
   __device__ __forceinline__ void clear() {
-    volatile u32* w = (volatile u32*)(t + lanebase);
+    lds_u32* w = (lds_u32*)(t + lanebase);
 #pragma unroll
     for (int a = 0; a < 64; ++a) w[a * 64] = 0;
   }
@@ -143,32 +145,29 @@ __device__ __forceinline__ u32 byte_of(const u32x4& d, int j) {
   return (w >> (8 * (j & 3))) & 255u;
 }
 
-// Advances this lane's stream by one 16-byte group (or one byte near the end of [pos, lim)).
-// on_cut(E) is called for every cut; the lane is finished when pos >= lim.
+// One 16-byte group.  Returns true when a cut happened (pos then points behind the cut and the
+// state is reset); otherwise pos advances by 16.
 template <class OnCut>
-__device__ __forceinline__ void lane_step(const u8* __restrict__ data, u64& pos, const u64 lim, const u64 file_end,
-                                          const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
-  if (pos + 16 <= lim) {
-    const u32x4 d = *(const u32x4_u*)(data + pos);
-    u32 c[16], pr[16];
-    u32 prev = s.c1;
+__device__ __forceinline__ bool lane_group(const u32x4 d, u64& pos, const u64 file_end, const FragP& P, LaneO1& o,
+                                           LaneState& s, OnCut&& on_cut) {
+  u32 c[16], pr[16];
+  u32 prev = s.c1;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {          // 16 in-order LDS read/write pairs, nothing waits in between
-      c[j] = byte_of(d, j);
-      const u32 a = o.addr(prev);
-      pr[j] = o.t[a];
-      o.t[a] = (u8)c[j];
-      prev = c[j];
-    }
-    u32 h = s.h, hmin = 0xffffffffu;
+  for (int j = 0; j < 16; ++j) {          // 16 in-order LDS read/write pairs, nothing waits in between
+    c[j] = byte_of(d, j);
+    const u32 a = o.addr(prev);
+    pr[j] = o.t[a];
+    o.t[a] = (u8)c[j];
+    prev = c[j];
+  }
+  u32 h = s.h, hmin = 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      h = (h + c[j] + 1u) * (c[j] == pr[j] ? 314159265u : 271828182u);
-      hmin = hmin < h ? hmin : h;
-    }
-    const bool maybe = (hmin < P.thresh && s.sz + 16 >= P.minf) || s.sz + 16 >= P.maxf || pos + 16 == file_end;
-    if (!maybe) { s.h = h; s.c1 = prev; s.sz += 16; pos += 16; return; }
-    // rare: locate the first cut of this group exactly
+  for (int j = 0; j < 16; ++j) {
+    h = (h + c[j] + 1u) * (c[j] == pr[j] ? 314159265u : 271828182u);
+    hmin = hmin < h ? hmin : h;
+  }
+  const bool maybe = (hmin < P.thresh && s.sz + 16 >= P.minf) || s.sz + 16 >= P.maxf || pos + 16 == file_end;
+  if (maybe) {                            // rare: locate the first cut of this group exactly
     u32 hh = s.h, sz = s.sz; int cutj = -1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -176,12 +175,54 @@ __device__ __forceinline__ void lane_step(const u8* __restrict__ data, u64& pos,
       ++sz;
       if (cutj < 0 && (sz >= P.maxf || (hh < P.thresh && sz >= P.minf) || pos + j + 1 == file_end)) cutj = j;
     }
-    if (cutj < 0) { s.h = h; s.c1 = prev; s.sz += 16; pos += 16; return; }
-    const u64 E = pos + (u64)cutj;
-    on_cut(E);
-    o.clear();            // also wipes what the bytes after the cut wrote: they are re-walked from E+1
-    s.h = 0; s.c1 = 0; s.sz = 0;
-    pos = E + 1;
+    if (cutj >= 0) {
+      const u64 E = pos + (u64)cutj;
+      on_cut(E);
+      o.clear();          // also wipes what the bytes after the cut wrote: they are re-walked from E+1
+      s.h = 0; s.c1 = 0; s.sz = 0;
+      pos = E + 1;
+      return true;
+    }
+  }
+  s.h = h; s.c1 = prev; s.sz += 16; pos += 16;
+  return false;
+}
+
+// A lane's input stream: the 64 bytes being walked plus the next 128 already in flight (there are
+// only one or two waves per SIMD in these kernels, so HBM latency has to be hidden by hand).
+struct LaneStream {
+  u64 at;          // stream offset of a[0]; ~0 when nothing is loaded
+  u64 readable;    // bytes of the data buffer that may be read
+  u32x4 a[4], b[4], c[4];
+  __device__ __forceinline__ u32x4 ld(const u8* data, u64 off) const {
+    const u32x4 z = {0, 0, 0, 0};
+    return off + 16 <= readable ? *(const u32x4_u*)(data + off) : z;
+  }
+  __device__ __forceinline__ void prime(const u8* data, u64 pos) {
+    at = pos;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = ld(data, pos + 16 * i); b[i] = ld(data, pos + 64 + 16 * i); c[i] = ld(data, pos + 128 + 16 * i); }
+  }
+};
+
+// Advances this lane's stream by 64 bytes (16 or 1 near the end of [pos, lim)).
+// on_cut(E) is called for every cut; the lane is finished when pos >= lim.
+template <class OnCut>
+__device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStream& ls, u64& pos, const u64 lim,
+                                          const u64 file_end, const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
+  if (pos + 64 <= lim) {
+    if (ls.at != pos) ls.prime(data, pos);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (lane_group(ls.a[g], pos, file_end, P, o, s, on_cut)) { ls.at = ~0ull; return; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ls.a[i] = ls.b[i]; ls.b[i] = ls.c[i]; ls.c[i] = ls.ld(data, pos + 128 + 16 * i); }
+    ls.at = pos;
+    return;
+  }
+  ls.at = ~0ull;
+  if (pos + 16 <= lim) {
+    lane_group(*(const u32x4_u*)(data + pos), pos, file_end, P, o, s, on_cut);
     return;
   }
   if (pos < lim) {        // fewer than 16 bytes left: one byte per call
@@ -201,7 +242,7 @@ __device__ __forceinline__ void lane_step(const u8* __restrict__ data, u64& pos,
 }
 
 // ---- 1. speculative pass: one LANE per 1 MiB segment ----------------------------------------------
-__global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+__global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
                                                             const u32* __restrict__ seg_file,
                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
                                                             u32 spec_cap, u32* __restrict__ spec_rel,
@@ -209,7 +250,7 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
   __shared__ u8 tab[16384];
   const u32 lane = (u32)lane_id();
   const u64 s = (u64)blockIdx.x * 64 + lane;
-  LaneO1 o{tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
+  LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
   o.clear();
   bool active = s < nseg;
   u64 pos = 0, lim = 0, fe = 0, g = 0;
@@ -222,11 +263,12 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
     pos = g;
   }
   LaneState st{0, 0, 0};
+  LaneStream ls; ls.at = ~0ull; ls.readable = readable;
   u32 cnt = 0;
   u32* out = spec_rel + s * (u64)spec_cap;
   while (__any(active)) {
     if (active) {
-      lane_step(data, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
+      lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
       active = pos < lim;
     }
   }
@@ -239,7 +281,7 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
 struct SeamOut { u64 start; u64 cont; u32 cnt; u32 sync_seg; u32 sync_from; u32 pad; };
 constexpr u32 kNoSync = 0xffffffffu;
 
-__global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+__global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
                                                             const u32* __restrict__ seg_file,
                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
                                                             u32 spec_cap, const u32* __restrict__ spec_rel,
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict_
   __shared__ u8 tab[16384];
   const u32 lane = (u32)lane_id();
   const u64 s = (u64)blockIdx.x * 64 + lane;      // seam after segment s (within the same file)
-  LaneO1 o{tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
+  LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
   o.clear();
   bool active = false;
   u64 pos = 0, lim = 0, fe = 0, fs = 0, g = 0, sb = 0;
@@ -270,11 +312,12 @@ __global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict_
     }
   }
   LaneState st{0, 0, 0};
+  LaneStream ls; ls.at = ~0ull; ls.readable = readable;
   u32* out = seam_rel + s * (u64)spec_cap;
   while (__any(active)) {
     if (active) {
       bool synced = false;
-      lane_step(data, pos, lim, fe, P, o, st, [&](u64 E) {
+      lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) {
         if (so.cnt < spec_cap) out[so.cnt] = (u32)(E - g);
         ++so.cnt;
         if (E + 1 >= fe) { so.sync_seg = nsegf; so.sync_from = 0; synced = true; return; }   // reached EOF
@@ -464,10 +507,10 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
 
   ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
-             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
+             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_LAUNCH(ctx, "fragment_seam_kernel", st, fragment_seam_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
-             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel);
+             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
              readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel,
