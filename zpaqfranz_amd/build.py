@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-               "-c", os.path.join(CSRC, s), "-o", o]
+               "-c", os.path.join(CSRC, s), "-o", o] + os.environ.get("ZPQ_EXTRA_FLAGS", "").split()
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

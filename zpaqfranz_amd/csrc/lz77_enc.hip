@@ -99,10 +99,18 @@ __device__ __forceinline__ u32 mismatch16(u32x4 a, u32x4 b) {
   return 16u;
 }
 
+// byte idx (0..31) of the 32 bytes held in two 16-byte vectors
+__device__ __forceinline__ u32 byte32(const u32x4& lo, const u32x4& hi, u32 idx) {
+  const u32 w = idx >> 2;
+  const u32 a = w & 1 ? (w & 2 ? lo.w : lo.y) : (w & 2 ? lo.z : lo.x);
+  const u32 b = w & 1 ? (w & 2 ? hi.w : hi.y) : (w & 2 ? hi.z : hi.x);
+  return ((w & 4 ? b : a) >> ((idx & 3) * 8)) & 255u;
+}
+
 // Whole-wave compare for long matches: 512 bytes per step.  All arguments wave-uniform.
-__device__ __forceinline__ u32 coop_match_len(const u8* in, u32 p, u32 q, u32 limit) {
+__device__ __forceinline__ u32 coop_match_len(const u8* in, u32 p, u32 q, u32 limit, u32 from = 0) {
   const u32 lane = (u32)lane_id();
-  u32 base = 0;
+  u32 base = from;
   while (base < limit) {
     u32 o = base + lane * 8;
     u64 x = o < limit ? (load8(in + p + o) ^ load8(in + q + o)) : 1ull;
@@ -131,6 +139,13 @@ template <> struct GroupLoad<8> { static __device__ __forceinline__ void ld(cons
 
 struct TokSink { u32* pos; u32* len; u32* off; u32 cap; u32 n; };
 
+#ifdef ZPQ_LZ_PROFILE
+__device__ unsigned long long g_lzprof[8];
+#define LZ_T(i) do { const u64 t_ = __builtin_readcyclecounter(); prof[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define LZ_T(i) do {} while (0)
+#endif
+
 // Speculative tokens of one segment, consulted by the stitcher after each of its own tokens.
 struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 
@@ -149,6 +164,9 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
   volatile unsigned long long* Tv = T;
   const bool fast_hash = mm <= 8;
   const u32 hfrozen = hash_at(C, C.upd_limit);   // h1 once updates have stopped (q > upd_limit)
+#ifdef ZPQ_LZ_PROFILE
+  u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 tlast = __builtin_readcyclecounter();
+#endif
 
   for (u32 base = wbase; base < x1 && base < n; base += 64) {
     const u32 q = base + lane;
@@ -169,6 +187,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
     const u32 grp = h & ~C.bucket;
     const bool look = inb && cur < wend;   // windows swallowed by a match only insert
 
+    LZ_T(0);
     u32 ent[NB];
     if (look) GroupLoad<NB>::ld(ht + grp, ent);   // bypasses L1: the table is rewritten by this wave
     else {
@@ -200,6 +219,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
       __builtin_amdgcn_wave_barrier();
       if (inb) Tv[tk] = 0ull;
     }
+    LZ_T(1);
     // ---- reorder the group into probe order ht[h1^k], k = 0..bucket (:6397) ---------------------
     {
       const u32 hb = h & C.bucket;
@@ -221,7 +241,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
     bool slow = false;
     const u32 limit = inb ? (n - q < kMaxMatch ? n - q : kMaxMatch) : 0u;
     const bool evalp = look && q >= cur;
-    u32x4 ca[NB];
+    u32x4 ca[NB], cb[NB];
     const u32x4 qa = load16(in + (q < n ? q : 0)), qc = load16(in + (q < n ? q : 0) + 16);
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -231,26 +251,21 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
         const u32 p = e >> C.checkbits;
         if (p < q) cp[k] = p;
       }
-      ca[k] = load16(in + (cp[k] != kNoCand ? cp[k] : 0u));
-    }
-    u32x4 cb[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      u32 l = 0;
-      if (cp[k] != kNoCand) l = mismatch16(ca[k], qa);
-      cl[k] = l;
-      cb[k] = load16(in + ((cp[k] != kNoCand && l == 16) ? cp[k] + 16u : 0u));
+      const u8* src = in + (cp[k] != kNoCand ? cp[k] : 0u);
+      ca[k] = load16(src); cb[k] = load16(src + 16);
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       if (cp[k] != kNoCand) {
-        u32 l = cl[k];
+        u32 l = mismatch16(ca[k], qa);
         if (l == 16) l = 16 + mismatch16(cb[k], qc);
         if (l >= limit) l = limit;                       // never beyond the input / maxMatch
         else if (l == kCap) slow = true;                 // may extend further: resolve exactly when reached
         cl[k] = l;
       }
     }
+    if (__ballot(cl[0] == 12345u)) LZ_T(7);   // forces the candidate results before the timestamp
+    LZ_T(2);
     // ---- the reference's decision for both values of (lit>0) (:6396-6421) -----------------------
     u32 rlen[2] = {0, 0}, roff[2] = {0, 0};
     if (evalp && !slow) {
@@ -266,7 +281,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
               const u32 idx = blen - 1;
               if (idx < l) ok = true;
               else if (idx == l) ok = false;  // first mismatch (l < limit here because q+blen<=n)
-              else ok = in[p + idx] == in[q + idx];
+              else ok = byte32(ca[k], cb[k], idx) == byte32(qa, qc, idx);   // idx < 32 here (no capped candidate)
             }
             if (ok) {
               const int score = (int)(l * 8) - lg32(q - p) - 2 * f - 11;
@@ -280,6 +295,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
     }
     // ---- serial greedy chain over this window (wave-uniform) -----------------------------------
     const unsigned long long slowmask = __ballot(slow);
+    LZ_T(3);
     const unsigned long long stop1 = __ballot(rlen[1] != 0) | slowmask;  // where a lit>0 run must stop
     while (cur < wend) {
       const u32 j = cur - base;
@@ -297,18 +313,57 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
       const u32 f = lit > 0 ? 1u : 0u;
       u32 tlen, toff;
       if ((slowmask >> j) & 1ull) {
-        // exact re-evaluation of position cur, replicating :6396-6408 with whole-wave compares
+        // exact re-evaluation of position cur (:6396-6408).  Lane j already holds every candidate's
+        // position and its length up to the 32-byte cap; capped candidates are extended for ALL
+        // candidates at once (64/NB lanes each, 8 bytes per lane and step), anything still
+        // unresolved after 4 steps by whole-wave compares.
         const u32 i = cur;
         const u32 lim_i = n - i < kMaxMatch ? n - i : kMaxMatch;
-        const u32 bi3 = in[i + 3];
+        u32 xp[NB], xl[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { xp[k] = __builtin_amdgcn_readlane(cp[k], j); xl[k] = __builtin_amdgcn_readlane(cl[k], j); }
+        {
+          constexpr u32 W = 64 / NB;                 // lanes per candidate
+          const u32 g = lane / W, sub = lane % W;
+          u32 myp = kNoCand; bool open = false;
+#pragma unroll
+          for (int k = 0; k < NB; ++k) if (g == (u32)k) { myp = xp[k]; open = xp[k] != kNoCand && xl[k] == kCap && kCap < lim_i; }
+          u32 found = 0xffffffffu;                   // exact length once known (per candidate group)
+          for (u32 step = 0; step < 4 && __ballot(open); ++step) {
+            const u32 o = kCap + step * 8 * W + 8 * sub;
+            u32 mine = 0xffffffffu;
+            if (open) {
+              if (o >= lim_i) mine = lim_i;
+              else {
+                const u64 x = load8(in + myp + o) ^ load8(in + i + o);
+                if (x) { const u32 l = o + (u32)(__builtin_ctzll(x) >> 3); mine = l < lim_i ? l : lim_i; }
+              }
+            }
+#pragma unroll
+            for (u32 d = 1; d < W; d <<= 1) { const u32 y = __shfl_xor(mine, (int)d); mine = mine < y ? mine : y; }
+            if (open && mine != 0xffffffffu) { found = mine; open = false; }
+          }
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const u32 fk = __builtin_amdgcn_readlane(found, k * W);
+            const bool still = __builtin_amdgcn_readlane((u32)open, k * W) != 0;
+            if (fk != 0xffffffffu) xl[k] = fk;
+            else if (still) xl[k] = coop_match_len(in, xp[k], i, lim_i, kCap + 4 * 8 * W);
+          }
+        }
         u32 blen = mm - 1, bp = 0; int bscore = 0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          const u32 e = __builtin_amdgcn_readlane(ent[k], j);
-          if (blen < 128 && e && i + 3 < n && (e & mask) == (bi3 & mask)) {
-            const u32 p = e >> C.checkbits;
-            if (p < i && i + blen <= n && in[p + blen - 1] == in[i + blen - 1]) {
-              const u32 l = coop_match_len(in, p, i, lim_i);
+          if (blen < 128 && xp[k] != kNoCand) {
+            const u32 p = xp[k], l = xl[k];
+            bool ok = false;
+            if (i + blen <= n) {
+              const u32 idx = blen - 1;
+              if (idx < l) ok = true;
+              else if (idx == l) ok = false;
+              else ok = in[p + idx] == in[i + idx];
+            }
+            if (ok) {
               const int score = (int)(l * 8) - lg32(i - p) - 2 * (int)f - 11;
               if (score > bscore) { blen = l; bp = p; bscore = score; }
             }
@@ -350,10 +405,15 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
         if (lit >= kMaxLiteral) lit = 0;  // forced literal flush (:6450-6451); runs are positional
       }
     }
+    LZ_T(4);
     // ---- insert this window's positions (latest writer of a slot wins) --------------------------
     if (ins && !superseded) ht[slot] = val;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LZ_T(5);
   }
+#ifdef ZPQ_LZ_PROFILE
+  if (lane == 0 && !spec) { for (int i = 0; i < 8; ++i) atomicAdd(&g_lzprof[i], (unsigned long long)prof[i]); }
+#endif
   return -1;
 }
 
@@ -572,6 +632,14 @@ __global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev*
 
 // ---- host side ---------------------------------------------------------------------------------------
 extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 512 + 64; }
+
+#ifdef ZPQ_LZ_PROFILE
+extern "C" int zpq_debug_lzprof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzprof), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzprof), z, 64); }
+  return 0;
+}
+#endif
 
 static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
   if ((a[1] & 3) != 1 || a[1] > 5) return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 level %d not implemented", a[1]);
