@@ -30,25 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BLOCK_LIMIT = (1 << 24) - 4096   # zpaqfranz -m1: method "14" -> 2^24 - 4096 byte blocks
+from zpaqfranz_amd.sharding import BLOCK_LIMIT, plan as shard_plan
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-
-
-def pack_blocks(uniq_len):
-    """Deterministic block packer over the unique-fragment sequence (host logic, as in the reference's
-    Jidac::add): a block takes fragments while bytes + 4*(count+1) + 8 <= BLOCK_LIMIT.  Returns the
-    block id of every unique fragment.  (The exact cut rule lives in the missing zpaqfranz.cpp:
-    parity unpinned, see DESIGN.md.)"""
-    n = len(uniq_len)
-    blk = np.empty(n, dtype=np.int64)
-    cs = np.concatenate(([0], np.cumsum(uniq_len.astype(np.int64) + 4)))
-    i, b = 0, 0
-    while i < n:
-        j = int(np.searchsorted(cs, cs[i] + BLOCK_LIMIT - 8, side="right")) - 1
-        j = max(j, i + 1)
-        blk[i:j] = b
-        i, b = j, b + 1
-    return blk, b
 
 
 class Pipeline:
@@ -115,26 +98,18 @@ class Pipeline:
         eng.sync()
         first = self.first[:ntot].cpu().numpy()
         lens = flen.cpu().numpy().astype(np.int64)
-        is_new = first == np.arange(ntot, dtype=first.dtype)
-        uniq_idx = np.nonzero(is_new)[0]
-        # 4. pack (host: which unique fragment goes to which block)
-        blk, nblk = pack_blocks(lens[uniq_idx])
-        owner_of_frag = np.searchsorted(np.cumsum(cnts), uniq_idx, side="right")
-        first_in_blk = np.concatenate(([0], np.nonzero(np.diff(blk))[0] + 1))
-        blk_owner = owner_of_frag[first_in_blk]
-        mine = np.nonzero(blk_owner == self.rank)[0]
+        # 4. pack (host: which unique fragment goes to which block, who owns it) -- zpaqfranz_amd/sharding.py
+        P = shard_plan(first, lens, cnts, self.rank)
+        uniq_idx, mine, starts, nblk = P["uniq_idx"], P["mine"], P["starts"], P["nblocks"]
         # block buffers of the blocks this rank owns: fragments + size table + 0 + count
-        starts = np.concatenate((first_in_blk, [len(uniq_idx)]))
-        blk_n, src_off, src_len, dst_off, trailers, foreign = [], [], [], [], [], []
+        blk_n, src_off, src_len, dst_off, trailers, layout = [], [], [], [], [], {}
         pos = 0
         for b in mine:
-            u = uniq_idx[starts[b]:starts[b + 1]]
-            l = lens[u]
+            u, l, own_rank = P["blocks"][int(b)]
             o = pos + np.concatenate(([0], np.cumsum(l)[:-1]))
-            own = owner_of_frag[starts[b]:starts[b + 1]] == self.rank
+            own = own_rank == self.rank
             src_off.append(u[own] - my_lo); src_len.append(l[own]); dst_off.append(o[own])
-            if not own.all():
-                foreign.append((b, u[~own], l[~own], o[~own]))
+            layout.update({int(g): int(d) for g, d in zip(u[~own].tolist(), o[~own].tolist())})
             size = int(l.sum())
             tr = np.concatenate((l.astype("<u4"), np.array([0, len(l)], dtype="<u4"))).tobytes()
             trailers.append((pos + size, tr))
@@ -149,10 +124,10 @@ class Pipeline:
             torch.cuda.synchronize()
             eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
                            blocks_buf.data_ptr())
-            for p, tr in trailers:
-                blocks_buf[p:p + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
+            for p_, tr in trailers:
+                blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
         if self.world > 1:
-            self._exchange_seams(uniq_idx, lens, blk, owner_of_frag, blk_owner, starts, cnts, nf, foreign, blocks_buf)
+            self._exchange_seams(P, lens, my_lo, nf, layout, blocks_buf)
         eng.sync(); torch.cuda.synchronize()
         # 5. compressBlock on every owned block ("14": LZ77 x4,1,5,0,3,24 + framing + SHA-1)
         nb = len(mine)
@@ -204,63 +179,66 @@ class Pipeline:
                           unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
         return out_bytes
 
-    def _exchange_seams(self, uniq_idx, lens, blk, owner_of_frag, blk_owner, starts, cnts, nf, foreign, blocks_buf):
-        """Fragments of a block that live on another rank (only at rank seams) travel peer to peer."""
+    def _exchange_seams(self, P, lens, my_lo, nf, layout, blocks_buf):
+        """Fragments of a block that live on another rank (only at rank seams) travel peer to peer:
+        both sides derive the same ordered lists from the plan, so one send/recv per rank pair suffices."""
         dev = self.dev
-        lo = np.concatenate(([0], np.cumsum(cnts)))
-        sends, recvs = [], []
-        # what I must send: my fragments inside blocks owned by someone else
-        theirs = np.nonzero((owner_of_frag == self.rank) & (blk_owner[blk] != self.rank))[0]
-        for dstrank in np.unique(blk_owner[blk[theirs]]):
-            sel = theirs[blk_owner[blk[theirs]] == dstrank]
-            idx = torch.from_numpy((uniq_idx[sel] - lo[self.rank]).astype(np.int64)).to(dev)
-            parts = [self.data[int(o):int(o) + int(l)] for o, l in zip(self.frag_off[:nf][idx].tolist(), lens[uniq_idx[sel]].tolist())]
-            payload = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
-            sends.append(dist.isend(payload, int(dstrank)))
-        for b, u, l, o in foreign:
-            for srcrank in np.unique(np.searchsorted(lo[1:], u, side="right")):
-                m = np.searchsorted(lo[1:], u, side="right") == srcrank
-                buf = torch.empty(int(l[m].sum()), dtype=torch.uint8, device=dev)
-                recvs.append((dist.irecv(buf, int(srcrank)), buf, o[m], l[m]))
-        for r, buf, o, l in recvs:
+        ops, recvs = [], []
+        for dst, idx in sorted(P["send"].items()):
+            loc = torch.from_numpy((idx - my_lo).astype(np.int64)).to(dev)
+            offs = self.frag_off[:nf][loc].tolist()
+            parts = [self.data[o:o + int(l)] for o, l in zip(offs, lens[idx].tolist())]
+            ops.append(dist.isend(torch.cat(parts), int(dst)))
+        for src, idx in sorted(P["recv"].items()):
+            buf = torch.empty(int(lens[idx].sum()), dtype=torch.uint8, device=dev)
+            recvs.append((dist.irecv(buf, int(src)), buf, idx))
+        for r, buf, idx in recvs:
             r.wait()
             q = 0
-            for oo, ll in zip(o.tolist(), l.tolist()):
-                blocks_buf[oo:oo + ll] = buf[q:q + ll]; q += ll
-        for s in sends:
-            s.wait()
+            for g, ll in zip(idx.tolist(), lens[idx].tolist()):
+                d = layout[int(g)]
+                blocks_buf[d:d + ll] = buf[q:q + ll]; q += ll
+        for o in ops:
+            o.wait()
 
 
 def cpu_baseline(corpus, copies):
-    """The CPU oracle (a port of the reference's path) on this host's cores, single thread, on a bounded
-    sample: fragment+SHA-1 of one Silesia-sized copy, compressBlock of its first two 16 MiB blocks;
-    extrapolated to the x256 job (256 x fragment/hash + 1 x compress of the unique copy)."""
+    """The CPU oracle (a port of the reference's path, oracle/liboracle.so) on this host's cores -- one
+    worker thread per core, as `zpaqfranz -tN` would use them (ctypes releases the GIL) -- on a bounded
+    sample: fragment + SHA-1 of one Silesia-sized copy, compressBlock("14") of its first blocks; the
+    x256 job is extrapolated as 256 x fragment/hash + 1 x compress of the unique copy."""
     import orc
-    t0 = time.time()
-    nbytes = 0
-    budget = 12.0
-    for _, b in corpus:
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 1
+
+    def frag_hash(b):
         off = 0
         for ln in orc.chunk(b):
             orc.sha1(b[off:off + ln]); off += ln
-        nbytes += len(b)
-        if time.time() - t0 > budget:
-            break
-    t_fh = (time.time() - t0) / max(1, nbytes)          # s per input byte, fragment + SHA-1
-    blob = b"".join(b for _, b in corpus)[: 2 * BLOCK_LIMIT]
-    t1 = time.time(); cin = cout = 0
-    for i in range(0, len(blob), BLOCK_LIMIT):
-        blk = blob[i:i + BLOCK_LIMIT]
-        out, _ = orc.compress_block(blk, "14", "jDC20240101000000d0000000001", "jDC\x01", True)
-        cin += len(blk); cout += len(out)
+        return len(b)
+
+    # split members into ~8 MiB pieces so that every core has work (files are independent anyway)
+    pieces = [b[i:i + (8 << 20)] for _, b in corpus for i in range(0, len(b), 8 << 20)]
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        nbytes = sum(ex.map(frag_hash, pieces))
+    t_fh = (time.time() - t0) / max(1, nbytes)          # s per input byte, fragment + SHA-1, all cores
+    blob = b"".join(b for _, b in corpus)
+    nblk = min(max(2, cores), (len(blob) + BLOCK_LIMIT - 1) // BLOCK_LIMIT)
+    blks = [blob[i * BLOCK_LIMIT:(i + 1) * BLOCK_LIMIT] for i in range(nblk)]
+    t1 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        outs = list(ex.map(lambda x: len(orc.compress_block(x, "14", "jDC20240101000000d0000000001", "jDC\x01", True)[0]), blks))
+    cin, cout = sum(len(x) for x in blks), sum(outs)
     t_c = (time.time() - t1) / max(1, cin)
     unit = sum(len(b) for _, b in corpus)
     est_time = t_fh * unit * copies + t_c * unit
     est_out = unit * (cout / max(1, cin))
-    return {"value": round(est_out / 1e6 / est_time, 3), "unit": "MB/s compressed output", "cores": 1, "kind": "port",
+    return {"value": round(est_out / 1e6 / est_time, 3), "unit": "MB/s compressed output", "cores": cores, "kind": "port",
             "input_GBps": round(unit * copies / 1e9 / est_time, 4),
-            "sample": "oracle/liboracle.so, 1 thread: fragment+SHA-1 of %d MB and compressBlock('14') of %d MB "
-                      "(ratio %.3f), extrapolated to 256 x fragment/hash + 1 x compress" % (nbytes >> 20, cin >> 20, cout / max(1, cin))}
+            "sample": "oracle/liboracle.so on %d threads: fragment+SHA-1 of %d MB (%.1f s) and compressBlock('14') of %d MB "
+                      "(%.1f s, ratio %.3f); extrapolated to 256 x fragment/hash + 1 x compress"
+                      % (cores, nbytes >> 20, t_fh * nbytes, cin >> 20, t_c * cin, cout / max(1, cin))}
 
 
 def main():
@@ -311,19 +289,29 @@ def main():
     if rank == 0:
         sec = dt / a.steps
         in_bytes = pipe.total * world
-        # algorithmic bytes per launch of each input-scanning kernel: every input byte read once
-        alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total + pipe.stats["unique_bytes"]}
-        dom = max(kern, key=lambda k: kern[k][1]) if kern else None
-        roof = None
-        if dom:
-            cnt, ms = kern[dom]
+        # algorithmic bytes per launch: fragment/hash kernels read every input byte once;
+        # the LZ77 and checksum kernels read every unique byte once (+ r bytes written)
+        ub = pipe.stats["unique_bytes"]
+        alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub + out_bytes,
+               "sha1_chain_kernel": ub, "fragment_seam_kernel": None, "lz77_stitch_kernel": None}
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")     # PMC bytes per launch from the last rocprofv3 --pmc run
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("bytes_per_launch", {})
+
+        def roof(k):
+            cnt, ms = kern[k]
             per = ms / cnt
-            launches_per_step = cnt / a.steps
-            ab = alg.get(dom, pipe.stats["unique_bytes"]) / max(1.0, launches_per_step if dom in alg else 1.0)
+            ab = alg.get(k)
+            if not ab:
+                return None
             ach = ab / 1e9 / (per / 1e3)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(per, 4),
+            return {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(k), "avg_launch_ms": round(per, 4),
                     "algorithmic_bytes_per_launch": int(ab)}
+        dom = max((k for k in kern if alg.get(k)), key=lambda k: kern[k][1], default=None)
+        roof_dom = roof(dom) if dom else None
+        roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r]
         res = {"metric": "MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x256", "value": round(out_bytes / 1e6 / sec, 3),
                "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -331,7 +319,7 @@ def main():
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **pipe.stats},
                "input_GBps": round(in_bytes / 1e9 / sec, 3),
                "kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof}
+               "roofline": roof_dom, "roofline_all": roof_all}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(corpus, a.copies)
         if not a.no_verify and getattr(pipe, "verify_sample", None) is not None:

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 (rocpd sqlite) outputs of one bench.py run into the text summaries kept under
+profiles/.  Usage: python profiles/summarize.py gpurun_out rNN
+
+  gpurun_out/prof_stats/*_results.db   rocprofv3 --kernel-trace --stats -- python bench.py ...
+  gpurun_out/prof_fetch/*_results.db   rocprofv3 --pmc FETCH_SIZE     -- python bench.py --steps 1 --warmup 0 ...
+  gpurun_out/prof_write/*_results.db   rocprofv3 --pmc WRITE_SIZE     -- ...
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide coalesced read; the run itself carries a calibration point (the
+rocclr copyBuffer dispatches that replicate the 211 938 580-byte corpus: FETCH_SIZE = 103 498 KiB =
+0.50 x bytes copied), so read bytes below are reported raw and x2."""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def q(dbdir):
+    f = glob.glob(os.path.join(dbdir, "*_results.db"))
+    return sqlite3.connect(f[0]).cursor() if f else None
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+def main(root, tag):
+    out = []
+    cur = q(os.path.join(root, "prof_stats"))
+    if cur:
+        out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1   (%s)\n" % tag)
+        out.append("%-34s %6s %14s %14s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+        for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+            out.append("%-34s %6d %14.1f %14.1f %7.2f" % (short(name)[:34], calls, total / 1e3, avg / 1e3, pct))
+        out.append("")
+    for sub, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
+        cur = q(os.path.join(root, sub))
+        if not cur:
+            continue
+        out.append("# rocprofv3 --pmc %s -- python bench.py --steps 1 --warmup 0   (KiB per dispatch, summed per kernel)" % ctr)
+        out.append("%-34s %6s %16s %16s" % ("kernel", "calls", "sum_KiB", "avg_KiB"))
+        rows = cur.execute("select kernel_name, count(*), sum(value), avg(value) from counters_collection where counter_name=? group by kernel_name order by sum(value) desc", (ctr,))
+        for name, calls, sm, av in rows:
+            out.append("%-34s %6d %16.1f %16.1f" % (short(name)[:34], calls, sm, av))
+        out.append("")
+    txt = "\n".join(out)
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_rocprof_summary.txt" % tag), "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -67,3 +67,16 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"liboracle|libzpaqref|oracle/|import orc|from orc", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_libzpaq_shim_builds_and_links(tmp_path, lib):
+    """The C++ host layer (same names as ZSFX/libzpaq.h) and a Jidac-style caller compile and link."""
+    from zpaqfranz_amd import build
+    so = build.build_shim()
+    assert os.path.exists(so)
+    drv = build.build_shim_driver(str(tmp_path / "shim_driver"))
+    assert os.path.exists(drv)
+    import subprocess
+    syms = subprocess.run(["nm", "-DC", so], capture_output=True, text=True).stdout
+    for name in ("libzpaq::compressBlock", "libzpaq::compress(", "libzpaq::decompress", "libzpaq::SHA1::result", "libzpaq::SHA256::result"):
+        assert name in syms, name

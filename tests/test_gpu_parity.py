@@ -250,3 +250,31 @@ def test_corrupt_block_is_detected(eng):
     bad = bytearray(out); bad[len(bad) // 2] ^= 0x55
     r, = eng.decompress_blocks([bytes(bad)], [len(b) + 64])
     assert r["status"] != 0 or r["data"] != b
+
+
+# ---------------------------------------------------------------------------------------------------
+# the libzpaq-shaped C++ shim, driven like Jidac's worker threads drive libzpaq
+# ---------------------------------------------------------------------------------------------------
+def test_libzpaq_shim_multithreaded_cpp_caller(tmp_path):
+    import subprocess
+    from zpaqfranz_amd import build
+    build.build(verbose=False)
+    drv = build.build_shim_driver(str(tmp_path / "shim_driver"))
+    data = datagen.mixed(5 * (1 << 20) + 12345, 31)
+    (tmp_path / "in.bin").write_bytes(data)
+    block = 1 << 20
+    r = subprocess.run([drv, str(tmp_path / "in.bin"), "14,128,0", "4", str(block), str(tmp_path / "out")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    s1, s256 = lines[0].split()
+    assert s1 == orc.sha1(data).hex() and s256 == orc.sha256(data).hex()
+    assert lines[1].startswith("unsupported: refused")
+    want = b""
+    for i in range(0, len(data), block):
+        blk, _ = orc.compress_block(data[i:i + block], "14,128,0", "jDC20240101000000d%010d" % (i // block + 1), "jDC\x01", True)
+        want += blk
+    assert (tmp_path / "out.zpaq").read_bytes() == want
+    assert (tmp_path / "out.back").read_bytes() == data
+    if orc.have_ref():     # and the REAL reference decoder accepts the archive the shim wrote
+        assert orc.ref_decompress(want, len(data) + 64) == data

@@ -1,0 +1,86 @@
+"""world_size-2 gloo test of the multi-GPU plan: both ranks all-gather their fragment
+tables, resolve the global first-occurrence dedup identically, and derive matching ownership and
+peer-to-peer lists.  Pure CPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zpaqfranz_amd import sharding
+
+
+def _tables(rank):
+    """Fragment table of one rank: 2500 fragments, ~60 % of the digests shared between ranks."""
+    rng = np.random.default_rng(100 + rank)
+    shared = np.random.default_rng(7).integers(0, 256, size=(1500, 20), dtype=np.uint8)
+    own = rng.integers(0, 256, size=(1000, 20), dtype=np.uint8)
+    pick = rng.integers(0, 2500, size=2500)
+    dig = np.where((pick < 1500)[:, None], shared[np.minimum(pick, 1499)], own[np.minimum(np.maximum(pick - 1500, 0), 999)])
+    lens = (np.frombuffer(dig.tobytes(), dtype=np.uint8).reshape(-1, 20)[:, 0].astype(np.int64) * 2000 + 4096)
+    return dig, lens
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dig, lens = _tables(rank)
+    td, tl = torch.from_numpy(dig.copy()), torch.from_numpy(lens.copy())
+    gd = [torch.empty_like(td) for _ in range(world)]
+    gl = [torch.empty_like(tl) for _ in range(world)]
+    dist.all_gather(gd, td)
+    dist.all_gather(gl, tl)
+    all_d = torch.cat(gd).numpy()
+    all_l = torch.cat(gl).numpy()
+    first = sharding.first_occurrence(all_d)
+    p = sharding.plan(first, all_l, [len(dig)] * world, rank, block_limit=4 << 20)
+    summary = dict(rank=rank, nblocks=p["nblocks"], mine=p["mine"].tolist(),
+                   send={k: v.tolist() for k, v in p["send"].items()}, recv={k: v.tolist() for k, v in p["recv"].items()},
+                   uniq=int(len(p["uniq_idx"])), blk_sig=int(p["blk"].sum()) if len(p["blk"]) else 0)
+    out = [None] * world
+    dist.all_gather_object(out, summary)
+    if rank == 0:
+        q.put(out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_plan_is_consistent():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a["nblocks"] == b["nblocks"] and a["uniq"] == b["uniq"] and a["blk_sig"] == b["blk_sig"]
+    assert sorted(a["mine"] + b["mine"]) == list(range(a["nblocks"]))          # every block has exactly one owner
+    assert a["send"].get(1, []) == b["recv"].get(0, [])                       # what 0 sends is what 1 expects
+    assert b["send"].get(0, []) == a["recv"].get(1, [])
+    # and the plan equals the single-process plan over the concatenated tables
+    d0, l0 = _tables(0); d1, l1 = _tables(1)
+    first = sharding.first_occurrence(np.concatenate((d0, d1)))
+    solo = sharding.plan(first, np.concatenate((l0, l1)), [len(d0) + len(d1)], 0, block_limit=4 << 20)
+    assert solo["nblocks"] == a["nblocks"] and len(solo["uniq_idx"]) == a["uniq"]
+
+
+def test_pack_blocks_respects_limit():
+    rng = np.random.default_rng(1)
+    lens = rng.integers(4096, 520193, size=5000)
+    blk, nb = sharding.pack_blocks(lens)
+    assert nb == blk.max() + 1 and (np.diff(blk) >= 0).all()
+    for b in range(nb):
+        m = blk == b
+        assert lens[m].sum() + 4 * m.sum() + 8 <= sharding.BLOCK_LIMIT
+    # greedy: adding the next fragment to any block but the last would overflow
+    for b in range(nb - 1):
+        m = blk == b
+        nxt = lens[np.nonzero(blk == b + 1)[0][0]]
+        assert lens[m].sum() + 4 * m.sum() + 8 + nxt + 4 > sharding.BLOCK_LIMIT

@@ -17,7 +17,8 @@ def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(ROOT, "include", "zpaqhip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(ROOT, "include", "zpaqhip.h"),
+            os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -40,9 +41,30 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     subprocess.check_call(cmd)
+    build_shim()
     if verbose:
         print("built", SO)
     return SO
+
+
+SHIM_SO = os.path.join(HERE, "libzpaq_gpu.so")
+
+
+def build_shim():
+    """The libzpaq-shaped C++ host layer (zpaqfranz_amd/shim), linked against libzpaqhip.so."""
+    src = os.path.join(HERE, "shim", "libzpaq_gpu.cpp")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(HERE, "shim"), src, "-L" + HERE, "-lzpaqhip", "-Wl,-rpath,$ORIGIN", "-o", SHIM_SO]
+    subprocess.check_call(cmd)
+    return SHIM_SO
+
+
+def build_shim_driver(out):
+    """tests/cpp/shim_driver.cpp: a Jidac-style multi-threaded caller of the shim."""
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(HERE, "shim"), os.path.join(ROOT, "tests", "cpp", "shim_driver.cpp"),
+           "-L" + HERE, "-lzpaq_gpu", "-lzpaqhip", "-Wl,-rpath," + HERE, "-o", out]
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

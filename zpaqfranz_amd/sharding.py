@@ -1,0 +1,72 @@
+"""Host-side planning of the multi-GPU add path: pure numpy, no device code, so that
+it can be exercised with world_size-2 gloo tests on CPU.
+
+Inputs are the all-gathered fragment tables (rank-major, order preserving): `first[i]` = index of the
+first fragment with the same SHA-1 (from zpq_dedup_dev, or any exact first-occurrence dedup), `lens[i]`,
+and `counts[r]` = number of fragments rank r contributed.  Every rank runs the same deterministic plan."""
+import numpy as np
+
+BLOCK_LIMIT = (1 << 24) - 4096   # zpaqfranz -m1: method "14" -> 2^24 - 4096 byte blocks
+
+
+def pack_blocks(uniq_len, block_limit=BLOCK_LIMIT):
+    """Deterministic block packer over the unique-fragment sequence (host logic, as in the reference's
+    Jidac::add): a block takes fragments while bytes + 4*count + 8 <= block_limit (the d block carries a
+    4-byte size per fragment plus 8 trailer bytes, ZSFX/zsfx.cpp:1468-1500 reads them back).  Returns
+    (block id of every unique fragment, number of blocks).  The exact cut rule lives in the missing
+    zpaqfranz.cpp: parity unpinned."""
+    n = len(uniq_len)
+    blk = np.empty(n, dtype=np.int64)
+    cs = np.concatenate(([0], np.cumsum(np.asarray(uniq_len, dtype=np.int64) + 4)))
+    i, b = 0, 0
+    while i < n:
+        j = int(np.searchsorted(cs, cs[i] + block_limit - 8, side="right")) - 1
+        j = max(j, i + 1)
+        blk[i:j] = b
+        i, b = j, b + 1
+    return blk, b
+
+
+def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT):
+    """Returns a dict describing what `rank` has to do:
+      uniq_idx     global indices of new fragments (ascending)
+      nblocks      number of d blocks in the archive
+      mine         block ids this rank compresses (owner = rank holding the block's first fragment)
+      blocks       {block id: (global fragment indices, lengths, owning rank of each fragment)}
+      send         {dst rank: global indices of MY fragments that live in blocks owned by dst, in order}
+      recv         {src rank: global indices of fragments I need from src, in order}"""
+    first = np.asarray(first)
+    lens = np.asarray(lens, dtype=np.int64)
+    ntot = len(first)
+    is_new = first == np.arange(ntot, dtype=first.dtype)
+    uniq_idx = np.nonzero(is_new)[0]
+    blk, nblk = pack_blocks(lens[uniq_idx], block_limit)
+    bounds = np.cumsum(np.asarray(counts, dtype=np.int64))
+    owner = np.searchsorted(bounds, uniq_idx, side="right")          # rank holding each unique fragment
+    first_in_blk = np.concatenate(([0], np.nonzero(np.diff(blk))[0] + 1)) if len(blk) else np.zeros(0, dtype=np.int64)
+    blk_owner = owner[first_in_blk] if len(blk) else np.zeros(0, dtype=np.int64)
+    starts = np.concatenate((first_in_blk, [len(uniq_idx)])).astype(np.int64)
+    mine = np.nonzero(blk_owner == rank)[0]
+    blocks = {}
+    recv = {}
+    for b in mine:
+        sl = slice(starts[b], starts[b + 1])
+        blocks[int(b)] = (uniq_idx[sl], lens[uniq_idx[sl]], owner[sl])
+        for src in np.unique(owner[sl]):
+            if src != rank:
+                recv.setdefault(int(src), []).append(uniq_idx[sl][owner[sl] == src])
+    send = {}
+    if len(blk):
+        theirs = np.nonzero((owner == rank) & (blk_owner[blk] != rank))[0]
+        for dst in np.unique(blk_owner[blk[theirs]]):
+            send[int(dst)] = uniq_idx[theirs[blk_owner[blk[theirs]] == dst]]
+    recv = {k: np.concatenate(v) for k, v in recv.items()}
+    return dict(uniq_idx=uniq_idx, nblocks=int(nblk), mine=mine, blocks=blocks, send=send, recv=recv,
+                starts=starts, owner=owner, blk=blk, blk_owner=blk_owner, is_new=is_new)
+
+
+def first_occurrence(digests20):
+    """Exact first-occurrence index over an (n,20) uint8 digest table (CPU stand-in for zpq_dedup_dev in tests)."""
+    d = np.ascontiguousarray(digests20).view([("k", "V20")]).ravel()
+    _, idx, inv = np.unique(d, return_index=True, return_inverse=True)
+    return idx[inv].astype(np.int64)
