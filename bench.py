@@ -148,7 +148,7 @@ class Pipeline:
                 jobs[k].method = b"14"
                 jobs[k].filename = names[-1]
                 jobs[k].comment = b"jDC\x01"
-                jobs[k].dosha1 = 1
+                jobs[k].dosha1 = 0 if getattr(self, 'no_block_sha1', False) else 1
                 jobs[k].out = outs.data_ptr() + p_out
                 jobs[k].out_cap = ocap[k]
                 p_in += (blk_n[k] + 63 + 64) & ~63
@@ -203,42 +203,19 @@ class Pipeline:
 
 
 def cpu_baseline(corpus, copies):
-    """The CPU oracle (a port of the reference's path, oracle/liboracle.so) on this host's cores -- one
-    worker thread per core, as `zpaqfranz -tN` would use them (ctypes releases the GIL) -- on a bounded
-    sample: fragment + SHA-1 of one Silesia-sized copy, compressBlock("14") of its first blocks; the
-    x256 job is extrapolated as 256 x fragment/hash + 1 x compress of the unique copy."""
-    import orc
-    from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
-
-    def frag_hash(b):
-        off = 0
-        for ln in orc.chunk(b):
-            orc.sha1(b[off:off + ln]); off += ln
-        return len(b)
-
-    # split members into ~8 MiB pieces so that every core has work (files are independent anyway)
-    pieces = [b[i:i + (8 << 20)] for _, b in corpus for i in range(0, len(b), 8 << 20)]
-    t0 = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        nbytes = sum(ex.map(frag_hash, pieces))
-    t_fh = (time.time() - t0) / max(1, nbytes)          # s per input byte, fragment + SHA-1, all cores
-    blob = b"".join(b for _, b in corpus)
-    nblk = min(max(2, cores), (len(blob) + BLOCK_LIMIT - 1) // BLOCK_LIMIT)
-    blks = [blob[i * BLOCK_LIMIT:(i + 1) * BLOCK_LIMIT] for i in range(nblk)]
-    t1 = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        outs = list(ex.map(lambda x: len(orc.compress_block(x, "14", "jDC20240101000000d0000000001", "jDC\x01", True)[0]), blks))
-    cin, cout = sum(len(x) for x in blks), sum(outs)
-    t_c = (time.time() - t1) / max(1, cin)
-    unit = sum(len(b) for _, b in corpus)
-    est_time = t_fh * unit * copies + t_c * unit
-    est_out = unit * (cout / max(1, cin))
-    return {"value": round(est_out / 1e6 / est_time, 3), "unit": "MB/s compressed output", "cores": cores, "kind": "port",
-            "input_GBps": round(unit * copies / 1e9 / est_time, 4),
-            "sample": "oracle/liboracle.so on %d threads: fragment+SHA-1 of %d MB (%.1f s) and compressBlock('14') of %d MB "
-                      "(%.1f s, ratio %.3f); extrapolated to 256 x fragment/hash + 1 x compress"
-                      % (cores, nbytes >> 20, t_fh * nbytes, cin >> 20, t_c * cin, cout / max(1, cin))}
+    """Runs tests/cpu_baseline.py (the CPU oracle on all host cores) in a fresh process and returns its JSON."""
+    import subprocess
+    import tempfile
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.NamedTemporaryFile(dir=d, suffix=".corpus") as f:
+        for _, b in corpus:
+            f.write(b)
+        f.flush()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline.py"), f.name, str(copies)],
+                           capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"value": None, "error": r.stderr[-300:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -249,6 +226,8 @@ def main():
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -264,6 +243,7 @@ def main():
     eng = Engine(local)
     corpus = datagen.silesia_like(seed=rank, scale=a.scale)
     pipe = Pipeline(eng, dev, corpus, a.copies, rank, world)
+    pipe.no_block_sha1 = a.no_block_sha1
 
     def barrier():
         if world > 1:
@@ -272,7 +252,7 @@ def main():
 
     for _ in range(a.warmup):
         pipe.step()
-    eng.profile(True)
+    eng.profile(not a.no_kernel_timing)
     barrier()
     t0 = time.perf_counter()
     out_bytes = 0

@@ -514,3 +514,28 @@ extern "C" long orc_decompress_block(const U8* arc, long n, U8* out, long cap, l
   meta[0] = p;
   return r;
 }
+
+// The fragment loop of Jidac::add in one call: fragment buf[0..n) and SHA-1
+// every fragment, entirely in C so that a thread pool can run it without Python in the way
+// (bench.py cpu_baseline).  Returns the fragment count; *digest_xor receives the XOR of the first 8
+// digest bytes (keeps the work observable).
+extern "C" long orc_fragment_and_hash(const U8* buf, long n, int fragment, U32 min_frag, U32 max_frag, U64* digest_xor) {
+  long nf = 0, i = 0; U64 acc = 0;
+  while (i < n) {
+    U32 h = 0, sz = 0; U8 o1[256]; memset(o1, 0, 256); unsigned c1 = 0;
+    const long start = i;
+    Sha1 s;
+    while (i < n) {
+      unsigned c = buf[i++];
+      if (c == o1[c1]) h = (h + c + 1) * 314159265u; else h = (h + c + 1) * 271828182u;
+      o1[c1] = (U8)c; c1 = c; ++sz;
+      if (sz >= max_frag || (fragment <= 22 && h < (1u << (22 - fragment)) && sz >= min_frag)) break;
+    }
+    s.update(buf + start, (size_t)(i - start));
+    U8 d[20]; s.final(d);
+    U64 v; memcpy(&v, d, 8); acc ^= v;
+    ++nf;
+  }
+  if (digest_xor) *digest_xor = acc;
+  return nf;
+}

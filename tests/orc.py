@@ -19,7 +19,7 @@ def _build():
 
 _L = C.CDLL(_build())
 _u8p = C.POINTER(C.c_ubyte)
-for name in ("orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block"):
+for name in ("orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
     getattr(_L, name).restype = C.c_long
 
 
@@ -45,6 +45,25 @@ def chunk(b, fragment=6, min_frag=4096, max_frag=520192):
     n = _L.orc_chunk(_buf(b), C.c_long(len(b)), fragment, C.c_uint32(min_frag), C.c_uint32(max_frag), lens, C.c_long(cap))
     assert n <= cap
     return list(lens[:n])
+
+
+def fragment_and_hash_view(mem, offset, n, fragment=6, min_frag=4096, max_frag=520192):
+    """Fragment + SHA-1 of mem[offset:offset+n] where mem is a ctypes array created once by the caller
+    (no per-call copy; the C call releases the GIL)."""
+    x = C.c_uint64(0)
+    nf = _L.orc_fragment_and_hash(C.byref(mem, offset), C.c_long(n), fragment, C.c_uint32(min_frag), C.c_uint32(max_frag), C.byref(x))
+    return nf, x.value
+
+
+def compress_block_view(mem, offset, n, method="14"):
+    """compressBlock of mem[offset:offset+n] without copying the input (output size only)."""
+    cap = n + n // 8 + 4096
+    out = (C.c_ubyte * cap)()
+    args = (C.c_int * 9)()
+    r = _L.orc_compress_block(C.byref(mem, offset), C.c_long(n), method.encode(), b"jDC20240101000000d0000000001", b"jDC\x01", 1, out, C.c_long(cap), args)
+    if r < 0:
+        raise RuntimeError("orc_compress_block failed: %d" % r)
+    return r
 
 
 def e8e9(b):

@@ -278,3 +278,12 @@ def test_libzpaq_shim_multithreaded_cpp_caller(tmp_path):
     assert (tmp_path / "out.back").read_bytes() == data
     if orc.have_ref():     # and the REAL reference decoder accepts the archive the shim wrote
         assert orc.ref_decompress(want, len(data) + 64) == data
+
+
+def test_fragmenter_fragments_longer_than_a_segment(eng):
+    """Fragments that swallow whole 256 KiB speculation segments (no cut inside a segment): incompressible
+    data with max-size fragments, and a run whose period defeats the rolling hash."""
+    files = [datagen.random_bytes(3 << 20, 41), bytes(range(256)) * 9000, datagen.random_bytes((1 << 20) + 5, 42)]
+    p = eng.fragment_params(2, 1 << 19, 2 << 20)        # min 512 KiB, max 2 MiB: every fragment spans >= 2 segments
+    assert eng.fragment_files(files, p) == _oracle_frags(files, 2, 1 << 19, 2 << 20)
+    assert eng.fragment_files(files) == _oracle_frags(files)

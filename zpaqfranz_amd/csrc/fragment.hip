@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr u64 kSegBytes = 1ull << 20;
+constexpr u64 kSegBytes = 1ull << 18;   // speculation segment (independent of the fragment size limits)
 constexpr u64 kNone = ~0ull;
 
 struct FragP {
@@ -188,15 +188,16 @@ __device__ __forceinline__ bool lane_group(const u32x4 d, u64& pos, const u64 fi
   return false;
 }
 
-// A lane's input stream: the 64 bytes being walked plus the next 128 already in flight (there are
-// only one or two waves per SIMD in these kernels, so HBM latency has to be hidden by hand).
+// A lane's input stream: the 64 bytes being walked plus the next 128 already in flight (these kernels
+// run at 2-3 waves per SIMD -- LDS bound -- so HBM latency has to be hidden by hand).  The steady-state
+// prefetch is UNCONDITIONAL (clamped address, executed by every lane every step): a load behind a branch
+// would force the compiler to drain the whole queue (s_waitcnt vmcnt(0)) before touching older data.
 struct LaneStream {
-  u64 at;          // stream offset of a[0]; ~0 when nothing is loaded
-  u64 readable;    // bytes of the data buffer that may be read
+  u64 at;          // stream offset of a[0]; ~0 when nothing usable is loaded
+  u64 last;        // highest offset a 16-byte load may start at (readable - 16)
   u32x4 a[4], b[4], c[4];
   __device__ __forceinline__ u32x4 ld(const u8* data, u64 off) const {
-    const u32x4 z = {0, 0, 0, 0};
-    return off + 16 <= readable ? *(const u32x4_u*)(data + off) : z;
+    return *(const u32x4_u*)(data + (off < last ? off : last));
   }
   __device__ __forceinline__ void prime(const u8* data, u64 pos) {
     at = pos;
@@ -205,40 +206,43 @@ struct LaneStream {
   }
 };
 
-// Advances this lane's stream by 64 bytes (16 or 1 near the end of [pos, lim)).
-// on_cut(E) is called for every cut; the lane is finished when pos >= lim.
+// Advances this lane's stream by 64 bytes (16 or 1 near the end of [pos, lim)).  Must be called by
+// every lane of the wave every step (finished lanes pass pos >= lim and only take part in the
+// prefetch).  on_cut(E) is called for every cut.
 template <class OnCut>
 __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStream& ls, u64& pos, const u64 lim,
                                           const u64 file_end, const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
   if (pos + 64 <= lim) {
-    if (ls.at != pos) ls.prime(data, pos);
+    if (ls.at != pos) ls.prime(data, pos);            // rare: first step, or right after a cut
+    bool cut = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      if (lane_group(ls.a[g], pos, file_end, P, o, s, on_cut)) { ls.at = ~0ull; return; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { ls.a[i] = ls.b[i]; ls.b[i] = ls.c[i]; ls.c[i] = ls.ld(data, pos + 128 + 16 * i); }
-    ls.at = pos;
-    return;
-  }
-  ls.at = ~0ull;
-  if (pos + 16 <= lim) {
-    lane_group(*(const u32x4_u*)(data + pos), pos, file_end, P, o, s, on_cut);
-    return;
-  }
-  if (pos < lim) {        // fewer than 16 bytes left: one byte per call
-    const u32 c = data[pos];
-    const u32 a = o.addr(s.c1);
-    const u32 pr = o.t[a];
-    o.t[a] = (u8)c;
-    s.h = (s.h + c + 1u) * (c == pr ? 314159265u : 271828182u);
-    s.c1 = c; ++s.sz;
-    if (s.sz >= P.maxf || (s.h < P.thresh && s.sz >= P.minf) || pos + 1 == file_end) {
-      on_cut(pos);
-      o.clear();
-      s.h = 0; s.c1 = 0; s.sz = 0;
+      if (!cut) cut = lane_group(ls.a[g], pos, file_end, P, o, s, on_cut);
+    ls.at = cut ? ~0ull : pos;
+  } else {
+    ls.at = ~0ull;
+    if (pos + 16 <= lim) {
+      lane_group(*(const u32x4_u*)(data + pos), pos, file_end, P, o, s, on_cut);
+    } else if (pos < lim) {   // fewer than 16 bytes left: one byte per call
+      const u32 c = data[pos];
+      const u32 a = o.addr(s.c1);
+      const u32 pr = o.t[a];
+      o.t[a] = (u8)c;
+      s.h = (s.h + c + 1u) * (c == pr ? 314159265u : 271828182u);
+      s.c1 = c; ++s.sz;
+      if (s.sz >= P.maxf || (s.h < P.thresh && s.sz >= P.minf) || pos + 1 == file_end) {
+        on_cut(pos);
+        o.clear();
+        s.h = 0; s.c1 = 0; s.sz = 0;
+      }
+      ++pos;
     }
-    ++pos;
   }
+  // steady-state rotation: a <- b <- c <- bytes [pos+128, pos+192) (meaningless but harmless when the
+  // stream is out of step; the next call primes)
+  const u64 nxt = (ls.at == pos ? pos : 0) + 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ls.a[i] = ls.b[i]; ls.b[i] = ls.c[i]; ls.c[i] = ls.ld(data, nxt + 16 * i); }
 }
 
 // ---- 1. speculative pass: one LANE per 1 MiB segment ----------------------------------------------
@@ -263,14 +267,12 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
     pos = g;
   }
   LaneState st{0, 0, 0};
-  LaneStream ls; ls.at = ~0ull; ls.readable = readable;
+  LaneStream ls; ls.at = ~0ull; ls.last = readable >= 16 ? readable - 16 : 0;
   u32 cnt = 0;
   u32* out = spec_rel + s * (u64)spec_cap;
-  while (__any(active)) {
-    if (active) {
-      lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
-      active = pos < lim;
-    }
+  while (__any(active)) {      // finished lanes keep stepping (pos >= lim: prefetch only)
+    lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
+    active = pos < lim;
   }
   if (s < nseg) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;
 }
@@ -306,16 +308,16 @@ __global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict_
     if (k + 1 < nsegf && nk > 0 && nk < spec_cap) {
       so.start = g + spec_rel[s * (u64)spec_cap + nk - 1] + 1;
       pos = so.start;
-      lim = g + 2 * kSegBytes < fe ? g + 2 * kSegBytes : fe;     // give up at the end of segment k+1
+      lim = g + 9 * kSegBytes < fe ? g + 9 * kSegBytes : fe;     // give up 8 segments further on (fragments may span several)
       active = true;
       if (pos == g + kSegBytes) { so.sync_seg = k + 1; so.sync_from = 0; active = false; }   // cut on the boundary
     }
   }
   LaneState st{0, 0, 0};
-  LaneStream ls; ls.at = ~0ull; ls.readable = readable;
+  LaneStream ls; ls.at = ~0ull; ls.last = readable >= 16 ? readable - 16 : 0;
   u32* out = seam_rel + s * (u64)spec_cap;
-  while (__any(active)) {
-    if (active) {
+  while (__any(active)) {      // finished lanes keep stepping with pos >= lim (prefetch only)
+    {
       bool synced = false;
       lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) {
         if (so.cnt < spec_cap) out[so.cnt] = (u32)(E - g);
@@ -332,7 +334,8 @@ __global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict_
           if (lo < spec_cnt[s2] && rel[lo] == want) { so.sync_seg = k2; so.sync_from = lo + 1; synced = true; }
         }
       });
-      active = !synced && pos < lim;
+      if (synced) lim = pos;                    // done: no further bytes for this lane
+      active = pos < lim;
     }
   }
   if (s < nseg) {
@@ -389,8 +392,8 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
       synced = false;
       rd.init(S);
     }
-    // exact evaluation of one fragment, then look for the speculation again
-    if ((S - fs) % kSegBytes == 0) { synced = true; k = (u32)((S - fs) / kSegBytes); from = 0; continue; }
+    // exact evaluation of one fragment, then look for the speculation again.  (No alignment test on
+    // S here: a segment without any speculative cut hands over at its own start and must make progress.)
     const u64 E = eval_fragment(rd, lds[wave], S, fe, kNone, P);
     if (lane == 0) out[cnt] = E;
     ++cnt;

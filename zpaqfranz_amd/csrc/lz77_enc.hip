@@ -450,6 +450,9 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
 // ---- speculative parse: one wave per segment ------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
+  // The block-checksum chains (sha1_chain_kernel, other stream) are pure VALU and may land on the same
+  // SIMD: this latency-bound parse must win issue arbitration or its slowest wave doubles the launch.
+  __builtin_amdgcn_s_setprio(3);
   const LzSegDev S = segs[list[blockIdx.x]];
   __shared__ unsigned long long T[256];
   const u32 lane = (u32)lane_id();
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
 template <int NB>
 __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
                                                          const u32* __restrict__ list) {
+  __builtin_amdgcn_s_setprio(3);
   const LzJobDev J = jobs[list[blockIdx.x]];
   __shared__ unsigned long long T[256];
   const u32 lane = (u32)lane_id();

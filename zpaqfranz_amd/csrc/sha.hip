@@ -267,7 +267,19 @@ int persistent_grid(zpq_ctx* ctx, size_t n) {
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests) {
   if (n == 0) return ZPQ_OK;
-  ZPQ_LAUNCH(ctx, "sha1_chain_kernel", s, sha1_chain_kernel, dim3((unsigned)n), dim3(64), d_base, d_off, d_len, d_digests);
+  // Each chain wants a SIMD to itself (it is bound by dependent-issue latency; a co-resident wave of a
+  // concurrent kernel would stretch it, or be stretched by it).  Asking for most of a CU's LDS keeps
+  // other workgroups that use LDS off the CU; chains are few (one per block), so the cost is nil.
+  static bool attr_set = false;
+  const unsigned hog = 163840 - 512;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sha1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hog);
+    attr_set = true;
+  }
+  {
+    ZpqProfScope prof_scope_(ctx, "sha1_chain_kernel", s);
+    hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), n <= 64 ? hog : 0, s, d_base, d_off, d_len, d_digests);
+  }
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
