@@ -35,19 +35,22 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 class Pipeline:
-    def __init__(self, eng, device, corpus, copies, rank, world):
+    def __init__(self, eng, device, corpus, copies, rank, world, share=None):
         from zpaqfranz_amd import engine as E
         self.E, self.eng, self.dev, self.rank, self.world = E, eng, device, rank, world
         base = b"".join(b for _, b in corpus)
         sizes = [len(b) for _, b in corpus]
         self.unit = len(base)
         self.total = self.unit * copies
-        self.data = torch.empty(self.total + 64, dtype=torch.uint8, device=device)
-        hb = torch.frombuffer(bytearray(base), dtype=torch.uint8)
-        self.data[: self.unit].copy_(hb)
-        for c in range(1, copies):
-            self.data[c * self.unit:(c + 1) * self.unit].copy_(self.data[: self.unit])
-        self.data[self.total:].zero_()
+        if share is not None:
+            self.data = share.data                       # the input is read-only: pipelines share it
+        else:
+            self.data = torch.empty(self.total + 64, dtype=torch.uint8, device=device)
+            hb = torch.frombuffer(bytearray(base), dtype=torch.uint8)
+            self.data[: self.unit].copy_(hb)
+            for c in range(1, copies):
+                self.data[c * self.unit:(c + 1) * self.unit].copy_(self.data[: self.unit])
+            self.data[self.total:].zero_()
         off = [0]
         for c in range(copies):
             for s in sizes:
@@ -62,10 +65,16 @@ class Pipeline:
         self.frag_file = torch.empty(self.cap, dtype=i32, device=device)
         self.digests = torch.empty(self.cap * 20 + 64, dtype=u8, device=device)
         self.first = torch.empty(self.cap * max(1, world), dtype=i32, device=device)
+        self.tstream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize()
 
     def step(self):
+        with torch.cuda.stream(self.tstream):
+            return self._step()
+
+    def _step(self):
         eng, E, dev = self.eng, self.E, self.dev
+        tsync = self.tstream.synchronize   # waits for THIS pipeline's torch work only (another step may be in flight)
         # 1. fragment + 2. SHA-1 of every fragment
         nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
                               self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
@@ -90,7 +99,7 @@ class Pipeline:
             flen = torch.cat([gl[r][: cnts[r]] for r in range(self.world)])
             my_lo = sum(cnts[: self.rank])
             ntot = sum(cnts)
-            torch.cuda.synchronize()
+            tsync()
         else:
             cnts, ntot = [nf], nf
         # 3. dedup (global first occurrence)
@@ -121,14 +130,14 @@ class Pipeline:
             sl = torch.from_numpy(np.concatenate(src_len).astype(np.int32)).to(dev)
             do = torch.from_numpy(np.concatenate(dst_off).astype(np.int64)).to(dev)
             abs_off = self.frag_off[:nf][so]
-            torch.cuda.synchronize()
+            tsync()
             eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
                            blocks_buf.data_ptr())
             for p_, tr in trailers:
                 blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
         if self.world > 1:
             self._exchange_seams(P, lens, my_lo, nf, layout, blocks_buf)
-        eng.sync(); torch.cuda.synchronize()
+        eng.sync(); tsync()
         # 5. compressBlock on every owned block ("14": LZ77 x4,1,5,0,3,24 + framing + SHA-1)
         nb = len(mine)
         out_bytes = 0
@@ -153,7 +162,7 @@ class Pipeline:
                 jobs[k].out_cap = ocap[k]
                 p_in += (blk_n[k] + 63 + 64) & ~63
                 p_out += ocap[k]
-            torch.cuda.synchronize()
+            tsync()
             eng.compress_blocks_dev(jobs, nb)
             out_bytes = sum(jobs[k].out_len for k in range(nb))
             self.last_blocks = [(int(mine[k]), jobs[k].out_len) for k in range(nb)]
@@ -174,7 +183,7 @@ class Pipeline:
             gathered = [torch.empty_like(buf) for _ in range(self.world)]
             dist.all_gather(gathered, buf)
             out_bytes = sum(int(x.item()) for x in ts)
-            torch.cuda.synchronize()
+            tsync()
         self.stats = dict(fragments=int(ntot), unique_fragments=int(len(uniq_idx)), blocks=int(nblk),
                           unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
         return out_bytes
@@ -225,6 +234,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
+    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight (each on its own engine context); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
@@ -242,26 +252,69 @@ def main():
     from zpaqfranz_amd import Engine
     eng = Engine(local)
     corpus = datagen.silesia_like(seed=rank, scale=a.scale)
-    pipe = Pipeline(eng, dev, corpus, a.copies, rank, world)
-    pipe.no_block_sha1 = a.no_block_sha1
+    depth = max(1, a.pipeline if world == 1 else 1)       # collectives keep the multi-rank path one step deep
+    pipes = [Pipeline(eng, dev, corpus, a.copies, rank, world)]
+    engines = [eng]
+    for _ in range(1, depth):
+        e2 = Engine(local)
+        engines.append(e2)
+        pipes.append(Pipeline(e2, dev, corpus, a.copies, rank, world, share=pipes[0]))
+    pipe = pipes[0]
+    for p_ in pipes:
+        p_.no_block_sha1 = a.no_block_sha1
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(); eng.sync()
+        torch.cuda.synchronize()
+        for e_ in engines:
+            e_.sync()
 
-    for _ in range(a.warmup):
-        pipe.step()
-    eng.profile(not a.no_kernel_timing)
+    def run_steps(n):
+        """n whole-job steps; with depth > 1 they are software-pipelined: while one step sits in its
+        latency-bound tail (LZ77 parse, block checksums: a few hundred waves) the next one already
+        fragments and hashes on the rest of the chip.  Every step is complete when this returns."""
+        import threading
+        nxt, lock, outs, errs = [0], threading.Lock(), [0] * n, []
+
+        def worker(p_, delay):
+            try:
+                time.sleep(delay)      # stagger: one step's chip-wide kernels against the other's latency-bound tail
+                while True:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= n:
+                        return
+                    outs[i] = p_.step()
+            except Exception as ex:       # surface worker failures in the main thread
+                errs.append(ex)
+        if depth == 1:
+            worker(pipes[0], 0.0)
+        else:
+            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth)) for k_, p_ in enumerate(pipes)]
+            for t in th: t.start()
+            for t in th: t.join()
+        if errs:
+            raise errs[0]
+        return outs[-1] if n else 0
+
+    stagger = [0.0]
+    if depth > 1:            # one untimed serial step per context: sizes scratch, measures the step for the stagger
+        for p_ in pipes:
+            t_ = time.perf_counter(); p_.step(); stagger[0] = time.perf_counter() - t_
+    run_steps(a.warmup)
+    for e_ in engines:
+        e_.profile(not a.no_kernel_timing)
     barrier()
     t0 = time.perf_counter()
-    out_bytes = 0
-    for _ in range(a.steps):
-        out_bytes = pipe.step()
+    out_bytes = run_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    kern = eng.profile_report()
-    eng.profile(False)
+    kern = {}
+    for e_ in engines:
+        for k_, (c_, m_) in e_.profile_report().items():
+            kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
+        e_.profile(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -297,7 +350,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": "silesia_x%d_m1" % a.copies, "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **pipe.stats},
-               "input_GBps": round(in_bytes / 1e9 / sec, 3),
+               "input_GBps": round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
+               "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
                "kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                "roofline": roof_dom, "roofline_all": roof_all}
         if world == 1 and not a.no_cpu_baseline:
@@ -310,7 +364,8 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
-    eng.close()
+    for e_ in engines:
+        e_.close()
 
 
 if __name__ == "__main__":
