@@ -184,6 +184,36 @@ typedef struct zpq_unblock_job {
 } zpq_unblock_job;
 int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
 
+/* ---- context-mixing blocks, n > 0 components (rows a11-a16) ---------------------------------- */
+/* header = the block header exactly as stored in the archive, starting at hsize[2]
+ * (hsize hh hm ph pm n COMP 0 HCOMP 0; ZPAQL::read, ZSFX/libzpaq.cpp:879-921), host pointer.
+ * encode: d_in = the bytes the Encoder sees (post-processor preamble + data); the output is the
+ *         arithmetic-coded stream including the end-of-segment symbol and the four 0 bytes that
+ *         follow it (what sits between the segment header and the 253/254 marker).
+ * decode: d_in = that stream; output = the decoded bytes (preamble included).  Decoding stops at
+ *         out_cap bytes with status ZPQ_ERR_CAPACITY (the bytes produced so far are valid). */
+typedef struct zpq_cm_job {
+  const uint8_t* header;  /* host */
+  uint32_t header_len;
+  const uint8_t* d_in;    /* device, readable 64 bytes past n */
+  uint32_t n;
+  uint8_t* d_out;         /* device */
+  uint32_t out_cap;
+  uint32_t out_len;       /* result */
+  int32_t status;         /* result */
+} zpq_cm_job;
+int zpq_cm_encode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs);
+int zpq_cm_decode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs);
+/* The model-independent tables the predictor uses (generated, not stored): squash[4096],
+ * stretch[32768], dt[1024], dt2k[256], ns[1024] -- exported so that tests can compare them with
+ * the reference's literal tables (ZSFX/libzpaq.cpp:718-847, 1264-1695). Host call, no GPU needed. */
+int zpq_cm_tables(uint16_t* squash, int16_t* stretch, int32_t* dt, int32_t* dt2k, uint8_t* ns);
+/* Generic post-processor (rows a14, a16): runs the PCOMP program `pcomp[0..psize)` (host pointer,
+ * bytecode without the 2-byte length) with H = 2^ph words, M = 2^pm bytes once per input byte and
+ * once with 2^32-1 at the end (PostProcessor::write, ZSFX/libzpaq.cpp:2185-2226); OUT bytes -> d_out. */
+int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm,
+                      const uint8_t* d_in, uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,9 @@
 // goes to oracle/_ref/ (git-ignored, but shipped to the GPU box by gpurun).
 //
 // Build: see oracle/Makefile (target _ref/libzpaqref.so).  Requires /root/reference.
+#define private public     // test shim only: lets ref_tables() read the Predictor's lookup tables
 #include "libzpaq.cpp"   // resolved through -I/root/reference/ZSFX
+#undef private
 
 #include <stdexcept>
 #include <string>
@@ -182,6 +184,42 @@ long ref_cm_encode(const unsigned char* header, long hlen, const unsigned char* 
     }
     encode(1, 0);
     v.push_back(0); v.push_back(0); v.push_back(0); v.push_back(0);
+    return emit(v, out, cap);
+  });
+}
+
+// The model-independent lookup tables exactly as the reference Predictor holds them after init()
+// (ZSFX/libzpaq.cpp:1724-1742, sources :718-847 and :1264-1695): squash[4096], stretch[32768],
+// dt[1024], dt2k[256], and the bit-history next-state table ns[1024].
+long ref_tables(unsigned short* squash, short* stretch, int* dt, int* dt2k, unsigned char* ns) {
+  return guarded([&]() -> long {
+    const unsigned char hdr[12] = {10, 0, 0, 0, 0, 0, 1, 1, 128, 0, 56, 0};   // comp 0 0 0 0 1 (cons 128) hcomp halt
+    MemReader hr(hdr, sizeof hdr);
+    libzpaq::ZPAQL z; z.read(&hr);
+    libzpaq::Predictor pr(z); pr.init();
+    memcpy(squash, pr.squasht, sizeof pr.squasht);
+    memcpy(stretch, pr.stretcht, sizeof pr.stretcht);
+    memcpy(dt, pr.dt, sizeof pr.dt);
+    memcpy(dt2k, pr.dt2k, sizeof pr.dt2k);
+    memcpy(ns, pr.st.ns, 1024);
+    return 0;
+  });
+}
+
+// Context-mixing DECODE of one coded segment with the reference Decoder/Predictor: header as for
+// ref_cm_encode, coded = arithmetic-coded bytes including the four trailing zero bytes.
+long ref_cm_decode(const unsigned char* header, long hlen, const unsigned char* coded, long n,
+                   unsigned char* out, long cap) {
+  return guarded([&]() -> long {
+    MemReader hr(header, hlen);
+    libzpaq::ZPAQL z; z.read(&hr);
+    libzpaq::Decoder dec(z);
+    MemReader in(coded, n);
+    dec.in = &in;
+    dec.init();
+    std::vector<unsigned char> v;
+    int c;
+    while ((c = dec.decompress()) >= 0) v.push_back((unsigned char)c);
     return emit(v, out, cap);
   });
 }

@@ -130,7 +130,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libzpaqref.so")
 _R = None
 if os.path.exists(REF_SO):
     _R = C.CDLL(REF_SO)
-    for name in ("ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode"):
+    for name in ("ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode", "ref_cm_decode", "ref_tables"):
         getattr(_R, name).restype = C.c_long
     _R.ref_last_error.restype = C.c_char_p
 
@@ -214,3 +214,18 @@ def ref_cm_encode(header, data):
     if r < 0:
         raise RuntimeError("ref_cm_encode: %s" % _R.ref_last_error())
     return bytes(out[:r])
+
+
+def ref_cm_decode(header, coded, cap):
+    out = (C.c_ubyte * max(1, cap))()
+    r = _R.ref_cm_decode(_buf(header), C.c_long(len(header)), _buf(coded), C.c_long(len(coded)), out, C.c_long(cap))
+    if r < 0:
+        raise RuntimeError("ref_cm_decode: %s" % _R.ref_last_error())
+    return bytes(out[:r])
+
+
+def ref_tables():
+    sq = (C.c_uint16 * 4096)(); st = (C.c_int16 * 32768)(); dt = (C.c_int * 1024)(); d2 = (C.c_int * 256)(); ns = (C.c_ubyte * 1024)()
+    if _R.ref_tables(sq, st, dt, d2, ns) != 0:
+        raise RuntimeError("ref_tables: %s" % _R.ref_last_error())
+    return list(sq), list(st), list(dt), list(d2), bytes(ns)

@@ -287,3 +287,67 @@ def test_fragmenter_fragments_longer_than_a_segment(eng):
     p = eng.fragment_params(2, 1 << 19, 2 << 20)        # min 512 KiB, max 2 MiB: every fragment spans >= 2 segments
     assert eng.fragment_files(files, p) == _oracle_frags(files, 2, 1 << 19, 2 << 20)
     assert eng.fragment_files(files) == _oracle_frags(files)
+
+
+# ---------------------------------------------------------------------------------------------------
+# rows a11-a16: context mixing (Predictor + arithmetic coder + ZPAQL HCOMP), checked against the
+# REAL reference Predictor/Decoder compiled in place (oracle/_ref)
+# ---------------------------------------------------------------------------------------------------
+import cmconfigs
+
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
+
+
+@needs_ref
+@pytest.mark.parametrize("name", list(cmconfigs.ALL))
+def test_cm_encode_decode_equal_reference(eng, name):
+    header, _ = orc.ref_compile(cmconfigs.ALL[name], [0] * 9)
+    inputs = [b"", b"\0", b"\0" + datagen.text_like(6000, 5), b"\0" + datagen.binary_like(5000, 6), b"\0" + bytes(3000),
+              b"\0" + datagen.random_bytes(2000, 7)]
+    want = [orc.ref_cm_encode(header, x) for x in inputs]
+    got = eng.cm_code([header] * len(inputs), inputs, [len(x) + len(x) // 2 + 64 for x in inputs], encode=True)
+    for x, w, (st, g) in zip(inputs, want, got):
+        assert st == 0 and g == w, (name, len(x))
+    back = eng.cm_code([header] * len(inputs), want, [len(x) + 16 for x in inputs], encode=False)
+    for x, (st, g) in zip(inputs, back):
+        assert st == 0 and g == x
+        assert orc.ref_cm_decode(header, want[inputs.index(x)], len(x) + 16) == x
+
+
+def test_cm_decode_fixture_dblock_prefix(eng, dplain):
+    """The -m5 d block of AUTOTEST/sha256.zpaq (23 components, 171-byte HCOMP): decode the first bytes of its
+    arithmetic-coded stream and compare with the golden plaintext (first decoded byte is the PASS marker 0)."""
+    arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()
+    blk = json.load(open(os.path.join(G, "blocks.json")))[1]
+    raw = arc[blk["offset"]: blk["offset"] + blk["size"]]
+    hs = 13 + 5
+    hsize = raw[hs] | raw[hs + 1] << 8
+    header = raw[hs: hs + 2 + hsize]
+    assert header[6] == 23
+    p = hs + 2 + hsize
+    assert raw[p] == 1
+    p += 1
+    p = raw.index(b"\0", p) + 1      # filename
+    p = raw.index(b"\0", p) + 1      # comment
+    p += 1                           # reserved
+    coded = raw[p: len(raw) - 22]    # ... 00 00 00 00 | fd sha1[20] ff
+    assert coded[-4:] == b"\0\0\0\0"
+    n = 3000
+    (st, got), = eng.cm_code([header], [coded], [n + 1], encode=False)
+    assert st == -4                  # stopped at out_cap: the stream holds 9 473 561 bytes
+    assert got == b"\0" + dplain[:n]
+
+
+@needs_ref
+def test_generic_pcomp_vm_runs_the_lz77_program(eng):
+    """Row a14/a16: the generic ZPAQL interpreter executing the 302-byte level-1 PCOMP byte by byte must give
+    what the reference PostProcessor gives (and what the native LZ77 decoder gives)."""
+    arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()
+    blk = json.load(open(os.path.join(G, "blocks.json")))[3]
+    raw = arc[blk["offset"]: blk["offset"] + blk["size"]]
+    plain = open(os.path.join(G, "iblock1.bin"), "rb").read()
+    k = raw.index(b"\x01\x2e\x01")
+    pcomp = raw[k + 3: k + 3 + 302]
+    stream = orc.lz77_encode(plain, [0, 1, 5, 0, 3, 20])
+    assert eng.pcomp_run(pcomp, 0, 20, stream, len(plain) + 64) == plain
+    assert orc.ref_postprocess(b"\x01\x2e\x01" + pcomp + stream, 0, 20, len(plain) + 64) == plain

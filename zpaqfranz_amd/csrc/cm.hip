@@ -1,0 +1,672 @@
+// Context-mixing codec for ZPAQ blocks with n > 0 components: the Predictor
+// (CONS/CM/ICM/MATCH/AVG/MIX2/MIX/ISSE/SSE), the 32-bit binary arithmetic coder, and the ZPAQL virtual
+// machine that computes the component contexts (HCOMP) and post-processes decoded data (PCOMP).
+// Reference: Predictor::init/predict0/update0/find/train (ZSFX/libzpaq.cpp:1715-2080, ZSFX/libzpaq.h:1151-1185),
+// Decoder::decode/decompress (:2096-2137), Encoder (declaration ZSFX/libzpaq.h:1273-1286; mirror of the
+// decoder), ZPAQL::run0/execute (:1019-1254), PostProcessor::write (:2185-2226).
+//
+// The lookup tables are GENERATED (squash/stretch from their defining formulas, quoted in the reference
+// at :1733 and :1739; the bit-history state table from the ZPAQ specification's num_states/next_state
+// rules); tests compare every entry with the reference's literal tables.
+//
+// Round-1 shape: one block = one serial chain of bit decisions; this first version walks it with ONE
+// lane per block (throughput comes from blocks in flight, as on the CPU it comes from threads), all
+// state in HBM except the per-bit scalars.  It is here for coverage and parity; mapping components to
+// lanes and the hot tables to LDS is the planned optimisation.
+#include <math.h>
+
+#include "zpq_internal.h"
+
+namespace {
+
+enum { NONE = 0, CONS, CM, ICM, MATCH, AVG, MIX2, MIX, ISSE, SSE };
+const int kCompSize[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};   // ZSFX/libzpaq.cpp:706
+
+struct Tables {
+  u16 squash[4096];
+  short stretch[32768];
+  int dt[1024];
+  int dt2k[256];
+  u8 ns[1024];
+};
+
+// ---- table generation (host) ------------------------------------------------------------------------
+int num_states(int n0, int n1) {
+  const int B = 6;
+  const int bound[B] = {20, 48, 15, 8, 6, 5};
+  if (n0 < n1) return num_states(n1, n0);
+  if (n0 < 0 || n1 < 0 || n1 >= B || n0 > bound[n1]) return 0;
+  return 1 + (n1 > 0 && n0 + n1 <= 17);
+}
+void discount(int& n0) { n0 = (n0 >= 1) + (n0 >= 2) + (n0 >= 3) + (n0 >= 4) + (n0 >= 5) + (n0 >= 7) + (n0 >= 8); }
+void next_state(int& n0, int& n1, int y) {
+  if (n0 < n1) { next_state(n1, n0, 1 - y); return; }
+  if (y) { ++n1; discount(n0); } else { ++n0; discount(n1); }
+  while (!num_states(n0, n1)) {
+    if (n1 < 2) --n0;
+    else { n0 = (n0 * (n1 - 1) + (n1 / 2)) / n1; --n1; }
+  }
+}
+
+void make_tables(Tables& T) {
+  for (int i = 0; i < 4096; ++i) {                       // squash(x) = floor(32768/(1+e^(-x/64))), x = i-2048
+    int v = (int)(32768.0 / (1 + exp((i - 2048) * (-1.0 / 64))));
+    T.squash[i] = (u16)(v < 0 ? 0 : v > 32767 ? 32767 : v);
+  }
+  for (int i = 16384; i < 32768; ++i)                    // stretch = ln(p/(1-p)) in 1/64 units, odd symmetric
+    T.stretch[i] = (short)((int)(log((i + 0.5) / (32767.5 - i)) * 64 + 0.5 + 100000) - 100000);
+  for (int i = 0; i < 16384; ++i) T.stretch[i] = (short)-T.stretch[32767 - i];
+  for (int i = 0; i < 1024; ++i) T.dt[i] = (1 << 17) / (i * 2 + 3) * 2;
+  T.dt2k[0] = 0;
+  for (int i = 1; i < 256; ++i) T.dt2k[i] = 2048 / i;
+  // bit-history states ordered by n0+n1, then n1 (ZPAQ specification)
+  const int N = 50;
+  static u8 t[N][N][2];
+  memset(t, 0, sizeof t);
+  int state = 0;
+  for (int i = 0; i < N; ++i)
+    for (int n1 = 0; n1 <= i; ++n1) {
+      const int n0 = i - n1, n = num_states(n0, n1);
+      if (n) { t[n0][n1][0] = (u8)state; t[n0][n1][1] = (u8)(state + n - 1); state += n; }
+    }
+  memset(T.ns, 0, sizeof T.ns);
+  for (int n0 = 0; n0 < N; ++n0)
+    for (int n1 = 0; n1 < N; ++n1)
+      for (int y = 0; y < num_states(n0, n1); ++y) {
+        const int s = t[n0][n1][y];
+        int s0 = n0, s1 = n1;
+        next_state(s0, s1, 0); T.ns[s * 4 + 0] = t[s0][s1][0];
+        s0 = n0; s1 = n1;
+        next_state(s0, s1, 1); T.ns[s * 4 + 1] = t[s0][s1][1];
+        T.ns[s * 4 + 2] = (u8)n0; T.ns[s * 4 + 3] = (u8)n1;
+      }
+}
+
+const Tables& host_tables() {
+  static Tables T;
+  static bool done = false;
+  if (!done) { make_tables(T); done = true; }
+  return T;
+}
+
+// ---- device-side model -----------------------------------------------------------------------------------
+struct Comp {
+  u32 type, a1, a2, a3, a4, a5;   // component type and its (up to 5) header arguments
+  u32 limit, cxt, a, b, c;        // Component scalars (ZSFX/libzpaq.h:1084-1111)
+  u32* cm; u32 cm_mask;           // cm[] and size-1
+  u8* ht; u32 ht_mask;
+  u16* a16; u32 a16_mask;
+};
+
+struct Vm {                       // one ZPAQL machine (HCOMP or PCOMP)
+  const u8* prog; u32 plen;       // bytecode, execution starts at 0
+  u32* H; u32 hmask; u8* M; u32 mmask; u32* R;
+  u32 a, b, c, d, f;
+  u8* out; u32 out_cap, out_len;  // OUT instruction target (PCOMP only)
+  int err;
+};
+
+struct CmJobDev {
+  u32 n;                          // components
+  Comp* comp;
+  int* p;                         // p[256]
+  u32* h;                         // h[256]
+  Vm vm;                          // HCOMP machine
+  const Tables* T;
+  const u8* in; u32 in_len;
+  u8* out; u32 out_cap;
+  u32* result;                    // [0]=bytes produced, [1]=status
+};
+
+__device__ __forceinline__ int clamp2k(int x) { return x < -2048 ? -2048 : x > 2047 ? 2047 : x; }
+__device__ __forceinline__ int clamp512k(int x) { return x < -(1 << 19) ? -(1 << 19) : x >= (1 << 19) ? (1 << 19) - 1 : x; }
+
+// ZPAQL interpreter (ZSFX/libzpaq.cpp:1033-1254).  Operand encodings are regular: op&7 selects
+// A B C D *B *C *D N for the two-operand groups.
+__device__ void vm_run(Vm& z, u32 input) {
+  const u8* P = z.prog;
+  u32 pc = 0, a = input, b = z.b, c = z.c, d = z.d, f = z.f;
+  for (int guard = 0; guard < (1 << 30); ++guard) {
+    if (pc >= z.plen) { z.err = 1; break; }
+    const u32 op = P[pc++];
+    if (op == 56) break;                                     // HALT
+    if (op >= 64 && op < 240 && (op < 120 || op >= 128)) {
+      const u32 sel = op & 7, grp = op >> 3;
+      u32 v;
+      switch (sel) {
+        case 0: v = a; break; case 1: v = b; break; case 2: v = c; break; case 3: v = d; break;
+        case 4: v = z.M[b & z.mmask]; break; case 5: v = z.M[c & z.mmask]; break; case 6: v = z.H[d & z.hmask]; break;
+        default: v = P[pc++]; break;
+      }
+      switch (grp) {
+        case 8: a = v; break; case 9: b = v; break; case 10: c = v; break; case 11: d = v; break;
+        case 12: z.M[b & z.mmask] = (u8)v; break; case 13: z.M[c & z.mmask] = (u8)v; break; case 14: z.H[d & z.hmask] = v; break;
+        case 16: a += v; break; case 17: a -= v; break; case 18: a *= v; break;
+        case 19: a = v ? a / v : 0; break; case 20: a = v ? a % v : 0; break;
+        case 21: a &= v; break; case 22: a &= ~v; break; case 23: a |= v; break; case 24: a ^= v; break;
+        case 25: a <<= (v & 31); break; case 26: a >>= (v & 31); break;
+        case 27: f = a == v; break; case 28: f = a < v; break; case 29: f = a > v; break;
+        default: z.err = 1; break;
+      }
+      if (z.err) break;
+      continue;
+    }
+    switch (op) {
+      case 1: ++a; break; case 2: --a; break; case 3: a = ~a; break; case 4: a = 0; break;
+      case 7: a = z.R[P[pc++]]; break;
+      case 8: { u32 t = a; a = b; b = t; } break; case 9: ++b; break; case 10: --b; break; case 11: b = ~b; break; case 12: b = 0; break;
+      case 15: b = z.R[P[pc++]]; break;
+      case 16: { u32 t = a; a = c; c = t; } break; case 17: ++c; break; case 18: --c; break; case 19: c = ~c; break; case 20: c = 0; break;
+      case 23: c = z.R[P[pc++]]; break;
+      case 24: { u32 t = a; a = d; d = t; } break; case 25: ++d; break; case 26: --d; break; case 27: d = ~d; break; case 28: d = 0; break;
+      case 31: d = z.R[P[pc++]]; break;
+      // a byte of M swaps with the LOW byte of A only (swap(U8&), ZSFX/libzpaq.h:1073)
+      case 32: { u8& x = z.M[b & z.mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 33: ++z.M[b & z.mmask]; break; case 34: --z.M[b & z.mmask]; break;
+      case 35: z.M[b & z.mmask] = ~z.M[b & z.mmask]; break; case 36: z.M[b & z.mmask] = 0; break;
+      case 39: if (f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;          // JT
+      case 40: { u8& x = z.M[c & z.mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 41: ++z.M[c & z.mmask]; break; case 42: --z.M[c & z.mmask]; break;
+      case 43: z.M[c & z.mmask] = ~z.M[c & z.mmask]; break; case 44: z.M[c & z.mmask] = 0; break;
+      case 47: if (!f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;         // JF
+      case 48: { u32& x = z.H[d & z.hmask]; u32 t = x; x = a; a = t; } break;
+      case 49: ++z.H[d & z.hmask]; break; case 50: --z.H[d & z.hmask]; break;
+      case 51: z.H[d & z.hmask] = ~z.H[d & z.hmask]; break; case 52: z.H[d & z.hmask] = 0; break;
+      case 55: z.R[P[pc++]] = a; break;
+      case 57: if (z.out) { if (z.out_len < z.out_cap) z.out[z.out_len] = (u8)a; ++z.out_len; } break;   // OUT
+      case 59: a = (a + z.M[b & z.mmask] + 512) * 773; break;                        // HASH
+      case 60: z.H[d & z.hmask] = (z.H[d & z.hmask] + a + 512) * 773; break;         // HASHD
+      case 63: pc += ((P[pc] + 128) & 255) - 127; break;                             // JMP
+      case 255: { u32 t = P[pc] + 256u * P[pc + 1]; if (t >= z.plen) { z.err = 1; } pc = t; } break;   // LJ
+      default: z.err = 1; break;
+    }
+    if (z.err) break;
+  }
+  z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;
+}
+
+// find(): ZSFX/libzpaq.cpp:2064-2080
+__device__ u32 cm_find(u8* ht, u32 ht_size, int sizebits, u32 cxt) {
+  const u32 chk = (cxt >> sizebits) & 255;
+  const u32 h0 = (cxt * 16) & (ht_size - 16);
+  if (ht[h0] == chk) return h0;
+  const u32 h1 = h0 ^ 16;
+  if (ht[h1] == chk) return h1;
+  const u32 h2 = h0 ^ 32;
+  if (ht[h2] == chk) return h2;
+  u32 r;
+  if (ht[h0 + 1] <= ht[h1 + 1] && ht[h0 + 1] <= ht[h2 + 1]) r = h0;
+  else if (ht[h1 + 1] < ht[h2 + 1]) r = h1;
+  else r = h2;
+  for (int i = 0; i < 16; ++i) ht[r + i] = 0;
+  ht[r] = (u8)chk;
+  return r;
+}
+
+struct Pred {
+  const CmJobDev& J;
+  u32 c8, hmap4;
+  __device__ Pred(const CmJobDev& j) : J(j), c8(1), hmap4(1) {}
+  __device__ int squash(int x) const { return J.T->squash[x + 2048]; }
+  __device__ int stretch(u32 x) const { return J.T->stretch[x]; }
+
+  __device__ int predict() {          // predict0, ZSFX/libzpaq.cpp:1846-1943
+    int* p = J.p; const u32* h = J.h;
+    const u32 n = J.n;
+    for (u32 i = 0; i < n; ++i) {
+      Comp& cr = J.comp[i];
+      switch (cr.type) {
+        case CONS: break;
+        case CM:
+          cr.cxt = h[i] ^ hmap4;
+          p[i] = stretch(cr.cm[cr.cxt & cr.cm_mask] >> 17);
+          break;
+        case ICM:
+          if (c8 == 1 || (c8 & 0xf0) == 16) cr.c = cm_find(cr.ht, cr.ht_mask + 1, cr.a1 + 2, h[i] + 16 * c8);
+          cr.cxt = cr.ht[cr.c + (hmap4 & 15)];
+          p[i] = stretch(cr.cm[cr.cxt & cr.cm_mask] >> 8);
+          break;
+        case MATCH:
+          if (cr.a == 0) p[i] = 0;
+          else {
+            cr.c = (cr.ht[(cr.limit - cr.b) & cr.ht_mask] >> (7 - cr.cxt)) & 1;
+            p[i] = stretch((u32)(J.T->dt2k[cr.a] * ((int)cr.c * -2 + 1)) & 32767u);
+          }
+          break;
+        case AVG:
+          p[i] = (p[cr.a1] * (int)cr.a3 + p[cr.a2] * (256 - (int)cr.a3)) >> 8;
+          break;
+        case MIX2: {
+          cr.cxt = (h[i] + (c8 & cr.a5)) & (cr.c - 1);
+          const int w = cr.a16[cr.cxt];
+          p[i] = (w * p[cr.a2] + (65536 - w) * p[cr.a3]) >> 16;
+        } break;
+        case MIX: {
+          const int m = (int)cr.a3;
+          cr.cxt = h[i] + (c8 & cr.a5);
+          cr.cxt = (cr.cxt & (cr.c - 1)) * m;
+          const int* wt = (const int*)&cr.cm[cr.cxt];
+          int s = 0;
+          for (int j = 0; j < m; ++j) s += (wt[j] >> 8) * p[cr.a2 + j];
+          p[i] = clamp2k(s >> 8);
+        } break;
+        case ISSE: {
+          if (c8 == 1 || (c8 & 0xf0) == 16) cr.c = cm_find(cr.ht, cr.ht_mask + 1, cr.a1 + 2, h[i] + 16 * c8);
+          cr.cxt = cr.ht[cr.c + (hmap4 & 15)];
+          const int* wt = (const int*)&cr.cm[cr.cxt * 2];
+          p[i] = clamp2k((wt[0] * p[cr.a2] + wt[1] * 64) >> 16);
+        } break;
+        case SSE: {
+          cr.cxt = (h[i] + c8) * 32;
+          int pq = p[cr.a2] + 992;
+          if (pq < 0) pq = 0;
+          if (pq > 1983) pq = 1983;
+          const int wt = pq & 63;
+          pq >>= 6;
+          cr.cxt += pq;
+          p[i] = stretch(((cr.cm[cr.cxt & cr.cm_mask] >> 10) * (64 - wt) + (cr.cm[(cr.cxt + 1) & cr.cm_mask] >> 10) * wt) >> 13);
+          cr.cxt += wt >> 5;
+        } break;
+        default: break;
+      }
+    }
+    return squash(p[n - 1]);
+  }
+
+  __device__ void train(Comp& cr, int y) {     // ZSFX/libzpaq.h:1151-1157; the product wraps in 32 bits
+    u32& pn = cr.cm[cr.cxt & cr.cm_mask];
+    const u32 count = pn & 0x3ff;
+    const int error = y * 32767 - (int)(pn >> 17);
+    pn += ((u32)error * (u32)J.T->dt[count] & 0xfffffc00u) + (count < cr.limit);
+  }
+
+  __device__ void update(int y) {              // update0, ZSFX/libzpaq.cpp:1946-2058
+    int* p = J.p; u32* h = J.h;
+    const u8* ns = J.T->ns;
+    const u32 n = J.n;
+    for (u32 i = 0; i < n; ++i) {
+      Comp& cr = J.comp[i];
+      switch (cr.type) {
+        case CM: train(cr, y); break;
+        case ICM: {
+          u8& bh = cr.ht[cr.c + (hmap4 & 15)];
+          bh = ns[bh * 4 + y];
+          u32& pn = cr.cm[cr.cxt & cr.cm_mask];
+          pn += (u32)((int)(y * 32767 - (int)(pn >> 8)) >> 2);
+        } break;
+        case MATCH: {
+          if ((int)cr.c != y) cr.a = 0;
+          u8& cur = cr.ht[cr.limit & cr.ht_mask];
+          cur = (u8)(cur + cur + y);
+          if (++cr.cxt == 8) {
+            cr.cxt = 0;
+            ++cr.limit;
+            cr.limit &= (1u << cr.a2) - 1;
+            if (cr.a == 0) {
+              cr.b = cr.limit - cr.cm[h[i] & cr.cm_mask];
+              if (cr.b & cr.ht_mask)
+                while (cr.a < 255 && cr.ht[(cr.limit - cr.a - 1) & cr.ht_mask] == cr.ht[(cr.limit - cr.a - cr.b - 1) & cr.ht_mask]) ++cr.a;
+            } else cr.a += cr.a < 255;
+            cr.cm[h[i] & cr.cm_mask] = cr.limit;
+          }
+        } break;
+        case MIX2: {
+          const int err = (y * 32767 - squash(p[i])) * (int)cr.a4 >> 5;
+          int w = cr.a16[cr.cxt];
+          w += (err * (p[cr.a2] - p[cr.a3]) + (1 << 12)) >> 13;
+          if (w < 0) w = 0;
+          if (w > 65535) w = 65535;
+          cr.a16[cr.cxt] = (u16)w;
+        } break;
+        case MIX: {
+          const int m = (int)cr.a3;
+          const int err = (y * 32767 - squash(p[i])) * (int)cr.a4 >> 4;
+          int* wt = (int*)&cr.cm[cr.cxt];
+          for (int j = 0; j < m; ++j) wt[j] = clamp512k(wt[j] + ((err * p[cr.a2 + j] + (1 << 12)) >> 13));
+        } break;
+        case ISSE: {
+          const int err = y * 32767 - squash(p[i]);
+          int* wt = (int*)&cr.cm[cr.cxt * 2];
+          wt[0] = clamp512k(wt[0] + ((err * p[cr.a2] + (1 << 12)) >> 13));
+          wt[1] = clamp512k(wt[1] + ((err + 16) >> 5));
+          cr.ht[cr.c + (hmap4 & 15)] = ns[cr.cxt * 4 + y];
+        } break;
+        case SSE: train(cr, y); break;
+        default: break;
+      }
+    }
+    c8 += c8 + y;
+    if (c8 >= 256) {
+      Vm& z = const_cast<Vm&>(J.vm);
+      vm_run(z, c8 - 256);
+      hmap4 = 1;
+      c8 = 1;
+      for (u32 i = 0; i < n; ++i) h[i] = z.H[i & z.hmask];
+    } else if (c8 >= 16 && c8 < 32) hmap4 = (hmap4 & 0xf) << 5 | y << 4 | 1;
+    else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + y) & 0xf);
+  }
+};
+
+__global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode) {
+  if (threadIdx.x != 0) return;
+  CmJobDev& J = jobs[blockIdx.x];
+  Pred pr(J);
+  u32 low = 1, high = 0xffffffffu, op = 0;
+  int status = ZPQ_OK;
+  if (encode) {
+    auto put = [&](u32 c) { if (op < J.out_cap) J.out[op] = (u8)c; ++op; };
+    auto enc = [&](int y, u32 p) {
+      const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
+      if (y) high = mid; else low = mid + 1;
+      while ((high ^ low) < 0x1000000u) { put(high >> 24); high = high << 8 | 255; low <<= 8; low += (low == 0); }
+    };
+    for (u32 i = 0; i < J.in_len && !J.vm.err; ++i) {
+      const u32 c = J.in[i];
+      enc(0, 0);
+      for (int b = 7; b >= 0; --b) {
+        const u32 p = (u32)pr.predict() * 2 + 1;
+        const int y = (c >> b) & 1;
+        enc(y, p);
+        pr.update(y);
+      }
+    }
+    enc(1, 0);
+    put(0); put(0); put(0); put(0);
+    if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
+  } else {
+    u32 ip = 0, curr = 0;
+    bool bad = false;
+    auto get = [&]() -> u32 { if (ip < J.in_len) return J.in[ip++]; bad = true; return 0; };
+    auto dec = [&](u32 p) -> int {               // Decoder::decode, ZSFX/libzpaq.cpp:2096-2114
+      if (curr < low || curr > high) { bad = true; return 1; }
+      const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
+      int y;
+      if (curr <= mid) { y = 1; high = mid; } else { y = 0; low = mid + 1; }
+      while ((high ^ low) < 0x1000000u) { high = high << 8 | 255; low <<= 8; low += (low == 0); curr = curr << 8 | get(); }
+      return y;
+    };
+    for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
+    while (!bad && !J.vm.err) {
+      if (dec(0)) { if (curr != 0) bad = true; break; }
+      u32 c = 1;
+      while (c < 256) {
+        const u32 p = (u32)pr.predict() * 2 + 1;
+        c += c + (u32)dec(p);
+        pr.update((int)(c & 1));
+      }
+      if (op < J.out_cap) J.out[op] = (u8)(c - 256);
+      ++op;
+    }
+    if (bad) status = ZPQ_ERR_FORMAT;
+    else if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
+  }
+  if (J.vm.err) status = ZPQ_ERR_FORMAT;
+  J.result[0] = op;
+  J.result[1] = (u32)status;
+}
+
+// Component array initialisation (Predictor::init, ZSFX/libzpaq.cpp:1757-1845), parallel over elements.
+struct InitJob { u32 kind; u32* cm; u32 count; u32 arg; const Tables* T; u16* a16; };
+__global__ __launch_bounds__(256) void cm_init_kernel(const InitJob* jobs) {
+  const InitJob J = jobs[blockIdx.y];
+  for (u32 j = blockIdx.x * 256u + threadIdx.x; j < J.count; j += gridDim.x * 256u) {
+    switch (J.kind) {
+      case CM: J.cm[j] = 0x80000000u; break;
+      case ICM: { const u8* ns = J.T->ns; J.cm[j] = (u32)(((ns[j * 4 + 3] * 2 + 1) << 22) / (ns[j * 4 + 2] + ns[j * 4 + 3] + 1)); } break;
+      case MIX2: J.a16[j] = 32768; break;
+      case MIX: J.cm[j] = 65536u / J.arg; break;
+      case ISSE: {
+        const u8* ns = J.T->ns; const u32 s = j >> 1;
+        if (j & 1) {
+          const int ci = ((ns[s * 4 + 3] * 2 + 1) << 22) / (ns[s * 4 + 2] + ns[s * 4 + 3] + 1);
+          J.cm[j] = (u32)clamp512k(J.T->stretch[ci >> 8] * 1024);
+        } else J.cm[j] = 1u << 15;
+      } break;
+      case SSE: J.cm[j] = (u32)J.T->squash[((j & 31) * 64 - 992) + 2048] << 17 | J.arg; break;
+      default: break;
+    }
+  }
+}
+
+// Generic post-processor: runs a PCOMP program once per decoded byte and once with 2^32-1 at the end
+// (PostProcessor::write state 5, ZSFX/libzpaq.cpp:2221-2224).
+__global__ __launch_bounds__(64) void pcomp_run_kernel(Vm* vms, const u8* in, u32 n, u32* result) {
+  if (threadIdx.x != 0) return;
+  Vm& z = vms[0];
+  for (u32 i = 0; i < n && !z.err; ++i) vm_run(z, in[i]);
+  if (!z.err) vm_run(z, 0xffffffffu);
+  result[0] = z.out_len;
+  result[1] = z.err ? (u32)ZPQ_ERR_FORMAT : (z.out_len > z.out_cap ? (u32)ZPQ_ERR_CAPACITY : 0u);
+}
+
+struct ParsedHeader {
+  u32 hh, hm, ph, pm, n;
+  std::vector<std::vector<u8>> comps;   // type + args per component
+  std::vector<u8> hcomp;                // program bytes (without the trailing END 0)
+};
+
+// Block header bytes starting at hsize[2] (ZPAQL::read, ZSFX/libzpaq.cpp:879-921)
+int parse_header(zpq_ctx* ctx, const u8* h, u32 len, ParsedHeader& P) {
+  if (len < 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header too short");
+  const u32 hsize = h[0] | (u32)h[1] << 8;
+  if (hsize + 2 > len) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header truncated");
+  P.hh = h[2]; P.hm = h[3]; P.ph = h[4]; P.pm = h[5]; P.n = h[6];
+  if (P.hh > 24 || P.hm > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "H/M of 2^%u/2^%u too large for this engine", P.hh, P.hm);
+  u32 p = 7;
+  for (u32 i = 0; i < P.n; ++i) {
+    if (p >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
+    const u32 t = h[p];
+    if (t < 1 || t > 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "invalid component type %u", t);
+    if (p + kCompSize[t] > hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
+    P.comps.push_back(std::vector<u8>(h + p, h + p + kCompSize[t]));
+    p += kCompSize[t];
+  }
+  if (h[p++] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing COMP END");
+  if (hsize + 2 < p + 1 || h[hsize + 1] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing HCOMP END");
+  P.hcomp.assign(h + p, h + hsize + 1);
+  return ZPQ_OK;
+}
+
+const Tables* device_tables(zpq_ctx* ctx) {
+  Tables* d = (Tables*)zpq_scratch(ctx, 9, sizeof(Tables));
+  if (!d) return nullptr;
+  // (re)upload every time the slot is fresh; cheap (86 KiB)
+  if (hipMemcpyAsync(d, &host_tables(), sizeof(Tables), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+  return d;
+}
+
+int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
+  if (njobs == 0) return ZPQ_OK;
+  hipStream_t st = ctx->stream;
+  const Tables* dT = device_tables(ctx);
+  if (!dT) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm tables");
+  // sizes
+  std::vector<ParsedHeader> ph(njobs);
+  size_t bytes = 0;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  for (size_t i = 0; i < njobs; ++i) {
+    int rc = parse_header(ctx, jobs[i].header, jobs[i].header_len, ph[i]);
+    if (rc) return rc;
+    if (ph[i].n == 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: block has no components (stored mode)", i);
+    bytes += al(ph[i].n * sizeof(Comp)) + al(256 * 4) * 3 + al((size_t)4 << ph[i].hh) + al((size_t)1 << ph[i].hm) + al(ph[i].hcomp.size() + 8);
+    for (auto& c : ph[i].comps) {
+      const u32 sb = c.size() > 1 ? c[1] : 0;
+      switch (c[0]) {
+        case CM: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "CM 2^%u too large", sb); bytes += al((size_t)4 << sb); break;
+        case ICM: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ICM 2^%u too large", sb); bytes += al(1024) + al((size_t)64 << sb); break;
+        case MATCH: if (sb > 28 || c[2] > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MATCH too large"); bytes += al((size_t)4 << sb) + al((size_t)1 << c[2]); break;
+        case MIX2: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX2 too large"); bytes += al((size_t)2 << sb); break;
+        case MIX: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX too large"); bytes += al(((size_t)4 << sb) * c[3]); break;
+        case ISSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ISSE too large"); bytes += al(2048) + al((size_t)64 << sb); break;
+        case SSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "SSE too large"); bytes += al((size_t)128 << sb); break;
+        default: break;
+      }
+    }
+  }
+  bytes += al(njobs * sizeof(CmJobDev)) + al(njobs * 8) + al(njobs * 256 * sizeof(InitJob));
+  u8* arena = (u8*)zpq_scratch(ctx, 0, bytes + 4096);
+  if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm model memory (%zu MiB)", bytes >> 20);
+  ZPQ_HIP(ctx, hipMemsetAsync(arena, 0, bytes, st));
+  u8* ap = arena;
+  auto take = [&](size_t x) { u8* r = ap; ap += al(x); return r; };
+  CmJobDev* d_jobs = (CmJobDev*)take(njobs * sizeof(CmJobDev));
+  u32* d_res = (u32*)take(njobs * 8);
+  InitJob* d_init = (InitJob*)take(njobs * 256 * sizeof(InitJob));
+  std::vector<CmJobDev> hj(njobs);
+  std::vector<InitJob> inits;
+  std::vector<std::pair<void*, std::vector<u8>>> uploads;   // small host->device blobs
+  std::vector<std::vector<Comp>> hcomp(njobs);
+  std::vector<std::vector<int>> hp(njobs);
+  for (size_t i = 0; i < njobs; ++i) {
+    ParsedHeader& P = ph[i];
+    CmJobDev& J = hj[i];
+    memset(&J, 0, sizeof J);
+    J.n = P.n; J.T = dT;
+    J.comp = (Comp*)take(P.n * sizeof(Comp));
+    J.p = (int*)take(256 * 4); J.h = (u32*)take(256 * 4);
+    J.vm.R = (u32*)take(256 * 4);
+    J.vm.H = (u32*)take((size_t)4 << P.hh); J.vm.hmask = (1u << P.hh) - 1;
+    J.vm.M = (u8*)take((size_t)1 << P.hm); J.vm.mmask = (1u << P.hm) - 1;
+    u8* prog = take(P.hcomp.size() + 8);
+    J.vm.prog = prog; J.vm.plen = (u32)P.hcomp.size();
+    uploads.push_back({prog, P.hcomp});
+    hcomp[i].resize(P.n);
+    hp[i].assign(256, 0);
+    for (u32 k = 0; k < P.n; ++k) {
+      const std::vector<u8>& c = P.comps[k];
+      Comp& C = hcomp[i][k];
+      memset(&C, 0, sizeof C);
+      C.type = c[0];
+      C.a1 = c.size() > 1 ? c[1] : 0; C.a2 = c.size() > 2 ? c[2] : 0; C.a3 = c.size() > 3 ? c[3] : 0;
+      C.a4 = c.size() > 4 ? c[4] : 0; C.a5 = c.size() > 5 ? c[5] : 0;
+      switch (c[0]) {
+        case CONS: hp[i][k] = ((int)c[1] - 128) * 4; break;
+        case CM:
+          C.cm = (u32*)take((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1; C.limit = c[2] * 4;
+          inits.push_back({CM, C.cm, 1u << c[1], 0, dT, nullptr});
+          break;
+        case ICM:
+          C.limit = 1023;
+          C.cm = (u32*)take(1024); C.cm_mask = 255;
+          C.ht = take((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
+          inits.push_back({ICM, C.cm, 256, 0, dT, nullptr});
+          break;
+        case MATCH:
+          C.cm = (u32*)take((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1;
+          C.ht = take((size_t)1 << c[2]); C.ht_mask = (1u << c[2]) - 1;
+          uploads.push_back({C.ht, std::vector<u8>(1, 1)});     // cr.ht(0)=1
+          break;
+        case AVG:
+          if (c[1] >= k || c[2] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "AVG input out of range");
+          break;
+        case MIX2:
+          if (c[2] >= k || c[3] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX2 input out of range");
+          C.c = 1u << c[1];
+          C.a16 = (u16*)take((size_t)2 << c[1]); C.a16_mask = (1u << c[1]) - 1;
+          inits.push_back({MIX2, nullptr, 1u << c[1], 0, dT, C.a16});
+          break;
+        case MIX:
+          if (c[2] >= k || c[3] < 1 || c[3] > k - c[2]) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX inputs out of range");
+          C.c = 1u << c[1];
+          C.cm = (u32*)take(((size_t)4 << c[1]) * c[3]); C.cm_mask = 0xffffffffu;
+          inits.push_back({MIX, C.cm, (1u << c[1]) * c[3], c[3], dT, nullptr});
+          break;
+        case ISSE:
+          if (c[2] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "ISSE input out of range");
+          C.ht = take((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
+          C.cm = (u32*)take(2048); C.cm_mask = 511;
+          inits.push_back({ISSE, C.cm, 512, 0, dT, nullptr});
+          break;
+        case SSE:
+          if (c[2] >= k || c[3] > c[4] * 4) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "SSE arguments out of range");
+          C.cm = (u32*)take((size_t)128 << c[1]); C.cm_mask = (32u << c[1]) - 1; C.limit = c[4] * 4;
+          inits.push_back({SSE, C.cm, 32u << c[1], c[3], dT, nullptr});
+          break;
+        default: break;
+      }
+    }
+    J.in = jobs[i].d_in; J.in_len = jobs[i].n;
+    J.out = jobs[i].d_out; J.out_cap = jobs[i].out_cap;
+    J.result = d_res + 2 * i;
+  }
+  for (size_t i = 0; i < njobs; ++i) {
+    ZPQ_HIP(ctx, hipMemcpyAsync(hj[i].comp, hcomp[i].data(), hcomp[i].size() * sizeof(Comp), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipMemcpyAsync(hj[i].p, hp[i].data(), 256 * 4, hipMemcpyHostToDevice, st));
+  }
+  for (auto& u : uploads)
+    if (!u.second.empty()) ZPQ_HIP(ctx, hipMemcpyAsync(u.first, u.second.data(), u.second.size(), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), njobs * sizeof(CmJobDev), hipMemcpyHostToDevice, st));
+  if (!inits.empty()) {
+    if (inits.size() > njobs * 256) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many components");
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_init, inits.data(), inits.size() * sizeof(InitJob), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    ZPQ_LAUNCH(ctx, "cm_init_kernel", st, cm_init_kernel, dim3(64, (unsigned)inits.size()), dim3(256), d_init);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
+  ZPQ_HIP(ctx, hipGetLastError());
+  std::vector<u32> res(njobs * 2);
+  ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  int first = ZPQ_OK;
+  for (size_t i = 0; i < njobs; ++i) {
+    jobs[i].out_len = res[2 * i];
+    jobs[i].status = (int32_t)res[2 * i + 1];
+    if (jobs[i].status && !first) first = jobs[i].status;
+  }
+  return first;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zpq_cm_tables(uint16_t* squash, int16_t* stretch, int32_t* dt, int32_t* dt2k, uint8_t* ns) {
+  const Tables& T = host_tables();
+  memcpy(squash, T.squash, sizeof T.squash);
+  memcpy(stretch, T.stretch, sizeof T.stretch);
+  memcpy(dt, T.dt, sizeof T.dt);
+  memcpy(dt2k, T.dt2k, sizeof T.dt2k);
+  memcpy(ns, T.ns, sizeof T.ns);
+  return ZPQ_OK;
+}
+
+int zpq_cm_encode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs) { return run_cm(ctx, jobs, njobs, 1); }
+int zpq_cm_decode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs) { return run_cm(ctx, jobs, njobs, 0); }
+
+int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm, const uint8_t* d_in,
+                      uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len) {
+  if (ph > 24 || pm > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "PCOMP memory 2^%u/2^%u too large", ph, pm);
+  hipStream_t st = ctx->stream;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t bytes = al(sizeof(Vm)) + al(8) + al(1024) + al((size_t)4 << ph) + al((size_t)1 << pm) + al(psize + 8);
+  u8* arena = (u8*)zpq_scratch(ctx, 0, bytes + 1024);
+  if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "pcomp memory");
+  ZPQ_HIP(ctx, hipMemsetAsync(arena, 0, bytes, st));
+  u8* ap = arena;
+  auto take = [&](size_t x) { u8* r = ap; ap += al(x); return r; };
+  Vm* d_vm = (Vm*)take(sizeof(Vm));
+  u32* d_res = (u32*)take(8);
+  Vm v;
+  memset(&v, 0, sizeof v);
+  v.R = (u32*)take(1024);
+  v.H = (u32*)take((size_t)4 << ph); v.hmask = (1u << ph) - 1;
+  v.M = take((size_t)1 << pm); v.mmask = (1u << pm) - 1;
+  u8* prog = take(psize + 8);
+  v.prog = prog; v.plen = psize;
+  v.out = d_out; v.out_cap = out_cap;
+  ZPQ_HIP(ctx, hipMemcpyAsync(prog, pcomp, psize, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_vm, &v, sizeof v, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  ZPQ_LAUNCH(ctx, "pcomp_run_kernel", st, pcomp_run_kernel, dim3(1), dim3(64), d_vm, d_in, n, d_res);
+  ZPQ_HIP(ctx, hipGetLastError());
+  u32 res[2];
+  ZPQ_HIP(ctx, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  *out_len = res[0];
+  if (res[1]) return zpq_fail(ctx, (int)res[1], "PCOMP run failed");
+  return ZPQ_OK;
+}
+
+}  // extern "C"

@@ -41,6 +41,11 @@ class UnblockJob(C.Structure):
                 ("out_len", C.c_uint32), ("consumed", C.c_uint32), ("status", C.c_int32), ("sha1", C.c_uint8 * 20)]
 
 
+class CmJob(C.Structure):
+    _fields_ = [("header", C.c_char_p), ("header_len", C.c_uint32), ("d_in", C.c_void_p), ("n", C.c_uint32),
+                ("d_out", C.c_void_p), ("out_cap", C.c_uint32), ("out_len", C.c_uint32), ("status", C.c_int32)]
+
+
 _lib = None
 
 
@@ -85,6 +90,11 @@ def load():
     L.zpq_gather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.zpq_profile_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.zpq_cm_encode_dev.argtypes = [C.c_void_p, C.POINTER(CmJob), C.c_size_t]
+    L.zpq_cm_decode_dev.argtypes = [C.c_void_p, C.POINTER(CmJob), C.c_size_t]
+    L.zpq_cm_tables.argtypes = [C.c_void_p] * 5
+    L.zpq_pcomp_run_dev.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_uint32, C.POINTER(C.c_uint32)]
     L.zpq_lz77_encode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77Job), C.c_size_t]
     L.zpq_lz77_decode_dev.argtypes = [C.c_void_p, C.POINTER(Lz77DecJob), C.c_size_t]
     L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
@@ -282,6 +292,37 @@ class Engine:
             for b in ins + outs:
                 b.free()
         return res
+
+    # ---- context mixing ---------------------------------------------------------------------------
+    def cm_code(self, headers, inputs, out_caps, encode):
+        """Host convenience: arithmetic-code (encode=True) or decode each input under its block header."""
+        n = len(inputs)
+        jobs = (CmJob * max(1, n))()
+        ins, outs = [], []
+        for i, b in enumerate(inputs):
+            d_in = self.upload(b); d_out = self.alloc(out_caps[i])
+            ins.append(d_in); outs.append(d_out)
+            jobs[i].header, jobs[i].header_len = bytes(headers[i]), len(headers[i])
+            jobs[i].d_in, jobs[i].n, jobs[i].d_out, jobs[i].out_cap = d_in.ptr, len(b), d_out.ptr, out_caps[i]
+        try:
+            fn = self.L.zpq_cm_encode_dev if encode else self.L.zpq_cm_decode_dev
+            rc = fn(self.ctx, jobs, n)
+            if rc != 0 and all(jobs[i].status == 0 for i in range(n)):
+                self._ck(rc)
+            res = [(jobs[i].status, outs[i].download(min(jobs[i].out_len, out_caps[i]))) for i in range(n)]
+        finally:
+            for b in ins + outs:
+                b.free()
+        return res
+
+    def pcomp_run(self, pcomp, ph, pm, data, out_cap):
+        d_in = self.upload(data); d_out = self.alloc(out_cap)
+        n = C.c_uint32(0)
+        try:
+            self._ck(self.L.zpq_pcomp_run_dev(self.ctx, bytes(pcomp), len(pcomp), ph, pm, d_in.ptr, len(data), d_out.ptr, out_cap, C.byref(n)))
+            return d_out.download(n.value)
+        finally:
+            d_in.free(); d_out.free()
 
     # ---- compressBlock / Decompresser -------------------------------------------------------------
     def block_bound(self, n, filename=None, comment=None):
