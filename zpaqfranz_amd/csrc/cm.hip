@@ -394,11 +394,10 @@ __global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode)
         c += c + (u32)dec(p);
         pr.update((int)(c & 1));
       }
-      if (op < J.out_cap) J.out[op] = (u8)(c - 256);
-      ++op;
+      if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
+      J.out[op++] = (u8)(c - 256);
     }
     if (bad) status = ZPQ_ERR_FORMAT;
-    else if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
   }
   if (J.vm.err) status = ZPQ_ERR_FORMAT;
   J.result[0] = op;
