@@ -351,3 +351,36 @@ def test_generic_pcomp_vm_runs_the_lz77_program(eng):
     stream = orc.lz77_encode(plain, [0, 1, 5, 0, 3, 20])
     assert eng.pcomp_run(pcomp, 0, 20, stream, len(plain) + 64) == plain
     assert orc.ref_postprocess(b"\x01\x2e\x01" + pcomp + stream, 0, 20, len(plain) + 64) == plain
+
+
+def _frame(header, body, level, plain, fn=b"f", comment=b"c"):
+    """Frames one ZPAQ block by hand (tag, zPQ, level, 1, header, segment, body, SHA-1 trailer, 255)."""
+    tag = bytes([0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3])
+    return tag + b"zPQ" + bytes([level, 1]) + header + b"\x01" + fn + b"\0" + comment + b"\0\0" + body + b"\xfd" + orc.sha1(plain) + b"\xff"
+
+
+@needs_ref
+def test_decompress_generic_blocks(eng):
+    """Decompresser for ANY single-segment block: context-model coded data (mid config) with and without a
+    post-processor, and a stored block whose PCOMP is not the known LZ77 program (generic ZPAQL VM)."""
+    plain = datagen.text_like(7000, 21)
+    # 1. modelled, PASS
+    hdr, _ = orc.ref_compile(cmconfigs.MID, [0] * 9)
+    b1 = _frame(hdr, orc.ref_cm_encode(hdr, b"\0" + plain), 1, plain)
+    # 2. modelled + PCOMP that undoes "every byte + 7"
+    cfg = cmconfigs.ORDER1_CM.replace("end\n", "pcomp add7 ;\n  a> 255 if halt endif a-= 7 out halt\nend\n")
+    hdr2, pc = orc.ref_compile(cfg, [0] * 9)
+    assert len(pc) > 2
+    enc_in = bytes([1]) + pc + bytes((c + 7) & 255 for c in plain)       # pc already carries its 2-byte length
+    b2 = _frame(hdr2, orc.ref_cm_encode(hdr2, enc_in), 1, plain)
+    # 3. stored (n = 0) + the same unknown PCOMP
+    hdr3, pc3 = orc.ref_compile("comp 0 0 0 0 0\nhcomp\n halt\npcomp add7 ;\n  a> 255 if halt endif a-= 7 out halt\nend\n", [0] * 9)
+    payload = bytes([1]) + pc3 + bytes((c + 7) & 255 for c in plain)
+    b3 = _frame(hdr3, struct.pack(">I", len(payload)) + payload + b"\0\0\0\0", 2, plain)
+    blocks = [b1, b2, b3]
+    for b in blocks:      # the hand framing is right: the reference decoder accepts it
+        r = orc.ref_decompress_block(b, len(plain) + 16)
+        assert r["data"] == plain and r["sha1_ok"] == 1
+    res = eng.decompress_blocks(blocks, [len(plain) + 16] * 3)
+    for r, b in zip(res, blocks):
+        assert r["status"] == 0 and r["data"] == plain and r["consumed"] == len(b) and r["sha1"] == orc.sha1(plain)

@@ -294,7 +294,10 @@ extern "C" int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njo
 extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify) {
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
-  struct Parsed { u32 kind; u32 pay_off, pay_len; int has_sha; u8 sha[20]; u32 rb; std::vector<u8> payload; };
+  // kind: 0 stored+PASS, 2 stored + the known LZ77-L1 PCOMP (native decoder), 3 generic (context-model
+  // coded and/or an arbitrary PCOMP: cm.hip decoder + ZPAQL interpreter)
+  struct Parsed { u32 kind; u32 pay_off, pay_len; int has_sha; u8 sha[20]; u32 rb; std::vector<u8> payload;
+                  std::vector<u8> header; u32 ncomp, ph, pm; };
   std::vector<Parsed> ps(njobs);
   int first_err = ZPQ_OK;
   size_t in_total = 0, out_total = 0;
@@ -312,7 +315,9 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
     p += 5;
     const u32 hsize = a[p] | (u32)a[p + 1] << 8;
     if (p + 2 + hsize > n || hsize < 7) { bad(ZPQ_ERR_FORMAT, "truncated header"); continue; }
-    if (a[p + 6] != 0) { bad(ZPQ_ERR_METHOD, "block has context-model components"); continue; }
+    Parsed& P = ps[i];
+    P.ncomp = a[p + 6]; P.ph = a[p + 4]; P.pm = a[p + 5];
+    P.header.assign(a + p, a + p + 2 + hsize);
     const u32 pm = a[p + 5];
     p += 2 + hsize;
     if (p >= n || a[p] != 1) { bad(ZPQ_ERR_FORMAT, "missing segment"); continue; }
@@ -321,8 +326,16 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
     while (p < n && a[p]) ++p; ++p;
     if (p >= n || a[p] != 0) { bad(ZPQ_ERR_FORMAT, "bad segment header"); continue; }
     ++p;
-    Parsed& P = ps[i];
     bool ok = true;
+    if (P.ncomp) {
+      // arithmetic-coded data ends with four 0 bytes (Decoder::skip, ZSFX/libzpaq.cpp:2150-2160)
+      u32 q = p, curr = 0;
+      while (curr == 0 && q < n) curr = a[q++];
+      while (curr && q < n) curr = curr << 8 | a[q++];
+      if (curr) { bad(ZPQ_ERR_FORMAT, "unterminated coded data"); continue; }
+      P.payload.assign(a + p, a + q);
+      p = q;
+    } else
     for (;;) {
       if (p + 4 > n) { ok = false; break; }
       const u32 k = (u32)a[p] << 24 | (u32)a[p + 1] << 16 | (u32)a[p + 2] << 8 | a[p + 3];
@@ -338,12 +351,14 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
     else { bad(ZPQ_ERR_FORMAT, "missing segment end"); continue; }
     if (p >= n || a[p] != 255) { bad(ZPQ_ERR_METHOD, "multi-segment block"); continue; }
     j.consumed = p + 1;
-    if (P.payload[0] == 0) { P.kind = 0; P.pay_off = 1; }
+    P.rb = pm > 24 ? pm - 24 : 0;
+    if (P.ncomp) { P.kind = 3; P.pay_off = 0; }
+    else if (P.payload[0] == 0) { P.kind = 0; P.pay_off = 1; }
     else {
       if (P.payload.size() < 3) { bad(ZPQ_ERR_FORMAT, "truncated PCOMP"); continue; }
       const u32 psize = P.payload[1] | (u32)P.payload[2] << 8;
-      if (psize != 302 || P.payload.size() < 3 + 302 || memcmp(&P.payload[3], kPcompLz1, 302) != 0) { bad(ZPQ_ERR_METHOD, "unknown PCOMP program"); continue; }
-      P.kind = 2; P.pay_off = 3 + 302; P.rb = pm > 24 ? pm - 24 : 0;
+      if (psize == 302 && P.payload.size() >= 3 + 302 && memcmp(&P.payload[3], kPcompLz1, 302) == 0) { P.kind = 2; P.pay_off = 3 + 302; }
+      else { P.kind = 3; P.pay_off = 0; }
     }
     P.pay_len = (u32)P.payload.size() - P.pay_off;
     in_total += ((size_t)P.pay_len + 31) & ~(size_t)15;
@@ -362,6 +377,10 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
     if (jobs[i].status != ZPQ_OK) continue;
     Parsed& P = ps[i];
     outp[i] = d_out + oo;
+    if (P.kind == 3) {
+      oo += ((size_t)jobs[i].out_cap + 31) & ~(size_t)15;
+      continue;                       // handled below, one block at a time
+    }
     if (P.kind == 0) {
       if (P.pay_len > jobs[i].out_cap) { jobs[i].status = ZPQ_ERR_CAPACITY; if (!first_err) first_err = ZPQ_ERR_CAPACITY; continue; }
       if (P.pay_len) ZPQ_HIP(ctx, hipMemcpyAsync(outp[i], &P.payload[P.pay_off], P.pay_len, hipMemcpyHostToDevice, st));
@@ -384,6 +403,62 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
       jobs[dj_job[k]].out_len = dj[k].out_len;
       if (dj[k].status != ZPQ_OK) { jobs[dj_job[k]].status = dj[k].status; jobs[dj_job[k]].out_len = 0; if (!first_err) first_err = dj[k].status; }
     }
+  }
+  // generic blocks: [context-model decode] -> post-processor preamble -> PASS / LZ77 fast path / ZPAQL VM
+  for (size_t i = 0; i < njobs; ++i) {
+    if (jobs[i].status != ZPQ_OK || ps[i].kind != 3) continue;
+    Parsed& P = ps[i];
+    auto fail_job = [&](int code) { jobs[i].status = code; jobs[i].out_len = 0; if (!first_err) first_err = code; };
+    const size_t dcap = (size_t)jobs[i].out_cap + 65536 + 64;
+    u8* d_dec = (u8*)zpq_scratch(ctx, 10, dcap + (P.ncomp ? P.payload.size() + 128 : 0) + 256);
+    if (!d_dec) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+    u32 dec_len = 0;
+    if (P.ncomp) {
+      u8* d_coded = d_dec + ((dcap + 255) & ~(size_t)255);
+      ZPQ_HIP(ctx, hipMemcpyAsync(d_coded, P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
+      ZPQ_HIP(ctx, hipStreamSynchronize(st));
+      zpq_cm_job cj;
+      memset(&cj, 0, sizeof cj);
+      cj.header = P.header.data(); cj.header_len = (u32)P.header.size();
+      cj.d_in = d_coded; cj.n = (u32)P.payload.size(); cj.d_out = d_dec; cj.out_cap = (u32)dcap;
+      int rc = zpq_cm_decode_dev(ctx, &cj, 1);
+      if (rc || cj.status) { fail_job(cj.status ? cj.status : rc); continue; }
+      dec_len = cj.out_len;
+    } else {
+      if (P.payload.size() > dcap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
+      ZPQ_HIP(ctx, hipMemcpyAsync(d_dec, P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
+      dec_len = (u32)P.payload.size();
+    }
+    if (dec_len < 1) { fail_job(ZPQ_ERR_FORMAT); continue; }
+    u8 pre[3] = {0, 0, 0};
+    ZPQ_HIP(ctx, hipMemcpyAsync(pre, d_dec, dec_len < 3 ? dec_len : 3, hipMemcpyDeviceToHost, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    if (pre[0] == 0) {                                  // PASS
+      const u32 len = dec_len - 1;
+      if (len > jobs[i].out_cap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
+      if (len) ZPQ_HIP(ctx, hipMemcpyAsync(outp[i], d_dec + 1, len, hipMemcpyDeviceToDevice, st));
+      jobs[i].out_len = len;
+    } else if (pre[0] == 1 && dec_len >= 3) {
+      const u32 psize = pre[1] | (u32)pre[2] << 8;
+      if (psize < 1 || 3 + psize > dec_len) { fail_job(ZPQ_ERR_FORMAT); continue; }
+      std::vector<u8> pc(psize);
+      ZPQ_HIP(ctx, hipMemcpyAsync(pc.data(), d_dec + 3, psize, hipMemcpyDeviceToHost, st));
+      ZPQ_HIP(ctx, hipStreamSynchronize(st));
+      const u8* d_data = d_dec + 3 + psize; const u32 dlen = dec_len - 3 - psize;
+      if (psize == 302 && memcmp(pc.data(), kPcompLz1, 302) == 0) {
+        zpq_lz77_dec_job d;
+        memset(&d, 0, sizeof d);
+        d.d_in = d_data; d.n = dlen; d.rb = P.rb; d.d_out = outp[i]; d.out_cap = jobs[i].out_cap;
+        int rc = zpq_lz77_decode_dev(ctx, &d, 1);
+        if (rc || d.status) { fail_job(d.status ? d.status : rc); continue; }
+        jobs[i].out_len = d.out_len;
+      } else {
+        u32 olen = 0;
+        int rc = zpq_pcomp_run_dev(ctx, pc.data(), psize, P.ph, P.pm, d_data, dlen, outp[i], jobs[i].out_cap, &olen);
+        if (rc) { fail_job(rc); continue; }
+        jobs[i].out_len = olen;
+      }
+    } else { fail_job(ZPQ_ERR_FORMAT); continue; }
   }
   std::vector<u64> so; std::vector<u32> sl; std::vector<size_t> sj;
   for (size_t i = 0; i < njobs; ++i)
