@@ -384,3 +384,48 @@ def test_decompress_generic_blocks(eng):
     res = eng.decompress_blocks(blocks, [len(plain) + 16] * 3)
     for r, b in zip(res, blocks):
         assert r["status"] == 0 and r["data"] == plain and r["consumed"] == len(b) and r["sha1"] == orc.sha1(plain)
+
+
+# ---------------------------------------------------------------------------------------------------
+# row a19 / section 8f-1: whole journaling archives (add -> reference reads it; extract -> originals)
+# ---------------------------------------------------------------------------------------------------
+def _walk(arc):
+    off, out = 0, []
+    while off < len(arc):
+        b = orc.ref_decompress_block(arc[off:], 40 << 20)
+        out.append(b)
+        off += b["consumed"]
+    return out
+
+
+def test_journaling_archive_add_and_extract(eng):
+    from zpaqfranz_amd import engine as E
+    shared = datagen.mixed(3 << 20, 51)
+    files = [("docs/a.txt", datagen.text_like(900000, 52)), ("docs/b.bin", datagen.binary_like(700000, 53)), ("empty", b""),
+             ("big/one", shared + datagen.text_like(200000, 54)), ("big/two", shared), ("z/tiny", b"hello")]
+    v1, st1 = E.jidac_add(eng, b"", files, 20240101120000)
+    assert st1["new_fragments"] < st1["fragments"]          # big/two repeats big/one's fragments
+    got = E.jidac_extract(eng, v1)
+    assert got == {n: d for n, d in files}
+    # second version: one file changed, one added, everything else dedups against version 1
+    files2 = list(files)
+    files2[0] = ("docs/a.txt", files[0][1][:400000] + b"EDIT" + files[0][1][400000:])
+    files2.append(("new/file", datagen.text_like(300000, 55)))
+    v2, st2 = E.jidac_add(eng, v1, files2, 20240202120000)
+    assert st2["unique_bytes"] < 0.2 * sum(len(d) for _, d in files2)
+    arc = v1 + v2
+    assert E.jidac_extract(eng, arc) == {n: d for n, d in files2}
+    if orc.have_ref():
+        # the REAL reference decoder walks the archive: every block decodes with a matching SHA-1, block
+        # names follow jDC<date><type><num>, c blocks hold the d-block byte counts
+        blocks = _walk(arc)
+        kinds = "".join(chr(b["filename"][17]) for b in blocks)
+        assert kinds.startswith("cd") and "h" in kinds and kinds.endswith("i")
+        assert all(b["sha1_ok"] == 1 and b["comment"].endswith(b" jDC\x01") for b in blocks)
+        for k, b in enumerate(blocks):
+            if chr(b["filename"][17]) == "c":
+                csize = struct.unpack("<q", b["data"])[0]
+                dsum, j = 0, k + 1
+                while j < len(blocks) and chr(blocks[j]["filename"][17]) == "d":
+                    dsum += blocks[j]["consumed"]; j += 1
+                assert csize == dsum

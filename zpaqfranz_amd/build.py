@@ -18,7 +18,8 @@ def needs_build():
         return True
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(ROOT, "include", "zpaqhip.h"),
-            os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h")]
+            os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h"),
+            os.path.join(HERE, "shim", "jidac_gpu.cpp")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -52,10 +53,13 @@ SHIM_SO = os.path.join(HERE, "libzpaq_gpu.so")
 
 def build_shim():
     """The libzpaq-shaped C++ host layer (zpaqfranz_amd/shim), linked against libzpaqhip.so."""
-    src = os.path.join(HERE, "shim", "libzpaq_gpu.cpp")
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(HERE, "shim"), src, "-L" + HERE, "-lzpaqhip", "-Wl,-rpath,$ORIGIN", "-o", SHIM_SO]
-    subprocess.check_call(cmd)
+    # libzpaq_gpu.so leaves libzpaq::error to the application (as libzpaq does); the journaling engine has
+    # no such hook and gets its own library so that any host can dlopen it
+    for srcs, so in (([os.path.join(HERE, "shim", "libzpaq_gpu.cpp")], SHIM_SO),
+                     ([os.path.join(HERE, "shim", "jidac_gpu.cpp")], os.path.join(HERE, "libzpaq_jidac.so"))):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(HERE, "shim")] + srcs + ["-L" + HERE, "-lzpaqhip", "-Wl,-rpath,$ORIGIN", "-o", so]
+        subprocess.check_call(cmd)
     return SHIM_SO
 
 

@@ -372,3 +372,66 @@ class Engine:
         self.L.zpq_decompress_blocks(self.ctx, jobs, n, int(verify))
         return [dict(status=jobs[i].status, data=keep_out[i].raw[:jobs[i].out_len], consumed=jobs[i].consumed,
                      sha1=bytes(jobs[i].sha1)) for i in range(n)]
+
+
+# ---- journaling archives (zpaqfranz_amd/shim/jidac_gpu.cpp) ---------------------------------------------
+_shim = None
+
+
+def load_shim():
+    global _shim
+    if _shim is None:
+        load()
+        p = os.path.join(_HERE, "libzpaq_jidac.so")
+        if not os.path.exists(p):
+            raise ImportError("libzpaq_jidac.so is missing: run `python -m zpaqfranz_amd.build`")
+        S = C.CDLL(p)
+        S.zpqj_free.argtypes = [C.c_void_p]
+        S.zpqj_free.restype = None
+        S.zpqj_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                               C.c_int64, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        S.zpqj_extract.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        _shim = S
+    return _shim
+
+
+def jidac_add(eng, archive, files, version_date, method="14", dates=None):
+    """files: list of (name, bytes).  Returns (bytes to append to the archive, stats dict)."""
+    S = load_shim()
+    n = len(files)
+    names = (C.c_char_p * max(1, n))(*[f[0].encode() for f in files])
+    keep = [C.create_string_buffer(bytes(f[1]), max(1, len(f[1]))) for f in files]
+    datas = (C.c_void_p * max(1, n))(*[C.cast(k, C.c_void_p).value for k in keep])
+    sizes = (C.c_uint64 * max(1, n))(*[len(f[1]) for f in files])
+    dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
+    out, out_len = C.c_void_p(), C.c_size_t(0)
+    stats = (C.c_uint64 * 6)()
+    rc = S.zpqj_add(eng.ctx, bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
+                    version_date, method.encode(), C.byref(out), C.byref(out_len), stats)
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    data = C.string_at(out.value, out_len.value)
+    S.zpqj_free(out)
+    keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
+    return data, dict(zip(keys, [int(x) for x in stats]))
+
+
+def jidac_extract(eng, archive):
+    """Returns {name: bytes} of the latest version of every file."""
+    S = load_shim()
+    data, sizes, names, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    rc = S.zpqj_extract(eng.ctx, bytes(archive), len(archive), C.byref(data), C.byref(sizes), C.byref(names), C.byref(n))
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    sz = list((C.c_uint64 * n.value).from_address(sizes.value)) if n.value else []
+    blob = C.string_at(data.value, sum(sz))
+    out, off, p = {}, 0, names.value
+    for k in range(n.value):
+        nm = C.string_at(p)
+        p += len(nm) + 1
+        out[nm.decode()] = blob[off:off + sz[k]]
+        off += sz[k]
+    for q in (data, sizes, names):
+        S.zpqj_free(q)
+    return out

@@ -1,0 +1,399 @@
+// jidac_gpu.cpp -- the journaling archive engine (zpaqfranz `a` / `x` for the -m0/-m1 family) on top of the
+// C ABI: SURVEY.md row a19 and section 8f-1.  Host C++ like the reference's Jidac; every byte-level operation
+// (fragmenting, SHA-1, dedup, LZ77, framing, decoding, verification) is one of the zpq_* GPU calls.
+//
+// Format (reference reader: Jidac::read_archive, ZSFX/zsfx.cpp:1283-1627):
+//   every block is a ZPAQ block named jDC<yyyymmddhhmmss><c|d|h|i><10 digits> with comment "<usize> jDC\x01"
+//   c: csize[8]            total size of the d blocks that follow (ZSFX/zsfx.cpp:1432-1461); method "0"
+//   d: fragment bytes, then usize[4] per fragment, 0[4], count[4] (:1468-1500 reads it back); method as given
+//   h: bsize[4] + {sha1[20], usize[4]} per fragment of one d block, num = first fragment id (:1463-1500); "0"
+//   i: {date[8], name, 0, na[4], attr[na], ni[4], ptr[ni][4]}... (:1506-1541); method "1"
+// The add-side rules that live only in the missing zpaqfranz.cpp (block cut, R/t hints, attr extension,
+// i-block flush threshold) follow zpaq 7.15 as far as recalled: "parity unpinned" (DESIGN.md section 2).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "zpaqhip.h"
+
+namespace {
+
+typedef std::vector<uint8_t> Bytes;
+
+const uint8_t kTag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
+const uint32_t kBlockLimit = (1u << 24) - 4096;
+
+void put32(Bytes& b, uint32_t x) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(x >> (8 * i))); }
+void put64(Bytes& b, uint64_t x) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(x >> (8 * i))); }
+uint32_t get32(const uint8_t* p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+uint64_t get64(const uint8_t* p) { return get32(p) | (uint64_t)get32(p + 4) << 32; }
+
+std::string block_name(int64_t date, char type, uint32_t num) {
+  char b[40];
+  snprintf(b, sizeof b, "jDC%014lld%c%010u", (long long)date, type, num);
+  return b;
+}
+
+struct Sha1Key {
+  uint8_t d[20];
+  bool operator==(const Sha1Key& o) const { return memcmp(d, o.d, 20) == 0; }
+};
+struct Sha1Hash { size_t operator()(const Sha1Key& k) const { size_t h; memcpy(&h, k.d, sizeof h); return h; } };
+
+int compress_host(zpq_ctx* ctx, const Bytes& in, const char* method, const std::string& name, Bytes& out) {
+  zpq_block_job j;
+  memset(&j, 0, sizeof j);
+  Bytes buf(zpq_block_bound(in.size(), name.c_str(), "jDC\x01"));
+  static const uint8_t empty[1] = {0};
+  j.in = in.empty() ? empty : in.data(); j.n = (uint32_t)in.size();
+  j.method = method; j.filename = name.c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
+  j.out = buf.data(); j.out_cap = (uint32_t)buf.size();
+  int rc = zpq_compress_blocks(ctx, &j, 1);
+  if (rc) return rc;
+  out.insert(out.end(), buf.begin(), buf.begin() + j.out_len);
+  return ZPQ_OK;
+}
+
+// ---- archive index as read back (HT / DT / Block of ZSFX/zsfx.cpp:651-698) ----------------------------------
+struct Frag { Sha1Key sha1; uint32_t usize; };
+struct DBlock { size_t offset; uint32_t csize; uint32_t first_frag; uint32_t nfrag; uint64_t usize; };
+struct FileRec { int64_t date; std::string attr; std::vector<uint32_t> ptr; };
+struct Index {
+  std::vector<Frag> ht;                 // 1-based: ht[0] unused
+  std::vector<DBlock> blocks;
+  std::map<std::string, FileRec> files; // latest version wins; date 0 = deleted
+  int versions;
+  Index() : ht(1), versions(0) {}
+};
+
+// Parses one block's framing: name, comment, payload extent; returns total block size or 0.
+struct RawBlock { std::string name, comment; size_t size; };
+bool parse_block(const uint8_t* a, size_t n, RawBlock& rb) {
+  if (n < 13 + 5 + 2 || memcmp(a, kTag, 13)) return false;
+  size_t p = 13;
+  if (a[p] != 'z' || a[p + 1] != 'P' || a[p + 2] != 'Q') return false;
+  const bool modelled = a[p + 3] == 1 && false;
+  (void)modelled;
+  p += 5;
+  const uint32_t hsize = a[p] | (uint32_t)a[p + 1] << 8;
+  const uint32_t ncomp = a[p + 6];
+  p += 2 + hsize;
+  if (p >= n || a[p] != 1) return false;
+  ++p;
+  size_t e = p; while (e < n && a[e]) ++e;
+  rb.name.assign((const char*)a + p, e - p); p = e + 1;
+  e = p; while (e < n && a[e]) ++e;
+  rb.comment.assign((const char*)a + p, e - p); p = e + 1;
+  if (p >= n || a[p] != 0) return false;
+  ++p;
+  if (ncomp) {
+    uint32_t curr = 0;
+    while (curr == 0 && p < n) curr = a[p++];
+    while (curr && p < n) curr = curr << 8 | a[p++];
+  } else {
+    for (;;) {
+      if (p + 4 > n) return false;
+      const uint32_t k = (uint32_t)a[p] << 24 | (uint32_t)a[p + 1] << 16 | (uint32_t)a[p + 2] << 8 | a[p + 3];
+      p += 4;
+      if (!k) break;
+      p += k;
+      if (p > n) return false;
+    }
+  }
+  if (p < n && a[p] == 253) p += 21; else if (p < n && a[p] == 254) ++p; else return false;
+  if (p >= n || a[p] != 255) return false;
+  rb.size = p + 1;
+  return true;
+}
+
+int decompress_host(zpq_ctx* ctx, const uint8_t* blk, size_t n, size_t usize, Bytes& out) {
+  out.resize(usize + 64);
+  zpq_unblock_job j;
+  memset(&j, 0, sizeof j);
+  j.in = blk; j.n = (uint32_t)n; j.out = out.data(); j.out_cap = (uint32_t)out.size();
+  int rc = zpq_decompress_blocks(ctx, &j, 1, 1);
+  if (rc) return rc;
+  if (j.status) return j.status;
+  out.resize(j.out_len);
+  return ZPQ_OK;
+}
+
+// read_archive (ZSFX/zsfx.cpp:1283-1627), journaling blocks only
+int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
+  size_t pos = 0, data_offset = 0;
+  while (pos < n) {
+    RawBlock rb;
+    if (!parse_block(arc + pos, n - pos, rb)) return ZPQ_ERR_FORMAT;
+    if (rb.name.size() != 28 || rb.name.compare(0, 3, "jDC") != 0 || rb.comment.size() < 4 ||
+        rb.comment.compare(rb.comment.size() - 4, 4, "jDC\x01") != 0)
+      return ZPQ_ERR_FORMAT;
+    const char type = rb.name[17];
+    const uint32_t num = (uint32_t)strtoul(rb.name.c_str() + 18, 0, 10);
+    const size_t usize = (size_t)strtoull(rb.comment.c_str(), 0, 10);
+    if (type == 'c' || type == 'h' || type == 'i') {
+      Bytes os;
+      int rc = decompress_host(ctx, arc + pos, rb.size, usize, os);
+      if (rc) return rc;
+      if (os.size() != usize) return ZPQ_ERR_FORMAT;
+      if (type == 'c') {
+        if (os.size() < 8) return ZPQ_ERR_FORMAT;
+        const int64_t jmp = (int64_t)get64(os.data());
+        if (jmp < 0) break;                       // incomplete transaction: roll back (ZSFX/zsfx.cpp:1436-1443)
+        ++ix.versions;
+        data_offset = pos + rb.size;
+      } else if (type == 'h') {
+        if (os.size() % 24 != 4) return ZPQ_ERR_FORMAT;
+        const uint32_t nf = (uint32_t)((os.size() - 4) / 24), bsize = get32(os.data());
+        DBlock b; b.offset = data_offset; b.csize = bsize; b.first_frag = num; b.nfrag = nf; b.usize = 8;
+        if (ix.ht.size() < (size_t)num + nf) ix.ht.resize((size_t)num + nf);
+        for (uint32_t i = 0; i < nf; ++i) {
+          memcpy(ix.ht[num + i].sha1.d, os.data() + 4 + 24 * i, 20);
+          ix.ht[num + i].usize = get32(os.data() + 24 + 24 * i);
+          b.usize += ix.ht[num + i].usize + 4u;
+        }
+        ix.blocks.push_back(b);
+        data_offset += bsize;
+      } else {
+        const uint8_t* s = os.data(); const uint8_t* end = s + os.size();
+        while (s + 9 <= end) {
+          FileRec fr; fr.date = (int64_t)get64(s); s += 8;
+          const uint8_t* z = (const uint8_t*)memchr(s, 0, end - s);
+          if (!z) return ZPQ_ERR_FORMAT;
+          std::string fn((const char*)s, z - s); s = z + 1;
+          if (fr.date) {
+            if (s + 4 > end) return ZPQ_ERR_FORMAT;
+            const uint32_t na = get32(s); s += 4;
+            if (s + na > end) return ZPQ_ERR_FORMAT;
+            fr.attr.assign((const char*)s, na); s += na;
+            if (s + 4 > end) return ZPQ_ERR_FORMAT;
+            const uint32_t ni = get32(s); s += 4;
+            if ((size_t)(end - s) / 4 < ni) return ZPQ_ERR_FORMAT;
+            fr.ptr.resize(ni);
+            for (uint32_t i = 0; i < ni; ++i) { fr.ptr[i] = get32(s); s += 4; }
+          }
+          ix.files[fn] = fr;
+        }
+      }
+    }
+    pos += rb.size;
+  }
+  return ZPQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void zpqj_free(void* p) { free(p); }
+
+// Adds one version holding `nfiles` files to `archive` (may be NULL/0 for a new archive) and returns
+// the NEW bytes to append (malloc'd; release with zpqj_free).  Fragments already stored by earlier
+// versions, and repeats inside this batch, become pointers (dedup).  stats[0..5] = fragments, new
+// fragments, d blocks, unique bytes, d-block bytes written, total bytes written.
+int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
+             const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
+             uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  *out = nullptr; *out_len = 0;
+  Index ix;
+  if (archive && archive_len) { int rc = read_index(ctx, archive, archive_len, ix); if (rc) return rc; }
+  std::unordered_map<Sha1Key, uint32_t, Sha1Hash> known;
+  for (size_t i = 1; i < ix.ht.size(); ++i) known.emplace(ix.ht[i].sha1, (uint32_t)i);
+  // files in name order (the fixture's i blocks are name ordered)
+  std::vector<size_t> order(nfiles);
+  for (size_t i = 0; i < nfiles; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
+  // 1. stage the batch in HBM, fragment, hash, dedup
+  std::vector<uint64_t> off(nfiles + 1, 0);
+  for (size_t k = 0; k < nfiles; ++k) off[k + 1] = off[k] + sizes[order[k]];
+  const uint64_t total = off[nfiles];
+  void* d_data = nullptr;
+  int rc = zpq_dev_alloc(ctx, total + 64, &d_data);
+  if (rc) return rc;
+  struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{ctx, {d_data}};
+  for (size_t k = 0; k < nfiles; ++k)
+    if (sizes[order[k]] && (rc = zpq_h2d(ctx, (uint8_t*)d_data + off[k], datas[order[k]], sizes[order[k]]))) return rc;
+  zpq_fragment_params fp;
+  zpq_fragment_params_default(&fp);
+  const size_t cap = std::max<size_t>(1, zpq_fragment_capacity(off.data(), nfiles, &fp));
+  void *d_foff, *d_flen, *d_ffile, *d_dig, *d_first;
+  if ((rc = zpq_dev_alloc(ctx, cap * 8, &d_foff))) return rc; dev.p.push_back(d_foff);
+  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_flen))) return rc; dev.p.push_back(d_flen);
+  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_ffile))) return rc; dev.p.push_back(d_ffile);
+  if ((rc = zpq_dev_alloc(ctx, cap * 20 + 64, &d_dig))) return rc; dev.p.push_back(d_dig);
+  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_first))) return rc; dev.p.push_back(d_first);
+  size_t nf = 0;
+  if ((rc = zpq_fragment_dev(ctx, (const uint8_t*)d_data, off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
+                             (uint32_t*)d_ffile, cap, &nf))) return rc;
+  if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)d_data, (const uint64_t*)d_foff, (const uint32_t*)d_flen, nf, (uint8_t*)d_dig))) return rc;
+  if ((rc = zpq_dedup_dev(ctx, (const uint8_t*)d_dig, nf, (uint32_t*)d_first))) return rc;
+  std::vector<uint64_t> foff(nf); std::vector<uint32_t> flen(nf), ffile(nf), first(nf); Bytes dig(nf * 20);
+  if (nf) {
+    if ((rc = zpq_d2h(ctx, foff.data(), d_foff, nf * 8)) || (rc = zpq_d2h(ctx, flen.data(), d_flen, nf * 4)) ||
+        (rc = zpq_d2h(ctx, ffile.data(), d_ffile, nf * 4)) || (rc = zpq_d2h(ctx, first.data(), d_first, nf * 4)) ||
+        (rc = zpq_d2h(ctx, dig.data(), d_dig, nf * 20))) return rc;
+  }
+  // 2. fragment ids: known from earlier versions, else new (first occurrence in this batch)
+  const uint32_t first_new_id = (uint32_t)ix.ht.size();
+  std::vector<uint32_t> id(nf, 0), newfrags;
+  for (size_t i = 0; i < nf; ++i) {
+    if (first[i] != i) { id[i] = id[first[i]]; continue; }
+    Sha1Key k; memcpy(k.d, &dig[20 * i], 20);
+    auto it = known.find(k);
+    if (it != known.end()) { id[i] = it->second; continue; }
+    id[i] = first_new_id + (uint32_t)newfrags.size();
+    newfrags.push_back((uint32_t)i);
+  }
+  // 3. pack new fragments into d blocks, gather in HBM, compress
+  std::vector<std::pair<size_t, size_t>> blocks;   // [begin, end) into newfrags
+  for (size_t b = 0; b < newfrags.size();) {
+    size_t e = b; uint64_t bytes = 8;
+    while (e < newfrags.size() && (e == b || bytes + flen[newfrags[e]] + 4 <= kBlockLimit)) { bytes += flen[newfrags[e]] + 4; ++e; }
+    blocks.push_back({b, e}); b = e;
+  }
+  Bytes dpart;                                      // the d blocks, in order
+  std::vector<uint32_t> dsize(blocks.size());
+  if (!blocks.empty()) {
+    std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(blocks.size()); std::vector<uint32_t> bn(blocks.size());
+    uint64_t pos = 0;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      boff[b] = pos; uint64_t q = pos;
+      for (size_t k = blocks[b].first; k < blocks[b].second; ++k) { const uint32_t f = newfrags[k]; so.push_back(foff[f]); sl.push_back(flen[f]); dso.push_back(q); q += flen[f]; }
+      const uint32_t cnt = (uint32_t)(blocks[b].second - blocks[b].first);
+      bn[b] = (uint32_t)(q - pos) + 4 * cnt + 8;
+      pos += (bn[b] + 127) & ~(uint64_t)63;
+    }
+    void *d_blk, *d_so, *d_sl, *d_dso;
+    if ((rc = zpq_dev_alloc(ctx, pos + 64, &d_blk))) return rc; dev.p.push_back(d_blk);
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+    if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
+        (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
+    if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blk))) return rc;
+    std::vector<zpq_block_job> jobs(blocks.size());
+    std::vector<std::string> nm(blocks.size());
+    uint64_t opos = 0; std::vector<uint64_t> ooff(blocks.size());
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      Bytes tr;
+      for (size_t k = blocks[b].first; k < blocks[b].second; ++k) put32(tr, flen[newfrags[k]]);
+      put32(tr, 0); put32(tr, (uint32_t)(blocks[b].second - blocks[b].first));
+      if ((rc = zpq_h2d(ctx, (uint8_t*)d_blk + boff[b] + bn[b] - tr.size(), tr.data(), tr.size()))) return rc;
+      nm[b] = block_name(version_date, 'd', first_new_id + (uint32_t)blocks[b].first);
+      ooff[b] = opos; opos += (zpq_block_bound(bn[b], nm[b].c_str(), "jDC\x01") + 63) & ~(size_t)63;
+    }
+    void* d_out;
+    if ((rc = zpq_dev_alloc(ctx, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      zpq_block_job& j = jobs[b];
+      memset(&j, 0, sizeof j);
+      j.in = (uint8_t*)d_blk + boff[b]; j.n = bn[b]; j.method = method; j.filename = nm[b].c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
+      j.out = (uint8_t*)d_out + ooff[b]; j.out_cap = (uint32_t)zpq_block_bound(bn[b], nm[b].c_str(), "jDC\x01");
+    }
+    if ((rc = zpq_compress_blocks_dev(ctx, jobs.data(), jobs.size()))) return rc;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const size_t at = dpart.size();
+      dpart.resize(at + jobs[b].out_len);
+      if ((rc = zpq_d2h(ctx, dpart.data() + at, jobs[b].out, jobs[b].out_len))) return rc;
+      dsize[b] = jobs[b].out_len;
+    }
+  }
+  // 4. c block, d blocks, h blocks, i blocks
+  Bytes outb, tmp;
+  put64(tmp, dpart.size());
+  if ((rc = compress_host(ctx, tmp, "0", block_name(version_date, 'c', first_new_id), outb))) return rc;
+  outb.insert(outb.end(), dpart.begin(), dpart.end());
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    tmp.clear();
+    put32(tmp, dsize[b]);
+    for (size_t k = blocks[b].first; k < blocks[b].second; ++k) { const uint32_t f = newfrags[k]; tmp.insert(tmp.end(), &dig[20 * f], &dig[20 * f] + 20); put32(tmp, flen[f]); }
+    if ((rc = compress_host(ctx, tmp, "0", block_name(version_date, 'h', first_new_id + (uint32_t)blocks[b].first), outb))) return rc;
+  }
+  tmp.clear();
+  uint32_t inum = 1;
+  size_t fi = 0;
+  for (size_t k = 0; k < nfiles; ++k) {
+    put64(tmp, (uint64_t)dates[order[k]]);
+    const char* nmz = names[order[k]];
+    tmp.insert(tmp.end(), nmz, nmz + strlen(nmz) + 1);
+    put32(tmp, 3); tmp.push_back('u'); tmp.push_back(0xa4); tmp.push_back(0x81);     // unix mode 0100644
+    std::vector<uint32_t> ptr;
+    while (fi < nf && ffile[fi] == k) ptr.push_back(id[fi++]);
+    put32(tmp, (uint32_t)ptr.size());
+    for (uint32_t q : ptr) put32(tmp, q);
+    if (tmp.size() > 16000 || k + 1 == nfiles) {       // zpaq flushes the index every ~16 KB
+      if ((rc = compress_host(ctx, tmp, "1", block_name(version_date, 'i', inum++), outb))) return rc;
+      tmp.clear();
+    }
+  }
+  *out = (uint8_t*)malloc(outb.size() ? outb.size() : 1);
+  if (!*out) return ZPQ_ERR_NOMEM;
+  memcpy(*out, outb.data(), outb.size());
+  *out_len = outb.size();
+  if (stats) {
+    uint64_t ub = 0; for (uint32_t f : newfrags) ub += flen[f];
+    stats[0] = nf; stats[1] = newfrags.size(); stats[2] = blocks.size(); stats[3] = ub; stats[4] = dpart.size(); stats[5] = outb.size();
+  }
+  return ZPQ_OK;
+}
+
+// Extracts the latest version of every file: decompresses the d blocks on the GPU, verifies every
+// fragment's SHA-1 against the h table (ZSFX/zsfx.cpp:1811-1834) and returns one malloc'd blob holding
+// the files back to back in name order plus their names/sizes (names: NUL-separated, malloc'd).
+int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes, char** names,
+                 size_t* nfiles) {
+  Index ix;
+  int rc = read_index(ctx, archive, archive_len, ix);
+  if (rc) return rc;
+  // decompress every d block (blocks are independent: one batch)
+  std::vector<Bytes> bdata(ix.blocks.size());
+  for (size_t b = 0; b < ix.blocks.size(); ++b) {
+    const DBlock& B = ix.blocks[b];
+    if (B.offset + B.csize > archive_len) return ZPQ_ERR_FORMAT;
+    if ((rc = decompress_host(ctx, archive + B.offset, B.csize, (size_t)B.usize, bdata[b]))) return rc;
+    if (bdata[b].size() != B.usize) return ZPQ_ERR_FORMAT;
+  }
+  // fragment id -> (block, offset)
+  std::vector<std::pair<uint32_t, uint64_t>> where(ix.ht.size(), {0xffffffffu, 0});
+  std::vector<const uint8_t*> vbuf; std::vector<size_t> vlen; std::vector<uint32_t> vid;
+  for (size_t b = 0; b < ix.blocks.size(); ++b) {
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < ix.blocks[b].nfrag; ++i) {
+      const uint32_t f = ix.blocks[b].first_frag + i;
+      where[f] = {(uint32_t)b, o};
+      vbuf.push_back(bdata[b].data() + o); vlen.push_back(ix.ht[f].usize); vid.push_back(f);
+      o += ix.ht[f].usize;
+    }
+  }
+  Bytes dg(vbuf.size() * 20);
+  if (!vbuf.empty() && (rc = zpq_sha1_many(ctx, vbuf.data(), vlen.data(), vbuf.size(), dg.data()))) return rc;
+  for (size_t k = 0; k < vid.size(); ++k)
+    if (memcmp(&dg[20 * k], ix.ht[vid[k]].sha1.d, 20)) return ZPQ_ERR_CHECKSUM;
+  Bytes blob; std::vector<uint64_t> sz; std::string nm;
+  for (auto& kv : ix.files) {
+    if (!kv.second.date) continue;
+    uint64_t len = 0;
+    for (uint32_t q : kv.second.ptr) {
+      if (q == 0 || q >= ix.ht.size() || where[q].first == 0xffffffffu) return ZPQ_ERR_FORMAT;
+      const Bytes& src = bdata[where[q].first];
+      blob.insert(blob.end(), src.begin() + where[q].second, src.begin() + where[q].second + ix.ht[q].usize);
+      len += ix.ht[q].usize;
+    }
+    sz.push_back(len); nm += kv.first; nm.push_back('\0');
+  }
+  *data = (uint8_t*)malloc(blob.size() ? blob.size() : 1);
+  *sizes = (uint64_t*)malloc((sz.size() ? sz.size() : 1) * 8);
+  *names = (char*)malloc(nm.size() ? nm.size() : 1);
+  if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
+  memcpy(*data, blob.data(), blob.size()); memcpy(*sizes, sz.data(), sz.size() * 8); memcpy(*names, nm.data(), nm.size());
+  *nfiles = sz.size();
+  return ZPQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+/* jidac_gpu.h -- journaling archive add/extract on the MI355X engine (see jidac_gpu.cpp).  C linkage so
+ * that any host can call it; memory returned through out-pointers is malloc'd: release with zpqj_free. */
+#ifndef JIDAC_GPU_H
+#define JIDAC_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#include "zpaqhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+void zpqj_free(void* p);
+int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names,
+             const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
+             int64_t version_date, const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]);
+int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes,
+                 char** names, size_t* nfiles);
+#ifdef __cplusplus
+}
+#endif
+#endif
