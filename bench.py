@@ -34,6 +34,33 @@ from zpaqfranz_amd.sharding import BLOCK_LIMIT, plan as shard_plan
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+_CPU_COLLECTIVES = False     # set when the process group is gloo (functional test on one GPU)
+
+
+def _all_gather(tensor):
+    """all_gather of equally-shaped tensors -> list; over RCCL on device tensors, or via host for gloo."""
+    world = dist.get_world_size()
+    if _CPU_COLLECTIVES:
+        t = tensor.cpu()
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.to(tensor.device) for o in out]
+    out = [torch.empty_like(tensor) for _ in range(world)]
+    dist.all_gather(out, tensor)
+    return out
+
+
+def _exchange(sends, recvs, device):
+    """sends: {dst: uint8 tensor}, recvs: {src: nbytes} -> {src: uint8 tensor}; one batched P2P group."""
+    got = {src: torch.empty(n, dtype=torch.uint8, device="cpu" if _CPU_COLLECTIVES else device) for src, n in recvs.items()}
+    ops = [dist.P2POp(dist.isend, (t.cpu() if _CPU_COLLECTIVES else t), int(dst)) for dst, t in sorted(sends.items())]
+    ops += [dist.P2POp(dist.irecv, got[src], int(src)) for src in sorted(got)]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return {src: t.to(device) for src, t in got.items()}
+
+
 class Pipeline:
     def __init__(self, eng, device, corpus, copies, rank, world, share=None):
         from zpaqfranz_amd import engine as E
@@ -86,15 +113,11 @@ class Pipeline:
         if self.world > 1:
             # exchange: fragment tables (20-byte id + length) of every rank, order-preserving
             cnt = torch.tensor([nf], dtype=torch.int64, device=dev)
-            cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-            dist.all_gather(cnts, cnt)
-            cnts = [int(c.item()) for c in cnts]
+            cnts = [int(c.item()) for c in _all_gather(cnt)]
             mx = max(cnts)
             pad_d = torch.zeros(mx * 20, dtype=torch.uint8, device=dev); pad_d[: nf * 20] = dig
             pad_l = torch.zeros(mx, dtype=torch.int32, device=dev); pad_l[:nf] = flen
-            gd = [torch.empty_like(pad_d) for _ in range(self.world)]
-            gl = [torch.empty_like(pad_l) for _ in range(self.world)]
-            dist.all_gather(gd, pad_d); dist.all_gather(gl, pad_l)
+            gd = _all_gather(pad_d); gl = _all_gather(pad_l)
             dig = torch.cat([gd[r][: cnts[r] * 20] for r in range(self.world)] + [torch.zeros(64, dtype=torch.uint8, device=dev)])
             flen = torch.cat([gl[r][: cnts[r]] for r in range(self.world)])
             my_lo = sum(cnts[: self.rank])
@@ -168,11 +191,14 @@ class Pipeline:
             self.last_blocks = [(int(mine[k]), jobs[k].out_len) for k in range(nb)]
             # kept for --verify (outside the timed region): input and framed output of the first block
             self.verify_sample = (blocks_buf[: blk_n[0]], outs[: jobs[0].out_len], names[0])
+            q_, pieces = 0, []
+            for k in range(nb):
+                pieces.append(outs[q_:q_ + jobs[k].out_len]); q_ += ocap[k]
+            self.verify_sample_all = torch.cat(pieces)
         if self.world > 1:
             # the archive is stitched on rank 0 in block order: gather the compressed streams
             t = torch.tensor([out_bytes], dtype=torch.int64, device=dev)
-            ts = [torch.zeros_like(t) for _ in range(self.world)]
-            dist.all_gather(ts, t)
+            ts = _all_gather(t)
             mx = max(int(x.item()) for x in ts)
             buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
             if outs is not None:
@@ -180,9 +206,9 @@ class Pipeline:
                 for k in range(nb):
                     buf[q:q + jobs[k].out_len] = outs[p_out:p_out + jobs[k].out_len]
                     q += jobs[k].out_len; p_out += ocap[k]
-            gathered = [torch.empty_like(buf) for _ in range(self.world)]
-            dist.all_gather(gathered, buf)
+            gathered = _all_gather(buf)
             out_bytes = sum(int(x.item()) for x in ts)
+            self.gathered = [g[: int(x.item())] for g, x in zip(gathered, ts)]   # rank r's framed blocks, block order
             tsync()
         self.stats = dict(fragments=int(ntot), unique_fragments=int(len(uniq_idx)), blocks=int(nblk),
                           unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
@@ -192,23 +218,19 @@ class Pipeline:
         """Fragments of a block that live on another rank (only at rank seams) travel peer to peer:
         both sides derive the same ordered lists from the plan, so one send/recv per rank pair suffices."""
         dev = self.dev
-        ops, recvs = [], []
-        for dst, idx in sorted(P["send"].items()):
+        sends, recvs = {}, {}
+        for dst, idx in P["send"].items():
             loc = torch.from_numpy((idx - my_lo).astype(np.int64)).to(dev)
             offs = self.frag_off[:nf][loc].tolist()
-            parts = [self.data[o:o + int(l)] for o, l in zip(offs, lens[idx].tolist())]
-            ops.append(dist.isend(torch.cat(parts), int(dst)))
-        for src, idx in sorted(P["recv"].items()):
-            buf = torch.empty(int(lens[idx].sum()), dtype=torch.uint8, device=dev)
-            recvs.append((dist.irecv(buf, int(src)), buf, idx))
-        for r, buf, idx in recvs:
-            r.wait()
-            q = 0
+            sends[int(dst)] = torch.cat([self.data[o:o + int(l)] for o, l in zip(offs, lens[idx].tolist())])
+        for src, idx in P["recv"].items():
+            recvs[int(src)] = int(lens[idx].sum())
+        got = _exchange(sends, recvs, dev)
+        for src, idx in P["recv"].items():
+            buf, q = got[int(src)], 0
             for g, ll in zip(idx.tolist(), lens[idx].tolist()):
                 d = layout[int(g)]
                 blocks_buf[d:d + ll] = buf[q:q + ll]; q += ll
-        for o in ops:
-            o.wait()
 
 
 def cpu_baseline(corpus, copies):
@@ -235,6 +257,9 @@ def main():
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight (each on its own engine context); 1 = strictly serial")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo runs the collectives through the host: functional test only")
+    ap.add_argument("--same-device", action="store_true", help="test only: every rank uses GPU 0 (with --dist-backend gloo)")
+    ap.add_argument("--dump-archive", default=None, help="test only: rank 0 writes the stitched d blocks of the last step to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
@@ -242,12 +267,19 @@ def main():
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.same_device:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        global _CPU_COLLECTIVES
+        if a.dist_backend == "gloo":
+            _CPU_COLLECTIVES = True
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
@@ -362,6 +394,12 @@ def main():
             want, _ = orc.compress_block(bytes(bin_.cpu().numpy()), "14", nm.decode(), "jDC\x01", True)
             res["verified_block0_bit_identical"] = bool(want == bytes(bout.cpu().numpy()))
         print(json.dumps(res))
+    if a.dump_archive and rank == 0:
+        parts = pipe.gathered if world > 1 else [pipe.verify_sample_all]
+        # blocks are owned in ascending order by ascending rank: concatenating the per-rank streams IS block order
+        with open(a.dump_archive, "wb") as f:
+            for g in parts:
+                f.write(bytes(g.cpu().numpy()))
     if world > 1:
         dist.destroy_process_group()
     for e_ in engines:

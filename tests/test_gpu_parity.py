@@ -429,3 +429,47 @@ def test_journaling_archive_add_and_extract(eng):
                 while j < len(blocks) and chr(blocks[j]["filename"][17]) == "d":
                     dsum += blocks[j]["consumed"]; j += 1
                 assert csize == dsum
+
+
+# ---------------------------------------------------------------------------------------------------
+# row e: the multi-rank add path, end to end.  Two ranks (gloo collectives through the host, both on
+# GPU 0 -- RCCL itself cannot put two ranks on one device) must produce exactly the d blocks a single
+# process produces for the concatenated inputs: table all-gather, global dedup, ownership, seam exchange.
+# ---------------------------------------------------------------------------------------------------
+def test_two_rank_add_is_bit_identical_to_serial(tmp_path):
+    import subprocess, sys
+    from zpaqfranz_amd import sharding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "two_rank.bin")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--copies", "2",
+           "--scale", "0.05", "--dist-backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-verify", "--dump-archive", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = open(out, "rb").read()
+    # serial expectation with the CPU oracle
+    files = []
+    for rank in range(2):
+        corpus = datagen.silesia_like(seed=rank, scale=0.05)
+        for _ in range(2):
+            files += [b for _, b in corpus]
+    frags = []
+    for f in files:
+        off = 0
+        for ln in orc.chunk(f):
+            frags.append(f[off:off + ln]); off += ln
+    seen, uniq = {}, []
+    for fr in frags:
+        d = orc.sha1(fr)
+        if d not in seen:
+            seen[d] = len(uniq); uniq.append(fr)
+    blk, nb = sharding.pack_blocks(np.array([len(u) for u in uniq]))
+    want = b""
+    for b in range(nb):
+        idx = np.nonzero(blk == b)[0]
+        body = b"".join(uniq[i] for i in idx)
+        body += b"".join(struct.pack("<I", len(uniq[i])) for i in idx) + struct.pack("<II", 0, len(idx))
+        fb, _ = orc.compress_block(body, "14", "jDC20240101000000d%010d" % (int(idx[0]) + 1), "jDC\x01", True)
+        want += fb
+    assert len(got) == len(want)
+    assert got == want
