@@ -33,7 +33,7 @@ constexpr u32 kMaxMatch = (1u << 14) * 3;   // ZSFX/libzpaq.cpp:6258 (BUFSIZE*3)
 constexpr u32 kMaxLiteral = (1u << 14) / 4;  // :6259
 constexpr u32 kCap = 32;                     // speculative compare cap (bytes)
 constexpr u32 kNoCand = 0xffffffffu;
-constexpr u32 kSegBytes = 1u << 20;          // speculation segment
+constexpr u32 kSegBytes = 1u << 20;          // speculation segment (more segments do not help: the parse is bound by random-access throughput)
 constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB blocks at most)
 
 struct LzCfg {
@@ -52,6 +52,9 @@ struct LzSegDev {
   u32* tpos; u32* tlen; u32* toff;  // speculative tokens
   u32 tcap;
   u32* state;        // [0]=ntok [1]=end cur [2]=end lit [3]=overflow
+  u32* qpos; u32* qlen; u32* qoff;  // tokens of the seam walk INTO this segment (lz77_seam_kernel)
+  u32* seam;         // [0]=ntok [1]=sync index into the speculative list (or ~0) [2]=end cur [3]=end lit
+                     // [4]=assumed entry cur [5]=assumed entry lit [6]=overflow [7]=valid
 };
 
 // per block (also what the pack kernels read)
@@ -64,6 +67,7 @@ struct LzJobDev {
   u32 tok_cap;
   u32* result;       // [0]=ntok, [1]=out_len bytes, [2]=overflow flag
   u8* out; u32 out_cap;
+  u32* plan;         // per segment 2 x {which list (0 spec / 1 seam), from, to, dst}: token ranges to move
 };
 
 __device__ __forceinline__ int lg32(u32 x) { return x ? 32 - __builtin_clz(x) : 0; }  // lg(), :6224-6233
@@ -467,7 +471,42 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
   }
 }
 
+// ---- seams: one wave per segment boundary -----------------------------------------------------------------
+// Seam k continues the parse from where segment k-1's SPECULATION ended (true whenever segment k-1 got back
+// in step, which the stitch kernel verifies) into segment k, on the pristine table of x0, until one of its
+// matches ends where a speculative match of segment k ends.
+template <int NB>
+__global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
+  __builtin_amdgcn_s_setprio(3);
+  const u32 si = list[blockIdx.x];
+  const LzSegDev S = segs[si];
+  const u32 lane = (u32)lane_id();
+  if (S.x0 == 0) { if (lane == 0) S.seam[7] = 0; return; }          // first segment of a block: no seam
+  __shared__ unsigned long long T[256];
+  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  const LzSegDev Pv = segs[si - 1];
+  u32 cur = Pv.state[1], lit = Pv.state[2];
+  const u32 ecur = cur, elit = lit;
+  TokSink sink{S.qpos, S.qlen, S.qoff, S.tcap, 0};
+  int hit = -1;
+  if (cur == S.x0 && lit == 0) hit = -2;                           // in step from the first position
+  else if (cur < S.x1) {
+    SpecList sl{S.tpos, S.tlen, S.state[0], 0};
+    hit = lz_walk<NB>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+  }
+  if (lane == 0) {
+    S.seam[0] = sink.n < sink.cap ? sink.n : sink.cap;
+    S.seam[1] = hit == -2 ? 0u : hit >= 0 ? (u32)hit + 1u : 0xffffffffu;    // adopt speculative tokens from here
+    S.seam[2] = cur; S.seam[3] = lit; S.seam[4] = ecur; S.seam[5] = elit;
+    S.seam[6] = sink.n > sink.cap; S.seam[7] = 1;
+  }
+}
+
 // ---- true chain: one wave per block ----------------------------------------------------------------------
+// Glues [speculative tokens of segment 0] [seam 1] [speculative tokens of segment 1 from its sync index] ...
+// A seam is used only if it started from the state the true chain really is in; otherwise the segment is
+// re-walked here on work[k-1] (after the speculative pass that table holds exactly the inserts < x0).
 template <int NB>
 __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
                                                          const u32* __restrict__ list) {
@@ -479,33 +518,62 @@ __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restr
   __builtin_amdgcn_wave_barrier();
   TokSink out{J.tok_pos, J.tok_len, J.tok_off, J.tok_cap, 0};
   u32 cur = 0, lit = 0, overflow = 0;
+  // adopted token ranges are only RECORDED here; lz77_move_tokens_kernel copies them with the whole chip
+  u32 kcur = 0, slot = 0;
+  auto append = [&](u32 which, u32 from, u32 to) {
+    if (lane == 0) {
+      u32* q = J.plan + (kcur * 2 + slot) * 4;
+      q[0] = which; q[1] = from; q[2] = to > from ? to : from; q[3] = out.n;
+    }
+    ++slot;
+    if (to > from) out.n += to - from;
+  };
+  for (u32 t = lane; t < J.nseg * 8; t += 64) J.plan[t] = 0;
+  __builtin_amdgcn_wave_barrier();
   for (u32 k = 0; k < J.nseg; ++k) {
     const LzSegDev S = segs[J.seg0 + k];
     const u32 ns = S.state[0];
     overflow |= S.state[3];
-    int from = -1;   // adopt speculative tokens from this index on (-1: none)
     if (cur >= S.x1) continue;                          // a match swallowed the whole segment
-    if (cur == S.x0 && lit == 0) from = 0;               // the speculation started in the true state
-    else {
-      SpecList sl{S.tpos, S.tlen, ns, 0};
-      const int hit = lz_walk<NB>(S.c, S.pristine, S.x0, S.x1, cur, lit, out, &sl, T);
-      if (hit >= 0) from = hit + 1;
-      // clean the collision masks a mid-window return may have left behind
-      T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (from >= 0) {
-      for (u32 t = (u32)from + lane; t < ns; t += 64) {
-        const u32 o = out.n + (t - (u32)from);
-        if (o < out.cap) { out.pos[o] = S.tpos[t]; out.len[o] = S.tlen[t]; out.off[o] = S.toff[t]; }
-      }
-      out.n += ns - (u32)from;
+    kcur = k; slot = 0;
+    if (cur == S.x0 && lit == 0) {                       // the speculation started in the true state
+      append(0, 0, ns);
       cur = S.state[1]; lit = S.state[2];
+      continue;
     }
+    if (k > 0 && S.seam[7] && S.seam[4] == cur && S.seam[5] == lit) {     // the seam continued exactly this chain
+      overflow |= S.seam[6];
+      append(1, 0, S.seam[0]);
+      if (S.seam[1] != 0xffffffffu) { append(0, S.seam[1], ns); cur = S.state[1]; lit = S.state[2]; }
+      else { cur = S.seam[2]; lit = S.seam[3]; }
+      continue;
+    }
+    // exact re-walk (rare: the previous segment never got back in step)
+    SpecList sl{S.tpos, S.tlen, ns, 0};
+    u32* table = k ? segs[J.seg0 + k - 1].work : S.work;
+    const int hit = lz_walk<NB>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (hit >= 0) { append(0, (u32)hit + 1, ns); cur = S.state[1]; lit = S.state[2]; }
   }
   if (lane == 0) {
     J.result[0] = out.n < out.cap ? out.n : out.cap;
     if (out.n > out.cap || overflow) J.result[2] = 1;
+  }
+}
+
+// Moves the recorded token ranges into the block's final token list: one workgroup per (segment, range, chunk).
+__global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
+                                                              const u32* __restrict__ seg_job) {
+  const u32 si = blockIdx.y >> 1, r = blockIdx.y & 1;
+  const LzJobDev J = jobs[seg_job[si]];
+  const LzSegDev S = segs[si];
+  const u32* q = J.plan + ((si - J.seg0) * 2 + r) * 4;
+  const u32 which = q[0], from = q[1], to = q[2], dst = q[3];
+  const u32* ps = which ? S.qpos : S.tpos; const u32* ln = which ? S.qlen : S.tlen; const u32* of = which ? S.qoff : S.toff;
+  for (u32 t = from + blockIdx.x * 256u + threadIdx.x; t < to; t += gridDim.x * 256u) {
+    const u32 o = dst + (t - from);
+    if (o < J.tok_cap) { J.tok_pos[o] = ps[t]; J.tok_len[o] = ln[t]; J.tok_off[o] = of[t]; }
   }
 }
 
@@ -679,7 +747,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
     tok_words += ((size_t)z.n / 4 + 2) * 4;                 // final pos/len/off/bit
     for (u32 k = 0; k < nseg; ++k) {
       const u32 x0 = k * kSegBytes, x1 = std::min<u64>((u64)x0 + kSegBytes, z.n);
-      tok_words += ((size_t)(x1 - x0) / 4 + 2) * 3;
+      tok_words += ((size_t)(x1 - x0) / 4 + 2) * 6;          // speculative + seam token lists
     }
     max_seg = std::max(max_seg, nseg);
   }
@@ -687,14 +755,16 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
   for (size_t i = 0; i < nj; ++i) nseg_total += std::max<u32>(1, (jobs[lo + i].n + kSegBytes - 1) / kSegBytes);
   u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
   u32* d_tok = (u32*)zpq_scratch(ctx, 1, tok_words * 4 + 256);
-  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4) + nseg_total * (sizeof(LzSegDev) + 16 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
+  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4) + nseg_total * (sizeof(LzSegDev) + 48 + 36 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
   u8* d_meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
   if (!d_tab || !d_tok || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 scratch (%zu MiB of tables)", table_words >> 18);
   u8* mp = d_meta;
   LzJobDev* d_jobs = carve<LzJobDev>(mp, nj);
   LzSegDev* d_segs = carve<LzSegDev>(mp, nseg_total);
   u32* d_res = carve<u32>(mp, nj * 4);
-  u32* d_state = carve<u32>(mp, nseg_total * 4);
+  u32* d_state = carve<u32>(mp, nseg_total * 12);            // state[4] + seam[8] per segment
+  u32* d_plan = carve<u32>(mp, nseg_total * 8);
+  u32* d_segjob = carve<u32>(mp, nseg_total);
   u32* d_lists = carve<u32>(mp, (nj + nseg_total) * 4);      // per bucket width: job list, segment list
   CopyJob* d_copy = carve<CopyJob>(mp, nseg_total * 2);
   ScatterJob* d_scat = carve<ScatterJob>(mp, nseg_total);
@@ -720,6 +790,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
     J.tok_pos = d_tok + to; J.tok_len = J.tok_pos + cap; J.tok_off = J.tok_len + cap; J.tok_bit = J.tok_off + cap;
     J.tok_cap = cap - 1; to += (size_t)cap * 4;
     J.result = d_res + 4 * i; J.out = z.d_out; J.out_cap = z.out_cap;
+    J.plan = d_plan + 8 * (size_t)hs.size();
     ZPQ_HIP(ctx, hipMemsetAsync(J.out, 0, J.out_cap, st));
     // tables: work[0..nseg-1], pristine[1..nseg-1]
     u32* work0 = d_tab + tabo;
@@ -733,7 +804,8 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
       S.pristine = k ? prist0 + words * k : nullptr;
       const u32 scap = (S.x1 - S.x0) / 4 + 2;
       S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap - 1; to += (size_t)scap * 3;
-      S.state = d_state + 4 * hs.size();
+      S.qpos = d_tok + to; S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; to += (size_t)scap * 3;
+      S.state = d_state + 12 * hs.size(); S.seam = S.state + 4;
       if (k) {
         copy_step[k].push_back({k == 1 ? nullptr : prist0 + words * (k - 1), S.pristine, (u32)words});
         scat_step[k].push_back({c, (k - 1) * kSegBytes, k * kSegBytes, S.pristine});
@@ -797,14 +869,26 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
     const u32* sl = d_lists + rng[nb].soff; const u32* jl = d_lists + rng[nb].joff;
     switch (nb) {
       case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, gs, blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
       case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, gs, blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
       case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, gs, blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
       default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl);
+               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, gs, blk, d_segs, sl);
                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
     }
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  {
+    std::vector<u32> segjob(nseg_total);
+    for (size_t i = 0; i < nj; ++i) for (u32 k = 0; k < hj[i].nseg; ++k) segjob[hj[i].seg0 + k] = (u32)i;
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_segjob, segjob.data(), nseg_total * 4, hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    ZPQ_LAUNCH(ctx, "lz77_move_tokens_kernel", st, lz77_move_tokens_kernel, dim3(32, (unsigned)(nseg_total * 2)), dim3(256), d_jobs, d_segs, d_segjob);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   // 4. tokens -> bits
