@@ -252,8 +252,8 @@ def cpu_baseline(corpus, copies):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight (each on its own engine context); 1 = strictly serial")

@@ -28,13 +28,26 @@ def _cb(t):
     return orc.compress_block_view(_mem, t[0], t[1])
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but grants a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     global _mem
     path, copies = sys.argv[1], int(sys.argv[2])
     blob = bytearray(open(path, "rb").read())
     unit = len(blob)
     _mem = (C.c_ubyte * unit).from_buffer(blob)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     piece = min(8 << 20, unit)
     tasks = [((i * 7919 * 4096) % max(1, unit - piece), piece) for i in range(cores * 4)]
     ctx = mp.get_context("fork")
