@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict_
   // neighbours keep hashing (no per-extent inner loop to re-converge on).  The next 64 input bytes
   // are always in flight while the 80 rounds of the current block run (a 16 MiB block checksum is
   // ONE chain on ONE lane: without the prefetch every block pays a full HBM round trip).
-  bool have = false, marker = false, pre = false;
+  bool have = false, marker = false;
   u32 idx = 0;
   const u8* p = nullptr;
   u64 total = 0, rem = 0;
+  u32 pre = 0;                       // whole 64-byte blocks already in registers (0..2)
   Sha1State s = {0, 0, 0, 0, 0};
-  u32x4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
+  u32x4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0, m0 = n0, m1 = n0, m2 = n0, m3 = n0;
   for (;;) {
     if (!have) {
       idx = atomicAdd(counter, 1u);
@@ -92,17 +93,24 @@ __global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict_
       s = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
       marker = false;
       have = true;
-      pre = false;
+      pre = 0;
     }
     u32 w[16];
     bool last = false;
     if (rem >= 64) {
-      u32x4 v0, v1, v2, v3;
-      if (pre) { v0 = n0; v1 = n1; v2 = n2; v3 = n3; }
-      else { const u32x4_u* q = (const u32x4_u*)p; v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
+      // two blocks (one 128-byte line) ahead: n = next block, m = the one after
+      if (pre == 0) {
+        const u32x4_u* q = (const u32x4_u*)p; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; pre = 1;
+      }
+      const u32x4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
       p += 64; rem -= 64;
-      pre = rem >= 64;
-      if (pre) { const u32x4_u* q = (const u32x4_u*)p; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+      if (pre == 2) { n0 = m0; n1 = m1; n2 = m2; n3 = m3; pre = 1; } else pre = 0;
+      if (pre == 0 && rem >= 64) {
+        const u32x4_u* q = (const u32x4_u*)p; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; pre = 1;
+      }
+      if (pre == 1 && rem >= 128) {
+        const u32x4_u* q = (const u32x4_u*)(p + 64); m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; pre = 2;
+      }
       w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
       w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
       w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
