@@ -46,6 +46,21 @@ def test_sha_many_ragged(eng):
     assert eng.sha256_many(bufs[:200]) == [orc.sha256(b) for b in bufs[:200]]
 
 
+def test_sha_more_extents_than_lanes_longest_first(eng):
+    """Above ~131k extents the kernels deal extents longest-first (counting sort on the length class);
+    every digest must still land in its own slot.  Overlapping extents of one buffer, ragged lengths."""
+    import hashlib
+    rng = np.random.default_rng(77)
+    n = 150000
+    data = datagen.random_bytes(6 << 20, 78)
+    off = rng.integers(0, (6 << 20) - 70000, n)
+    ln = rng.integers(0, 200, n)
+    ln[::1000] = rng.integers(4096, 70000, len(ln[::1000]))       # a few long ones, so that the order matters
+    bufs = [data[int(o):int(o) + int(l)] for o, l in zip(off, ln)]
+    assert eng.sha1_many(bufs) == [hashlib.sha1(b).digest() for b in bufs]
+    assert eng.sha256_many(bufs) == [hashlib.sha256(b).digest() for b in bufs]
+
+
 def test_sha256_fixture_known_answers(eng, dplain):
     """AUTOTEST/README.txt:42-297: 256 files of 37 000 bytes named by their SHA-256."""
     names = []
@@ -100,6 +115,41 @@ def test_fragmenter_multi_segment_file(eng):
     """A 24 MiB file spans 24 speculative segments: the stitcher must reproduce the serial chain."""
     f = datagen.mixed(24 << 20, 11)
     assert eng.fragment_files([f]) == _oracle_frags([f])
+
+
+def test_fragmenter_lanes_pull_many_segments(eng, monkeypatch):
+    """The speculative kernel is persistent: lanes pull segments from a device counter.  With the launch
+    capped to one or two waves every lane walks several segments in turn (and their crossing
+    fragments), over several files at once."""
+    files = [datagen.mixed(40 << 20, 12), datagen.text_like((9 << 20) + 333, 13), b"", datagen.binary_like(5 << 20, 14),
+             bytes(2 << 20), datagen.random_bytes((3 << 20) + 1, 15)]
+    want = _oracle_frags(files)
+    for waves, seg in (("1", "262144"), ("2", "65536"), ("1", "86016"), ("3", "1048576")):
+        monkeypatch.setenv("ZPQ_FRAG_MAX_WAVES", waves)
+        monkeypatch.setenv("ZPQ_FRAG_SEG", seg)          # the segment size is a per-call choice; results never depend on it
+        assert eng.fragment_files(files) == want
+    monkeypatch.delenv("ZPQ_FRAG_MAX_WAVES")
+    monkeypatch.delenv("ZPQ_FRAG_SEG")
+    assert eng.fragment_files(files) == want
+
+
+def test_fragmenter_periodic_and_constant_runs(eng):
+    """Fully predictable data: the hash never forgets where its fragment began, so speculative and true
+    chains never fall in step and the exact wave evaluator does the work (its steady-state fast path
+    and the general path alternate at the edges of the runs)."""
+    rng = np.random.default_rng(31)
+    parts = []
+    for i in range(40):
+        kind = i % 5
+        n = int(rng.integers(50000, 900000))
+        if kind == 0: parts.append(bytes([int(rng.integers(0, 256))]) * n)
+        elif kind == 1: parts.append((bytes(rng.integers(0, 256, int(rng.integers(2, 40)), dtype=np.uint8)) * n)[:n])
+        elif kind == 2: parts.append(datagen.text_like(n // 8, 100 + i))
+        elif kind == 3: parts.append((b"ab" * n)[:n])
+        else: parts.append(datagen.random_bytes(n // 16, 200 + i))
+    big = b"".join(parts)
+    files = [big, bytes(7 << 20), big[12345:3000000]]
+    assert eng.fragment_files(files) == _oracle_frags(files)
 
 
 def test_fragmenter_never_synchronising_input(eng):

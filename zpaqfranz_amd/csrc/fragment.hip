@@ -6,32 +6,38 @@
 //
 // MI355X formulation -- exact, no heuristics.  The recurrence is serial per fragment and "cut k
 // decides where fragment k+1 starts" is serial per file, so the parallelism is speculative:
-//  1. fragment_spec_kernel: files are split into 1 MiB segments and EVERY LANE fragments one segment
-//     from its own start, as if a fragment began there.  Lane-serial is the instruction-efficient
-//     shape for this loop (~12 VALU per byte-step of 64 lanes): each lane owns a 256-entry o1[] table
-//     in LDS (bank = lane, conflict free) and streams its segment 16 bytes per load; the 16 LDS
-//     read/write pairs of a group are issued back to back, the multiply chain runs on registers, and
-//     only a group whose minimum hash falls under the threshold is re-walked byte by byte.
-//  2. fragment_seam_kernel: one lane per segment boundary continues from the last speculative cut of
-//     segment k across the boundary until one of its cuts coincides with a speculative cut of the
-//     next segment: from there both chains are in the same (reset) state.
-//  3. fragment_stitch_kernel: one wave per file glues the pieces: speculative cuts, seam cuts,
-//     speculative cuts ... -- every hand-over is verified (the seam must start where the previous
-//     piece ended), and anything that does not line up (never-synchronising data such as runs of
-//     zeros) is re-evaluated exactly by the wave-parallel evaluator below (64 bytes per step:
+//  1. fragment_spec_kernel: files are split into 256 KiB segments and persistent LANES pull segments
+//     from a device counter; a lane fragments its segment from the segment start, as if a fragment
+//     began there, and then walks on across the segment end until the crossing fragment is closed.
+//     Lane-serial is the instruction-efficient shape for this loop (~12 VALU per byte-step of 64
+//     lanes): each lane owns a 256-entry o1[] table in LDS (bank = lane, conflict free) and streams
+//     its segment 16 bytes per load, three 64-byte register buffers deep; the 16 LDS read/write pairs
+//     of a group are issued back to back, the multiply chain runs on registers, and only a group
+//     whose minimum hash falls under the threshold is re-walked byte by byte.
+//  2. fragment_stitch_kernel: one wave per file glues the pieces: cuts of segment k from the index
+//     where the true chain fell in step with it, its crossing cut(s), then segment k' from the index
+//     of that cut in its list ... -- a hand-over happens only at a cut BOTH chains made (same reset
+//     state from there), and anything that does not line up (never-synchronising data such as runs
+//     of zeros) is re-evaluated exactly by the wave-parallel evaluator below (64 bytes per step:
 //     in-window o1 forwarding through 64-bit LDS masks, affine-map scan for the hash).
-// Integer-only byte work; traffic = input read ~1.1x (seam re-reads); bound by VALU/LDS issue.
+// Integer-only byte work; traffic = input read ~1.25x (crossing fragments); bound by VALU/LDS issue.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "zpq_internal.h"
 
 namespace {
 
-constexpr u64 kSegBytes = 1ull << 18;   // speculation segment (independent of the fragment size limits)
+// The speculation segment (independent of the fragment size limits) is chosen per call so that the
+// resident lanes get one segment each: a lane walks ~10-40 MB/s, so a second, partly filled round of
+// segments would cost as much again as the first.
+constexpr u64 kSegMin = 1ull << 16, kSegMax = 1ull << 20, kSegGrain = 1ull << 14;
 constexpr u64 kNone = ~0ull;
 
 struct FragP {
   u32 minf, maxf, thresh;  // thresh = 2^(22-fragment) or 0 when fragment > 22
+  u32 pad;
+  u64 seg;                 // speculation segment size of this call
 };
 
 struct WaveLds {
@@ -39,95 +45,130 @@ struct WaveLds {
   u32 O[64];                  // o1[] packed 4 entries per word
 };
 
-// Streams a byte range through three 256-byte register chunks (one aligned dword per lane each),
-// prefetched two chunks ahead; get() hands lane l the byte at pos+l.
-struct ByteReader {
-  const u8* data;
-  u64 readable;  // bytes of `data` that may be touched (multiple of 4)
-  u64 cb;        // offset of chunk r0 (multiple of 4)
-  u32 r0, r1, r2;
-  __device__ __forceinline__ u32 load(u64 off) const {
-    u64 a = off + 4u * (u32)lane_id();
-    return a + 4 <= readable ? *(const u32*)(data + a) : 0u;
-  }
-  __device__ __forceinline__ void init(u64 pos) {
-    cb = pos & ~3ull;
-    r0 = load(cb); r1 = load(cb + 256); r2 = load(cb + 512);
-  }
-  __device__ __forceinline__ void advance_to(u64 pos) {
-    while (pos >= cb + 256) { r0 = r1; r1 = r2; cb += 256; r2 = load(cb + 512); }
-  }
-  __device__ __forceinline__ u32 get(u64 pos) const {  // requires cb <= pos < cb+256
-    u32 idx = (u32)(pos - cb) + (u32)lane_id();
-    u32 src = idx >> 2;
-    u32 v0 = __shfl(r0, (int)(src & 63)), v1 = __shfl(r1, (int)(src & 63));
-    u32 v = src < 64 ? v0 : v1;
-    return (v >> ((idx & 3) * 8)) & 255u;
-  }
-};
-
-__device__ __forceinline__ void reset_o1(WaveLds& L) {
-  L.O[lane_id()] = 0;
-  __builtin_amdgcn_wave_barrier();
+template <int CTRL, int ROWS>
+__device__ __forceinline__ u32 dpp_mov(u32 old, u32 src) {   // lanes without a source keep `old`
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROWS, 0xf, false);
 }
 
-// Evaluates the fragment that starts at S (fresh state) and returns the offset E of its last byte,
-// or kNone if no cut was found before `stop` (speculative callers stop at their segment end).
-__device__ u64 eval_fragment(ByteReader& rd, WaveLds& L, u64 S, u64 file_end, u64 stop, const FragP P) {
-  const int lane = lane_id();
-  volatile unsigned long long* M = L.M;
-  volatile u8* O = (volatile u8*)L.O;
-  reset_o1(L);
+// LDS is addressed through address_space(3) pointers throughout: a generic pointer would turn every
+// table access into a flat_* instruction, which also waits on the outstanding global prefetches.
+typedef __attribute__((address_space(3))) volatile u8 lds_u8;
+typedef __attribute__((address_space(3))) volatile u32 lds_u32;
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
+
+// Wave-parallel exact evaluator: the fragment that starts at S (fresh state); returns the offset E of
+// its last byte.  Used where speculation cannot help (chains that never fall in step: periodic or
+// constant data, where every byte is predicted and the hash never forgets its start).  256 bytes per
+// iteration:
+//   * predictions, 64 positions at a time (lane = position): the o1[] entry a position sees is the
+//     byte after the nearest earlier position with the same predecessor -- inside the window that is
+//     "highest lower lane with my predecessor" (one 64-bit lane mask per predecessor value, built
+//     with LDS atomics), before the window it is the table itself;
+//   * the hash: byte j is the affine map h -> m_j*h + m_j*(c_j+1); every lane composes the maps of
+//     its four consecutive bytes, an inclusive DPP scan composes across the wave, and each lane
+//     replays its four positions from its exclusive prefix to test the cut condition.
+__device__ __forceinline__ u64 eval_fragment(const u8* __restrict__ data, u64 readable, lds_u64* M, lds_u32* O32, u64 S,
+                                             u64 file_end, const FragP P) {
+  const u32 lane = (u32)lane_id();
+  lds_u8* O = (lds_u8*)O32;
+  O32[lane] = 0;                       // fresh o1[]
+  __builtin_amdgcn_wave_barrier();
+  const u64 lastb = readable ? readable - 1 : 0, lastw = readable >= 4 ? readable - 4 : 0;
+  auto ldb = [&](u64 q) -> u32 { return data[q < lastb ? q : lastb]; };
+  auto ldw = [&](u64 q) -> u32 { return *(const u32_u*)(data + (q < lastw ? q : lastw)); };
   u64 pos = S;
   u32 hin = 0, c1in = 0;
+  u32 nb0 = ldb(pos + lane), nb1 = ldb(pos + 64 + lane), nb2 = ldb(pos + 128 + lane), nb3 = ldb(pos + 192 + lane);
+  u32 nw = ldw(pos + 4 * lane);
   for (;;) {
-    if (pos >= stop) return kNone;
-    rd.advance_to(pos);
-    const u64 q = pos + (u64)lane;
-    const bool valid = q < file_end;
-    const u32 craw = rd.get(pos);  // shuffles inside: must run with the whole wave active
-    const u32 c = valid ? craw : 0u;
-    u32 p = __shfl_up(c, 1);
-    if (lane == 0) p = c1in;
-    if (valid) atomicOr((unsigned long long*)&L.M[p], 1ull << lane);
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long mask = valid ? M[p] : 0ull;
-    const unsigned long long lower = mask & ((1ull << lane) - 1ull);
-    const int k = lower ? 63 - __builtin_clzll(lower) : 0;
-    const u32 pc = __shfl(c, k);
-    const u32 pred = lower ? pc : (u32)O[p];
-    const u32 m = (valid && c == pred) ? 314159265u : 271828182u;
-    // affine map of this byte: h -> a*h + b; invalid lanes are the identity
-    u32 a = valid ? m : 1u, b = valid ? (c + 1u) * m : 0u;
+    const u32 bb[4] = {nb0, nb1, nb2, nb3};
+    const u32 w = nw;
+    nb0 = ldb(pos + 256 + lane); nb1 = ldb(pos + 320 + lane); nb2 = ldb(pos + 384 + lane); nb3 = ldb(pos + 448 + lane);
+    nw = ldw(pos + 256 + 4 * lane);
+    const u64 q0 = pos + 4ull * lane;
+    // Fast path: every byte of the tile is what the table already predicts.  Then the table does not
+    // change (each write repeats its entry), in-window forwarding cannot differ from the table, and
+    // all flags are "predicted".  This is the steady state of exactly the data that ends up here.
+    bool steady = true;
+    {
+      u32 pp = dpp_mov<0x138, 0xf>(c1in, w >> 24);           // byte before this lane's four
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      u32 alo = __shfl_up(a, d), blo = __shfl_up(b, d);
-      if (lane >= d) { b = a * blo + b; a = a * alo; }
+      for (int j = 0; j < 4; ++j) {
+        const u32 c = (w >> (8 * j)) & 255u;
+        if (q0 + j < file_end && (u32)O[pp] != c) steady = false;
+        pp = c;
+      }
     }
-    const u32 h = a * hin + b;
-    const u64 sz = q - S + 1;
-    const bool cut = valid && (sz >= P.maxf || (h < P.thresh && sz >= P.minf) || q + 1 == file_end);
-    const unsigned long long cm = __ballot(cut);
-    if (valid) M[p] = 0ull;  // leave the mask table clean for the next window
-    if (cm) {
+    unsigned long long F[4];
+    if (__all(steady)) {
+      F[0] = F[1] = F[2] = F[3] = ~0ull;
+      c1in = (u32)__builtin_amdgcn_readlane((int)(w >> 24), 63);
+    } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u64 q = pos + 64u * r + lane;
+      const bool valid = q < file_end;
+      const u32 c = valid ? bb[r] : 0u;
+      const u32 p = dpp_mov<0x138, 0xf>(c1in, c);          // wave_shr:1 -- lane 0 keeps the byte before the window
+      if (valid) __hip_atomic_fetch_or((__attribute__((address_space(3))) unsigned long long*)(M + p), 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       __builtin_amdgcn_wave_barrier();
-      u64 E = pos + (u64)__builtin_ctzll(cm);
-      return E < stop ? E : kNone;
+      const unsigned long long mask = valid ? M[p] : 0ull;
+      const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+      const int k = lower ? 63 - __builtin_clzll(lower) : 0;
+      const u32 pc = (u32)__shfl((int)c, k);
+      const u32 pred = lower ? pc : (u32)O[p];
+      F[r] = __ballot(valid && c == pred);
+      if (valid) M[p] = 0ull;                                // leave the mask table clean for the next window
+      if (valid && (mask >> lane) == 1ull) O[p] = (u8)c;    // latest occurrence of p in the window
+      __builtin_amdgcn_wave_barrier();
+      c1in = (u32)__builtin_amdgcn_readlane((int)c, 63);
     }
-    if (valid && (mask >> lane) == 1ull) O[p] = (u8)c;  // latest occurrence of p in the window
-    __builtin_amdgcn_wave_barrier();
-    hin = __shfl(h, 63);
-    c1in = __shfl(c, 63);
-    pos += 64;
+    }
+    // blocked layout: lane l owns positions pos + 4l .. pos + 4l + 3 (window l >> 4, bits 4(l & 15)...)
+    const u32 win = lane >> 4;
+    const unsigned long long Fm = win == 0 ? F[0] : win == 1 ? F[1] : win == 2 ? F[2] : F[3];
+    const u32 bits = (u32)(Fm >> ((4u * lane) & 63u)) & 15u;
+    u32 a[4], b[4];
+    u32 ca = 1u, cb = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 c = (w >> (8 * j)) & 255u;
+      const u32 m = ((bits >> j) & 1u) ? 314159265u : 271828182u;
+      if (q0 + j < file_end) { cb = m * (cb + c + 1u); ca = m * ca; }
+      a[j] = ca; b[j] = cb;
+    }
+    // inclusive scan of (ca, cb) over the wave: hi o lo = (a_hi * a_lo, a_hi * b_lo + b_hi)
+#define ZPQ_SCAN_STEP(CTRL, ROWS) { const u32 alo = dpp_mov<CTRL, ROWS>(1u, ca), blo = dpp_mov<CTRL, ROWS>(0u, cb); cb = ca * blo + cb; ca = ca * alo; }
+    ZPQ_SCAN_STEP(0x111, 0xf) ZPQ_SCAN_STEP(0x112, 0xf) ZPQ_SCAN_STEP(0x114, 0xf) ZPQ_SCAN_STEP(0x118, 0xf)   // row_shr 1,2,4,8
+    ZPQ_SCAN_STEP(0x142, 0xa) ZPQ_SCAN_STEP(0x143, 0xc)                                                        // row_bcast 15, 31
+#undef ZPQ_SCAN_STEP
+    const u32 ax = dpp_mov<0x138, 0xf>(1u, ca), bx = dpp_mov<0x138, 0xf>(0u, cb);   // exclusive prefix
+    const u32 h0 = ax * hin + bx;
+    u64 firstq = kNone;
+    u32 hlast = h0;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const u64 q = q0 + j;
+      const u32 h = a[j] * h0 + b[j];
+      if (j == 3) hlast = h;
+      const u64 sz = q - S + 1;
+      if (q < file_end && (sz >= P.maxf || (h < P.thresh && sz >= P.minf) || q + 1 == file_end)) firstq = q;
+    }
+    const unsigned long long cm = __ballot(firstq != kNone);
+    if (cm) {
+      const int l0 = __builtin_ctzll(cm);
+      const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)firstq, l0);
+      const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(firstq >> 32), l0);
+      return ((u64)hi << 32) | lo;
+    }
+    hin = (u32)__builtin_amdgcn_readlane((int)hlast, 63);
+    pos += 256;
   }
 }
-
 
 // ---- lane-serial evaluator ------------------------------------------------------------------------
 // o1[] of lane l lives at byte ((v>>2)*2 + (l>>5))*128 + (l&31)*4 + (v&3) of a 16 KiB per-wave block:
 // every lane of a 32-lane half hits its own bank whatever v is.
-typedef __attribute__((address_space(3))) volatile u8 lds_u8;     // keeps the accesses ds_* (not flat_*)
-typedef __attribute__((address_space(3))) volatile u32 lds_u32;
 struct LaneO1 {
   lds_u8* t;
   u32 lanebase;
@@ -189,35 +230,41 @@ __device__ __forceinline__ bool lane_group(const u32x4 d, u64& pos, const u64 fi
 }
 
 // A lane's input stream: the 64 bytes being walked plus the next 128 already in flight (these kernels
-// run at 2-3 waves per SIMD -- LDS bound -- so HBM latency has to be hidden by hand).  The steady-state
-// prefetch is UNCONDITIONAL (clamped address, executed by every lane every step): a load behind a branch
-// would force the compiler to drain the whole queue (s_waitcnt vmcnt(0)) before touching older data.
+// run at 2-3 waves per SIMD -- LDS bound -- so HBM latency has to be hidden by hand).  Three register
+// buffers take turns (phase PH walks buffer PH and refills it with the bytes 192 further on), so a
+// loaded value is never copied: a register copy of a buffer would make the compiler wait for the load
+// it was just issued for.  The steady-state refill is UNCONDITIONAL (clamped address, executed by
+// every lane every step): a load behind a branch would force a full drain (s_waitcnt vmcnt(0))
+// before older data could be touched.
 struct LaneStream {
-  u64 at;          // stream offset of a[0]; ~0 when nothing usable is loaded
+  u64 at;          // stream offset the buffer of the coming phase starts at; ~0 when nothing usable is loaded
   u64 last;        // highest offset a 16-byte load may start at (readable - 16)
   u32x4 a[4], b[4], c[4];
   __device__ __forceinline__ u32x4 ld(const u8* data, u64 off) const {
     return *(const u32x4_u*)(data + (off < last ? off : last));
   }
-  __device__ __forceinline__ void prime(const u8* data, u64 pos) {
-    at = pos;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a[i] = ld(data, pos + 16 * i); b[i] = ld(data, pos + 64 + 16 * i); c[i] = ld(data, pos + 128 + 16 * i); }
-  }
 };
 
 // Advances this lane's stream by 64 bytes (16 or 1 near the end of [pos, lim)).  Must be called by
-// every lane of the wave every step (finished lanes pass pos >= lim and only take part in the
-// prefetch).  on_cut(E) is called for every cut.
-template <class OnCut>
+// every lane of the wave every step, with PH cycling 0,1,2 (finished lanes pass pos >= lim and only
+// take part in the refill).  on_cut(E) is called for every cut.
+template <int PH, class OnCut>
 __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStream& ls, u64& pos, const u64 lim,
                                           const u64 file_end, const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
+  u32x4 (&cur)[4] = PH == 0 ? ls.a : PH == 1 ? ls.b : ls.c;
+  u32x4 (&nx1)[4] = PH == 0 ? ls.b : PH == 1 ? ls.c : ls.a;
+  u32x4 (&nx2)[4] = PH == 0 ? ls.c : PH == 1 ? ls.a : ls.b;
   if (pos + 64 <= lim) {
-    if (ls.at != pos) ls.prime(data, pos);            // rare: first step, or right after a cut
+    if (ls.at != pos) {                               // rare: first step, or right after a cut
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cur[i] = ls.ld(data, pos + 16 * i); nx1[i] = ls.ld(data, pos + 64 + 16 * i); nx2[i] = ls.ld(data, pos + 128 + 16 * i);
+      }
+    }
     bool cut = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      if (!cut) cut = lane_group(ls.a[g], pos, file_end, P, o, s, on_cut);
+      if (!cut) cut = lane_group(cur[g], pos, file_end, P, o, s, on_cut);
     ls.at = cut ? ~0ull : pos;
   } else {
     ls.at = ~0ull;
@@ -238,121 +285,97 @@ __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStrea
       ++pos;
     }
   }
-  // steady-state rotation: a <- b <- c <- bytes [pos+128, pos+192) (meaningless but harmless when the
-  // stream is out of step; the next call primes)
+  // refill the buffer this phase walked with bytes [pos+128, pos+192) of the advanced stream
+  // (meaningless but harmless when the stream is out of step; the next call reloads all three)
   const u64 nxt = (ls.at == pos ? pos : 0) + 128;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ls.a[i] = ls.b[i]; ls.b[i] = ls.c[i]; ls.c[i] = ls.ld(data, nxt + 16 * i); }
+  for (int i = 0; i < 4; ++i) cur[i] = ls.ld(data, nxt + 16 * i);
 }
 
-// ---- 1. speculative pass: one LANE per 1 MiB segment ----------------------------------------------
+// ---- 1. speculative pass: persistent LANES, each pulling 256 KiB segments from a device counter -------
+// A lane fragments its segment from the segment start as if a fragment began there, records the cuts
+// that fall inside the segment, and then keeps walking -- its state at the segment end is exactly what
+// the seam needs -- until the crossing fragment ends at a place where the next lane could have cut
+// too (>= min_fragment behind the boundary; at most two cuts).  Crossing fragments are ~64 KiB on
+// average but exponentially distributed, hence the dynamic hand-out: a wave never idles behind its
+// slowest lane.
+struct CrossOut { u64 x[2]; u32 n; u32 pad; };
+__device__ unsigned long long g_frag_stats[8];   // ZPQ_FRAG_STATS=1: [0] seams in step, [1] cross unusable, [2] lookups missed, [3] exact evals, [4] exact bytes
+
 __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
                                                             const u32* __restrict__ seg_file,
                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
                                                             u32 spec_cap, u32* __restrict__ spec_rel,
-                                                            u32* __restrict__ spec_cnt) {
+                                                            u32* __restrict__ spec_cnt, CrossOut* __restrict__ cross,
+                                                            unsigned long long* __restrict__ counter) {
   __shared__ u8 tab[16384];
   const u32 lane = (u32)lane_id();
-  const u64 s = (u64)blockIdx.x * 64 + lane;
   LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
   o.clear();
-  bool active = s < nseg;
-  u64 pos = 0, lim = 0, fe = 0, g = 0;
-  if (active) {
-    const u32 f = seg_file[s];
-    const u64 fs = file_off[f];
-    fe = file_off[f + 1];
-    g = fs + (s - seg_base[f]) * kSegBytes;
-    lim = g + kSegBytes < fe ? g + kSegBytes : fe;
-    pos = g;
-  }
+  bool active = false, exhausted = false;
+  u64 s = 0, pos = 0, lim = 0, fe = 0, g = 0, segend = 0, x0 = 0, x1 = 0;
+  u32 cnt = 0, nx = 0;
+  u32* out = spec_rel;
   LaneState st{0, 0, 0};
   LaneStream ls; ls.at = ~0ull; ls.last = readable >= 16 ? readable - 16 : 0;
-  u32 cnt = 0;
-  u32* out = spec_rel + s * (u64)spec_cap;
-  while (__any(active)) {      // finished lanes keep stepping (pos >= lim: prefetch only)
-    lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) { if (cnt < spec_cap) out[cnt] = (u32)(E - g); ++cnt; });
-    active = pos < lim;
+#define ZPQ_FRAG_STEP(PH)                                                                                     \
+  {                                                                                                           \
+    if (!active && !exhausted) {                                                                              \
+      s = atomicAdd(counter, 1ull);                                                                           \
+      if (s < nseg) {                                                                                         \
+        const u32 f = seg_file[s];                                                                            \
+        const u64 fs = file_off[f];                                                                           \
+        fe = file_off[f + 1];                                                                                 \
+        g = fs + (s - seg_base[f]) * P.seg;                                                                   \
+        segend = g + P.seg < fe ? g + P.seg : fe;                                                             \
+        const u64 far = segend + (u64)P.minf + (u64)P.maxf + 64; /* two crossing fragments at most */         \
+        lim = far < fe ? far : fe;                                                                            \
+        pos = g; cnt = 0; nx = 0; x0 = x1 = 0;                                                                \
+        out = spec_rel + s * (u64)spec_cap;                                                                   \
+        ls.at = ~0ull;                                                                                        \
+        active = true; /* o1[] and the hash state are clean: lanes stop on a cut */                           \
+      } else {                                                                                                \
+        exhausted = true;                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+    if (!__any(active)) break;                                                                                \
+    bool done = false;                                                                                        \
+    /* every lane steps every iteration; idle ones have pos >= lim and only take part in the refill */        \
+    lane_step<PH>(data, ls, pos, lim, fe, P, o, st, [&](u64 E) {                                              \
+      if (E < segend) {                                                                                       \
+        if (cnt < spec_cap) out[cnt] = (u32)(E - g);                                                          \
+        ++cnt;                                                                                                \
+        if (E + 1 == segend) done = true; /* cut on the boundary: the next lane starts in step */             \
+      } else {                                                                                                \
+        if (nx == 0) x0 = E; else x1 = E;                                                                     \
+        ++nx;                                                                                                 \
+        if (E + 1 >= segend + (u64)P.minf || nx == 2) done = true;                                            \
+      }                                                                                                       \
+      if (E + 1 == fe) done = true;                                                                           \
+    });                                                                                                       \
+    if (active && (done || pos >= lim)) {                                                                     \
+      spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;                                                          \
+      CrossOut co; co.x[0] = x0; co.x[1] = x1; co.n = (done && cnt <= spec_cap) ? nx : 0xffffffffu; co.pad = 0; \
+      cross[s] = co;                                                                                          \
+      active = false;                                                                                         \
+      lim = pos;                                                                                              \
+    }                                                                                                         \
   }
-  if (s < nseg) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;
+  for (;;) {
+    ZPQ_FRAG_STEP(0)
+    ZPQ_FRAG_STEP(1)
+    ZPQ_FRAG_STEP(2)
+  }
+#undef ZPQ_FRAG_STEP
 }
 
-// ---- 2. seams: one LANE per segment boundary ---------------------------------------------------------
-// seam k of a file continues from the last speculative cut of segment k until it is back in step with a
-// later segment's speculation (or has run past segment k+1 without meeting it).
-struct SeamOut { u64 start; u64 cont; u32 cnt; u32 sync_seg; u32 sync_from; u32 pad; };
-constexpr u32 kNoSync = 0xffffffffu;
-
-__global__ __launch_bounds__(64) void fragment_seam_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
-                                                            const u32* __restrict__ seg_file,
-                                                            const u64* __restrict__ seg_base, u64 nseg, FragP P,
-                                                            u32 spec_cap, const u32* __restrict__ spec_rel,
-                                                            const u32* __restrict__ spec_cnt,
-                                                            SeamOut* __restrict__ seam, u32* __restrict__ seam_rel) {
-  __shared__ u8 tab[16384];
-  const u32 lane = (u32)lane_id();
-  const u64 s = (u64)blockIdx.x * 64 + lane;      // seam after segment s (within the same file)
-  LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
-  o.clear();
-  bool active = false;
-  u64 pos = 0, lim = 0, fe = 0, fs = 0, g = 0, sb = 0;
-  u32 k = 0, nsegf = 0;
-  SeamOut so{~0ull, 0, 0, kNoSync, 0, 0};
-  if (s < nseg) {
-    const u32 f = seg_file[s];
-    fs = file_off[f]; fe = file_off[f + 1]; sb = seg_base[f];
-    k = (u32)(s - sb);
-    nsegf = (u32)((fe - fs + kSegBytes - 1) / kSegBytes);
-    g = fs + (u64)k * kSegBytes;
-    const u32 nk = spec_cnt[s];
-    if (k + 1 < nsegf && nk > 0 && nk < spec_cap) {
-      so.start = g + spec_rel[s * (u64)spec_cap + nk - 1] + 1;
-      pos = so.start;
-      lim = g + 9 * kSegBytes < fe ? g + 9 * kSegBytes : fe;     // give up 8 segments further on (fragments may span several)
-      active = true;
-      if (pos == g + kSegBytes) { so.sync_seg = k + 1; so.sync_from = 0; active = false; }   // cut on the boundary
-    }
-  }
-  LaneState st{0, 0, 0};
-  LaneStream ls; ls.at = ~0ull; ls.last = readable >= 16 ? readable - 16 : 0;
-  u32* out = seam_rel + s * (u64)spec_cap;
-  while (__any(active)) {      // finished lanes keep stepping with pos >= lim (prefetch only)
-    {
-      bool synced = false;
-      lane_step(data, ls, pos, lim, fe, P, o, st, [&](u64 E) {
-        if (so.cnt < spec_cap) out[so.cnt] = (u32)(E - g);
-        ++so.cnt;
-        if (E + 1 >= fe) { so.sync_seg = nsegf; so.sync_from = 0; synced = true; return; }   // reached EOF
-        const u32 k2 = (u32)((E - fs) / kSegBytes);
-        if ((E + 1 - fs) % kSegBytes == 0) { so.sync_seg = k2 + 1; so.sync_from = 0; synced = true; return; }
-        if (k2 > k) {                           // is E a speculative cut of its segment?
-          const u64 s2 = sb + k2;
-          const u32* rel = spec_rel + s2 * (u64)spec_cap;
-          const u32 want = (u32)(E - (fs + (u64)k2 * kSegBytes));
-          u32 lo = 0, hi = spec_cnt[s2];
-          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (rel[mid] < want) lo = mid + 1; else hi = mid; }
-          if (lo < spec_cnt[s2] && rel[lo] == want) { so.sync_seg = k2; so.sync_from = lo + 1; synced = true; }
-        }
-      });
-      if (synced) lim = pos;                    // done: no further bytes for this lane
-      active = pos < lim;
-    }
-  }
-  if (s < nseg) {
-    so.cont = pos;
-    if (so.cnt > spec_cap) { so.start = ~0ull; }      // overflow: never trusted
-    seam[s] = so;
-  }
-}
-
-// ---- 3. exact chain: one wave per file ---------------------------------------------------------------
+// ---- 2. exact chain: one wave per file ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restrict__ data, u64 readable,
                                                                const u64* __restrict__ file_off, u32 nfiles,
                                                                const u64* __restrict__ seg_base, FragP P, u32 spec_cap,
                                                                const u32* __restrict__ spec_rel,
                                                                const u32* __restrict__ spec_cnt,
-                                                               const SeamOut* __restrict__ seam,
-                                                               const u32* __restrict__ seam_rel,
+                                                               const CrossOut* __restrict__ cross,
                                                                const u64* __restrict__ cut_base,
                                                                u64* __restrict__ cuts, u32* __restrict__ cut_cnt) {
   __shared__ WaveLds lds[4];
@@ -363,42 +386,52 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
   if (f >= nfiles) return;
   const u64 fs = file_off[f], fe = file_off[f + 1];
   const u64 sb = seg_base[f];
+  const u64 kSegBytes = P.seg;
   const u32 nsegf = (u32)((fe - fs + kSegBytes - 1) / kSegBytes);
   u64* out = cuts + cut_base[f];
   u32 cnt = 0;
-  ByteReader rd{data, readable, 0, 0, 0, 0};
   u64 S = fs;                 // start of the next fragment of the true chain
   bool synced = true;         // true chain == speculation of segment k from its cut index `from`
   u32 k = 0, from = 0;
   while (S < fe) {
+    u64 E = 0;                // last cut emitted in this round
     if (synced) {
       if (k >= nsegf) break;
       const u64 sidx = sb + k;
       const u64 g = fs + (u64)k * kSegBytes;
+      const u64 segend = g + kSegBytes < fe ? g + kSegBytes : fe;
       const u32 nk = spec_cnt[sidx];
       const u32* rel = spec_rel + sidx * (u64)spec_cap;
       for (u32 j = from + lane; j < nk; j += 64) out[cnt + (j - from)] = g + rel[j];
       if (nk > from) { S = g + rel[nk - 1] + 1; cnt += nk - from; }
       if (S >= fe) break;
-      const SeamOut so = seam[sidx];
-      if (so.start == S) {                      // the seam continued exactly this chain
-        const u32* srel = seam_rel + sidx * (u64)spec_cap;
-        for (u32 j = lane; j < so.cnt; j += 64) out[cnt + j] = g + srel[j];
-        if (so.cnt) S = g + srel[so.cnt - 1] + 1;
-        cnt += so.cnt;
-        if (so.sync_seg != kNoSync) { k = so.sync_seg; from = so.sync_from; continue; }
-        // else: the seam ran through segment k+1 without meeting its speculation; go on exactly from S
+      if (S == segend) { ++k; from = 0; continue; }     // cut on the boundary
+      // The lane that produced this list was in the true state from cut `from` on (or from the segment
+      // start when from == 0), so the fragment(s) it walked across the boundary are true as well.
+      const CrossOut co = cross[sidx];
+      if (co.n == 0xffffffffu || co.n == 0 || co.n > 2) {
+        if (lane == 0) atomicAdd(&g_frag_stats[1], 1ull);
+        synced = false;       // nothing usable: go on exactly from S
+        continue;
       }
-      synced = false;
-      rd.init(S);
+      if (lane == 0) { out[cnt] = co.x[0]; if (co.n == 2) out[cnt + 1] = co.x[1]; }
+      cnt += co.n;
+      E = co.x[co.n - 1];
+      S = E + 1;
+      if (S >= fe) break;
+    } else {
+      // exact evaluation of one fragment.  (No alignment test on S here: a segment without any
+      // speculative cut hands over at its own start and must make progress.)
+      E = eval_fragment(data, readable, (lds_u64*)lds[wave].M, (lds_u32*)lds[wave].O, S, fe, P);
+      if (lane == 0) { atomicAdd(&g_frag_stats[3], 1ull); atomicAdd(&g_frag_stats[4], E + 1 - S); }
+      if (lane == 0) out[cnt] = E;
+      ++cnt;
+      S = E + 1;
+      if (S >= fe) break;
     }
-    // exact evaluation of one fragment, then look for the speculation again.  (No alignment test on
-    // S here: a segment without any speculative cut hands over at its own start and must make progress.)
-    const u64 E = eval_fragment(rd, lds[wave], S, fe, kNone, P);
-    if (lane == 0) out[cnt] = E;
-    ++cnt;
-    S = E + 1;
-    if (S >= fe) break;
+    // is the chain back in step with a speculation?  Only a cut that the speculating lane made too
+    // puts both in the same (reset) state.
+    synced = false;
     if ((S - fs) % kSegBytes == 0) { synced = true; k = (u32)((S - fs) / kSegBytes); from = 0; continue; }
     const u32 k2 = (u32)((E - fs) / kSegBytes);
     const u64 sidx2 = sb + k2;
@@ -408,7 +441,8 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
     u32 hit = 0xffffffffu;
     for (u32 j = lane; j < n2; j += 64) if (rel2[j] == want) hit = j;
     const unsigned long long hm = __ballot(hit != 0xffffffffu);
-    if (hm) { synced = true; k = k2; from = (u32)__shfl((int)hit, __builtin_ctzll(hm)) + 1; }
+    if (hm) { synced = true; k = k2; from = (u32)__shfl((int)hit, __builtin_ctzll(hm)) + 1; if (lane == 0) atomicAdd(&g_frag_stats[0], 1ull); }
+    else if (lane == 0) atomicAdd(&g_frag_stats[2], 1ull);
   }
   if (lane == 0) cut_cnt[f] = cnt;
 }
@@ -469,6 +503,19 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   P.thresh = p->fragment_log2 <= 22 ? 1u << (22 - p->fragment_log2) : 0u;
   const u64 total = file_off[nfiles];
   const u64 readable = (total + 3) & ~3ull;  // callers pad allocations by >= 16 bytes (see header)
+  // every resident lane owns 256 B of LDS: 10 waves per CU fill the 160 KiB
+  int waves_per_cu = 10;
+  if (const char* e = getenv("ZPQ_FRAG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) waves_per_cu = v; }
+  u64 cap_waves = (u64)ctx->cu_count * (u64)waves_per_cu;
+  {
+    const u64 lanes = cap_waves * 64;
+    u64 seg = (total + lanes - lanes / 32 - 1) / (lanes - lanes / 32);         // ~3% slack for the ragged file ends
+    seg = (seg + kSegGrain - 1) / kSegGrain * kSegGrain;
+    seg = std::min(std::max(seg, kSegMin), kSegMax);
+    if (const char* e = getenv("ZPQ_FRAG_SEG")) { const long long v = atoll(e); if (v >= 4096) seg = (u64)v; }   // tests
+    P.seg = seg; P.pad = 0;
+  }
+  const u64 kSegBytes = P.seg;
 
   // host-side segment and capacity tables
   std::vector<u64> seg_base(nfiles + 1), cut_base(nfiles + 1);
@@ -489,13 +536,12 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
 
   // device scratch: [file_off | seg_base | cut_base | frag_base | seg_file | spec_cnt | cut_cnt] , spec_rel, cuts
   const size_t nf1 = nfiles + 1;
-  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 256;
+  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 8 + 256;
   u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
-  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 8 + nseg * sizeof(SeamOut) + 256);
+  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4 + nseg * sizeof(CrossOut) + 256);
   u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
   if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
-  u32* d_seam_rel = d_spec_rel + nseg * (size_t)spec_cap;
-  SeamOut* d_seam = (SeamOut*)(d_seam_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
+  CrossOut* d_cross = (CrossOut*)(d_spec_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
   u64* d_file_off = (u64*)meta;
   u64* d_seg_base = d_file_off + nf1;
   u64* d_cut_base = d_seg_base + nf1;
@@ -503,23 +549,31 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   u32* d_seg_file = (u32*)(d_frag_base + nf1);
   u32* d_spec_cnt = d_seg_file + nseg;
   u32* d_cut_cnt = d_spec_cnt + nseg;
+  unsigned long long* d_counter = (unsigned long long*)(((uintptr_t)(d_cut_cnt + nfiles) + 7) & ~(uintptr_t)7);
   hipStream_t st = ctx->stream;
+  ZPQ_HIP(ctx, hipMemsetAsync(d_counter, 0, 8, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_file_off, file_off, nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_base, seg_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
 
-  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
-             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt);
-  ZPQ_HIP(ctx, hipGetLastError());
-  ZPQ_LAUNCH(ctx, "fragment_seam_kernel", st, fragment_seam_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), d_base,
-             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel);
+  u64 want_waves = (nseg + 63) / 64;
+  if (const char* e = getenv("ZPQ_FRAG_MAX_WAVES")) { const int v = atoi(e); if (v >= 1) cap_waves = std::min<u64>(cap_waves, (u64)v); }  // tests
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64), d_base,
+             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
-             readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_seam, d_seam_rel,
-             d_cut_base, d_cuts, d_cut_cnt);
+             readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_cut_base, d_cuts,
+             d_cut_cnt);
   ZPQ_HIP(ctx, hipGetLastError());
 
+  if (getenv("ZPQ_FRAG_STATS")) {
+    unsigned long long st8[8] = {0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_frag_stats), sizeof(st8));
+    fprintf(stderr, "[frag stats] nseg=%llu in_step=%llu cross_unusable=%llu lookups_missed=%llu exact_evals=%llu exact_bytes=%llu\n",
+            (unsigned long long)nseg, st8[0], st8[1], st8[2], st8[3], st8[4]);
+  }
   // per-file counts -> exclusive prefix on the host (nfiles words; the data never leaves HBM)
   std::vector<u32> cnt(nfiles);
   ZPQ_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cut_cnt, nfiles * 4, hipMemcpyDeviceToHost, st));

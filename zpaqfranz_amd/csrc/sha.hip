@@ -6,6 +6,9 @@
 // for fragment ids (ZSFX/zsfx.cpp:1463-1500, 1811-1834), segment checksums (ZSFX/libzpaq.cpp:2338-2366)
 // and file verification.  Integer-only (u32 adds, rotates, boolean functions): no MFMA applies.
 // Bound: VALU issue (~14 ops per input byte); traffic = each input byte read once.
+#include <algorithm>
+#include <stdlib.h>
+
 #include "zpq_internal.h"
 
 namespace {
@@ -15,7 +18,10 @@ struct Sha1State { u32 a, b, c, d, e; };
 // gfx950 three-operand integer ops; hipcc does not form them reliably from C, and the SHA round
 // count is what bounds these kernels (VALU issue), so they are spelled out.
 __device__ __forceinline__ u32 add3(u32 a, u32 b, u32 c) { u32 r; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }   // no v_xor3_b32 on gfx950
+// gfx950 has no v_xor3_b32 but it has the generic three-input LUT op: one instruction for a^b^c and
+// for the majority function (both symmetric, so the operand order cannot matter).
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { u32 r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { u32 r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // (x & m) | (y & ~m)
 __device__ __forceinline__ u32 bfi(u32 m, u32 x, u32 y) { u32 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(x), "v"(y)); return r; }
 
@@ -30,7 +36,7 @@ __device__ __forceinline__ u32 bfi(u32 m, u32 x, u32 y) { u32 r; asm("v_bfi_b32 
   _Pragma("unroll") for (int t = 0; t < 16; ++t) SHA1_R(bfi(b, c, d), K0, WT0(t))     \
   _Pragma("unroll") for (int t = 16; t < 20; ++t) SHA1_R(bfi(b, c, d), K0, WT(t))     \
   _Pragma("unroll") for (int t = 20; t < 40; ++t) SHA1_R(xor3(b, c, d), K1, WT(t))    \
-  _Pragma("unroll") for (int t = 40; t < 60; ++t) SHA1_R(bfi(b ^ c, d, c), K2, WT(t)) \
+  _Pragma("unroll") for (int t = 40; t < 60; ++t) SHA1_R(maj3(b, c, d), K2, WT(t)) \
   _Pragma("unroll") for (int t = 60; t < 80; ++t) SHA1_R(xor3(b, c, d), K3, WT(t))
 
 __device__ __forceinline__ void sha1_rounds(u32 (&w)[16], Sha1State& s) {
@@ -72,7 +78,7 @@ __device__ __forceinline__ bool tail_block(u32 (&w)[16], const u8* p, u32 rem, b
 
 __global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                             const u32* __restrict__ len, u32 n, u8* __restrict__ digests,
-                                                            u32* __restrict__ counter) {
+                                                            u32* __restrict__ counter, const u32* __restrict__ order) {
   // One flat loop: a lane that finishes its extent immediately pulls the next one while its
   // neighbours keep hashing (no per-extent inner loop to re-converge on).  The next 64 input bytes
   // are always in flight while the 80 rounds of the current block run (a 16 MiB block checksum is
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict_
     if (!have) {
       idx = atomicAdd(counter, 1u);
       if (idx >= n) return;
+      if (order) idx = order[idx];      // longest extents first (see extent_order)
       p = base + off[idx];
       total = rem = len[idx];
       s = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
@@ -146,12 +153,12 @@ __device__ __forceinline__ void sha256_rounds(u32 (&w)[16], u32 (&s)[8]) {
     if (t < 16) wt = w[t];
     else {
       u32 w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
-      u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-      u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      u32 s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+      u32 s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
       wt = w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
     }
-    u32 t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + K256[t] + wt;
-    u32 t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    u32 t1 = add3(h, xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), bfi(e, f, g)) + K256[t] + wt;
+    u32 t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + maj3(a, b, c);
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }
   s[0] += a; s[1] += b; s[2] += c; s[3] += d; s[4] += e; s[5] += f; s[6] += g; s[7] += h;
@@ -159,7 +166,7 @@ __device__ __forceinline__ void sha256_rounds(u32 (&w)[16], u32 (&s)[8]) {
 
 __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                               const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
-                                                              u32* __restrict__ counter) {
+                                                              u32* __restrict__ counter, const u32* __restrict__ order) {
   bool have = false, marker = false;
   u32 idx = 0;
   const u8* p = nullptr;
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restric
     if (!have) {
       idx = atomicAdd(counter, 1u);
       if (idx >= n) return;
+      if (order) idx = order[idx];
       p = base + off[idx];
       total = rem = len[idx];
       s[0] = 0x6a09e667; s[1] = 0xbb67ae85; s[2] = 0x3c6ef372; s[3] = 0xa54ff53a;
@@ -265,9 +273,85 @@ __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ b
   }
 }
 
-int persistent_grid(zpq_ctx* ctx, size_t n) {
-  size_t blocks = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
+// ---- longest-first work order ------------------------------------------------------------------------
+// A lane hashes ~13-25 MB/s, so one 508 KiB fragment is tens of milliseconds of serial work: handed
+// out in input order, the last long extents would finish long after everything else (measured: the
+// tail was most of the kernel).  Extents are therefore dealt longest first -- a counting sort on
+// len/4096 (256 classes, descending), which is all the order LPT scheduling needs.
+constexpr u32 kLenClasses = 256;
+template <class L>
+__device__ __forceinline__ u32 len_class(L len) {
+  const u64 c = (u64)len >> 12;
+  return (kLenClasses - 1) - (u32)(c < kLenClasses - 1 ? c : kLenClasses - 1);   // class 0 = longest
+}
+
+template <class L>
+__global__ __launch_bounds__(256) void extent_hist_kernel(const L* __restrict__ len, u32 n, u32* __restrict__ hist) {
+  __shared__ u32 h[kLenClasses];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&h[len_class(len[i])], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// hist[c] -> exclusive prefix (class 0 first), in place
+__global__ __launch_bounds__(256) void extent_scan_kernel(u32* __restrict__ hist) {
+  __shared__ u32 h[kLenClasses];
+  h[threadIdx.x] = hist[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 acc = 0;
+    for (u32 c = 0; c < kLenClasses; ++c) { const u32 v = h[c]; h[c] = acc; acc += v; }
+  }
+  __syncthreads();
+  hist[threadIdx.x] = h[threadIdx.x];
+}
+
+// Each workgroup claims a contiguous run per class for its slice, then places its items (the order
+// inside a class is irrelevant, so nothing downstream depends on which workgroup came first).
+constexpr u32 kOrderSlice = 256 * 16;
+template <class L>
+__global__ __launch_bounds__(256) void extent_scatter_kernel(const L* __restrict__ len, u32 n, u32* __restrict__ cursor,
+                                                             u32* __restrict__ order) {
+  __shared__ u32 cnt[kLenClasses], base[kLenClasses];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 lo = blockIdx.x * kOrderSlice;
+  const u32 hi = lo + kOrderSlice < n ? lo + kOrderSlice : n;
+  for (u32 i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[len_class(len[i])], 1u);
+  __syncthreads();
+  base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0u;
+  __syncthreads();
+  for (u32 i = lo + threadIdx.x; i < hi; i += 256) order[atomicAdd(&base[len_class(len[i])], 1u)] = i;
+}
+
+// Persistent launch shape: `waves` resident waves per SIMD.  Two are enough to keep the VALU issuing
+// (the rounds are one dependent chain per lane) and halve the time a single long extent needs
+// compared with four.
+int persistent_grid(zpq_ctx* ctx, size_t n, int waves) {
+  if (const char* e = getenv("ZPQ_SHA_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) waves = v; }
+  size_t blocks = (n + 255) / 256, cap = (size_t)ctx->cu_count * (size_t)waves;
   return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+// Builds the longest-first order of n extents in scratch slot 8 (main stream only); nullptr = keep
+// the input order (few extents, or scratch unavailable).
+template <class L>
+const u32* extent_order(zpq_ctx* ctx, hipStream_t s, const L* d_len, size_t n, int grid) {
+  if (s != ctx->stream || n <= (size_t)grid * 256) return nullptr;
+  if (getenv("ZPQ_SHA_NO_ORDER")) return nullptr;
+  u32* buf = (u32*)zpq_scratch(ctx, 8, (n + kLenClasses) * 4 + 256);
+  if (!buf) return nullptr;
+  u32* hist = buf;
+  u32* order = buf + kLenClasses;
+  if (hipMemsetAsync(hist, 0, kLenClasses * 4, s) != hipSuccess) return nullptr;
+  const unsigned hb = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(extent_hist_kernel<L>, dim3(hb), dim3(256), 0, s, d_len, (u32)n, hist);
+  hipLaunchKernelGGL(extent_scan_kernel, dim3(1), dim3(256), 0, s, hist);
+  hipLaunchKernelGGL(extent_scatter_kernel<L>, dim3((unsigned)((n + kOrderSlice - 1) / kOrderSlice)), dim3(256), 0, s, d_len,
+                     (u32)n, hist, order);
+  return order;
 }
 
 }  // namespace
@@ -300,8 +384,10 @@ int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + (s == ctx->stream2 ? 16 : 0);
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
-  ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), d_base, d_off, d_len, (u32)n,
-                     d_digests, counter);
+  const int grid = persistent_grid(ctx, n, 2);
+  const u32* order = extent_order(ctx, s, d_len, n, grid);
+  ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n, d_digests, counter,
+             order);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
@@ -320,8 +406,10 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + 32;
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
-  ZPQ_LAUNCH(ctx, "sha256_extents_kernel", ctx->stream, sha256_extents_kernel, dim3(persistent_grid(ctx, n)), dim3(256), d_base, d_off,
-                     d_len, (u32)n, d_digests, counter);
+  const int grid = persistent_grid(ctx, n, 2);
+  const u32* order = extent_order(ctx, ctx->stream, d_len, n, grid);
+  ZPQ_LAUNCH(ctx, "sha256_extents_kernel", ctx->stream, sha256_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n,
+             d_digests, counter, order);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
