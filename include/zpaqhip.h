@@ -214,6 +214,19 @@ int zpq_cm_tables(uint16_t* squash, int16_t* stretch, int32_t* dt, int32_t* dt2k
 int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm,
                       const uint8_t* d_in, uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len);
 
+/* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */
+/* compressBlock()'s expansion of "0".."5"[B][,R,t] into the x/0 method it stands for
+ * (libzpaq 7.15 compressBlock; the snapshot's ZSFX/libzpaq.cpp ends before it, see config.hip).
+ * `data` (n bytes, host) is only read for level 5. */
+int zpq_expand_method(zpq_ctx* ctx, const char* method, const uint8_t* data, size_t n, char* out, size_t cap);
+/* makeConfig(): "x..."/"0..." method -> ZPAQ config source (NUL terminated) and $1..$9 in args. */
+int zpq_make_config(zpq_ctx* ctx, const char* method, int32_t args[9], char* out, size_t cap, size_t* out_len);
+/* libzpaq::Compiler (ZSFX/libzpaq.h:1373-1420, ZSFX/libzpaq.cpp:2500-2706): config source ->
+ * header = hsize[2] hh hm ph pm n COMP 0 HCOMP 0 (what Compressor::startBlock writes after "zPQ" level
+ * type), pcomp = post-processor bytecode with its closing 0 (empty when the config has none). */
+int zpq_compile_config(zpq_ctx* ctx, const char* source, const int32_t* args, uint8_t* header, size_t header_cap,
+                       size_t* header_len, uint8_t* pcomp, size_t pcomp_cap, size_t* pcomp_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,13 @@ while off < len(arc):
     off += b["consumed"]
 json.dump(blocks, open(os.path.join(HERE, "blocks.json"), "w"), indent=1)
 print(json.dumps(blocks, indent=1))
+
+# ZSFX/zsfx.zpaq, ZSFX/zsfx32.zpaq: one streaming block each, method "5" (23 components, no PCOMP).
+# Golden vectors for makeConfig/compressBlock level 5 and the whole context-mixing encoder.
+for name in ("zsfx.zpaq", "zsfx32.zpaq"):
+    a = open("/root/reference/ZSFX/" + name, "rb").read()
+    shutil.copyfile("/root/reference/ZSFX/" + name, os.path.join(HERE, name))
+    b = orc.ref_decompress_block(a, 1 << 20)
+    assert b["consumed"] == len(a) and b["sha1_ok"] == 1, (b["consumed"], len(a), b["sha1_ok"])
+    open(os.path.join(HERE, name.replace(".zpaq", "_plain.xz")), "wb").write(lzma.compress(b["data"], preset=9 | lzma.PRESET_EXTREME))
+    print(name, len(a), "->", len(b["data"]), b["filename"], b["comment"])

@@ -76,6 +76,10 @@ static __device__ __forceinline__ u32 rotr32(u32 x, int k) { return __builtin_ro
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // internal cross-TU entry points
+// method string -> expanded x/0 method, $1..$9, block header bytes (hsize..HCOMP 0) and PCOMP bytecode
+// (config.hip; host_data is only read for level 5)
+int zpq_build_config(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, std::string* xmethod, int args[9],
+                     std::vector<u8>* header, std::vector<u8>* pcomp);
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests);

@@ -100,8 +100,51 @@ def load():
     L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_compress_blocks.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_decompress_blocks.argtypes = [C.c_void_p, C.POINTER(UnblockJob), C.c_size_t, C.c_int]
+    L.zpq_expand_method.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.zpq_make_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_compile_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
+
+
+class ConfigRefused(ValueError):
+    """The method needs a pre-processor no fixture pins (status ZPQ_ERR_METHOD) or the source does not compile."""
+
+
+def expand_method(method, data=b""):
+    """compressBlock's "0".."5"[B][,R,t] -> the x/0 method it stands for (host only, no GPU)."""
+    L = load()
+    out = C.create_string_buffer(4096)
+    rc = L.zpq_expand_method(None, method.encode(), bytes(data), len(data), out, 4096)
+    if rc:
+        raise ConfigRefused("zpq_expand_method(%r) -> %d" % (method, rc))
+    return out.value.decode()
+
+
+def make_config(method):
+    """makeConfig: x/0 method -> (config source, [$1..$9]) (host only, no GPU)."""
+    L = load()
+    args = (C.c_int32 * 9)()
+    out = C.create_string_buffer(1 << 16)
+    n = C.c_size_t(0)
+    rc = L.zpq_make_config(None, method.encode(), args, out, 1 << 16, C.byref(n))
+    if rc:
+        raise ConfigRefused("zpq_make_config(%r) -> %d" % (method, rc))
+    return out.value.decode(), list(args)
+
+
+def compile_config(source, args=()):
+    """libzpaq::Compiler: config source -> (header bytes hsize..HCOMP 0, pcomp bytecode) (host only, no GPU)."""
+    L = load()
+    a = (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9])
+    h = (C.c_ubyte * 70000)()
+    p = (C.c_ubyte * 70000)()
+    hl, pl = C.c_size_t(0), C.c_size_t(0)
+    rc = L.zpq_compile_config(None, source.encode(), a, h, 70000, C.byref(hl), p, 70000, C.byref(pl))
+    if rc:
+        raise ConfigRefused("zpq_compile_config -> %d" % rc)
+    return bytes(h[:hl.value]), bytes(p[:pl.value])
 
 
 class DevBuf:
