@@ -15,6 +15,7 @@ import orc
 
 pytestmark = pytest.mark.gpu
 G = orc.GOLDEN
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
 
 
 @pytest.fixture(scope="module")
@@ -289,6 +290,54 @@ def test_compress_block_without_sha1_and_comment(eng):
     assert st == 0 and out == want
 
 
+# ---------------------------------------------------------------------------------------------------
+# rows a5/a6 + a11-a16 together: compressBlock with context-mixing methods.  The configuration comes from
+# the host-side makeConfig/ZPAQL compiler (config.hip), the coding from the GPU Predictor/Encoder.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["zsfx", "zsfx32"])
+def test_compress_block_level5_reproduces_fixture_archives(eng, name):
+    """ZSFX/zsfx.zpaq and zsfx32.zpaq are single streaming blocks written with method "5": 23 components, no
+    post-processor, comment = the size.  compressBlock over the plaintext must give the archive, byte for byte."""
+    arc = open(os.path.join(G, name + ".zpaq"), "rb").read()
+    plain = lzma.decompress(open(os.path.join(G, name + "_plain.xz"), "rb").read())
+    (st, out), = eng.compress_blocks([plain], ["5"], [""], None, True)
+    assert st == 0
+    assert out == arc
+    r, = eng.decompress_blocks([out], [len(plain) + 8])
+    assert r["status"] == 0 and r["data"] == plain
+
+
+def _reference_cm_block(data, method, fn, comment, sha):
+    """What compressBlock writes for a context-mixing method, with the coding done by the REAL reference
+    Predictor/Encoder (oracle/_ref) and the configuration by the reference Compiler over the makeConfig source."""
+    from zpaqfranz_amd import engine
+    x = engine.expand_method(method, data)
+    src, args = engine.make_config(x)
+    header, pcomp = orc.ref_compile(src, args)
+    assert header[6] > 0
+    body = orc.lz77_encode(data, args[:6]) if args[1] == 1 else data
+    pre = (b"\1" + pcomp) if pcomp else b"\0"            # ref pcomp already carries its 2-byte length
+    coded = orc.ref_cm_encode(header, pre + body)
+    cs = str(len(data)) + ((" " + comment) if comment else "")
+    out = bytes.fromhex("376b5374a03183d38cb228b0d3") + b"zPQ\1\1" + header + b"\1" + (fn or "").encode("latin1") + b"\0" + \
+        cs.encode("latin1") + b"\0\0" + coded
+    return out + ((b"\xfd" + orc.sha1(data)) if sha else b"\xfe") + b"\xff"
+
+
+@needs_ref
+@pytest.mark.parametrize("method", ["4", "44,128,1", "x0,0w2c0,1010,255i1m", "x0,1,5,0,3,20c0,0,255i1", "x1,0c0,0,1004,255i1c0,5i1c256ac0,2,0,255mm16ts19t0"])
+def test_compress_block_cm_methods_equal_reference_coder(eng, method):
+    ins = [datagen.text_like(30000, 51), datagen.binary_like(24000, 52), b"", b"z", bytes(5000) + datagen.random_bytes(3000, 53)]
+    fns = ["jDC20240101000000d%010d" % (i + 1) for i in range(len(ins))]
+    res = eng.compress_blocks(ins, [method] * len(ins), fns, ["jDC\x01"] * len(ins), True)
+    for b, fn, (st, out) in zip(ins, fns, res):
+        assert st == 0
+        assert out == _reference_cm_block(b, method, fn, "jDC\x01", True)
+    back = eng.decompress_blocks([o for _, o in res], [len(b) + 8 for b in ins])
+    for b, r in zip(ins, back):
+        assert r["status"] == 0 and r["data"] == b and r["sha1"] == orc.sha1(b)
+
+
 def test_unsupported_methods_are_refused_not_approximated(eng):
     res = eng.compress_blocks([b"hello world" * 100] * 3, ["3", "14,100,2", "x4,3ci1"], None, None, True)
     assert [st for st, _ in res] == [-5, -5, -5]
@@ -344,8 +393,6 @@ def test_fragmenter_fragments_longer_than_a_segment(eng):
 # REAL reference Predictor/Decoder compiled in place (oracle/_ref)
 # ---------------------------------------------------------------------------------------------------
 import cmconfigs
-
-needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
 
 
 @needs_ref

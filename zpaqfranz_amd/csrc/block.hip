@@ -37,73 +37,43 @@ const u8 kPcompLz1[302] = {
     0x43, 0xef, 0x07, 0x2f, 0x1d, 0x0f, 0x04, 0x42, 0x60, 0x39, 0x09, 0x41, 0x37, 0x04, 0x42, 0xd7, 0x08, 0x50, 0x43,
     0x8f, 0x08, 0x58, 0x07, 0x02, 0x02, 0x37, 0x02, 0xdf, 0x00, 0x2f, 0x03, 0x04, 0x37, 0x01, 0x38, 0x00};
 
-int lg_host(u32 x) { int r = 0; while (x) ++r, x >>= 1; return r; }
-
 enum Kind { KIND_STORE0 = 0, KIND_STOREX = 1, KIND_LZ1 = 2 };
 
 struct Config {
-  Kind kind;
+  Kind kind;           // what produces the bytes the Encoder sees after the preamble
   int args[9];
+  std::vector<u8> header;   // hsize[2] hh hm ph pm n COMP 0 HCOMP 0 (config.hip, == libzpaq::Compiler)
+  std::vector<u8> pcomp;    // post-processor bytecode, empty = PASS
+  u32 ncomp;                // > 0: the Encoder is the arithmetic coder over the context-mixing model
+  std::string xmethod;
 };
 
-// Method string -> configuration, following compressBlock's digit expansion and makeConfig's
-// argument scan (level-1 row pinned by the fixture for type 512).
-int parse_method(zpq_ctx* ctx, const char* method, u32 n, Config* cfg) {
+// Method string -> configuration: compressBlock's digit expansion, makeConfig and the ZPAQL compiler
+// (config.hip).  `host_data` is only needed for levels 5..9 (search for periodic structure).
+int parse_method(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, Config* cfg) {
   if (!method || !method[0]) return zpq_fail(ctx, ZPQ_ERR_ARG, "empty method");
-  std::string m(method);
-  const int arg0 = std::max(lg_host(n + 4095) - 20, 0);
-  if (m[0] >= '0' && m[0] <= '9' && m != "0") {
-    int commas = 0, a[4] = {0, 0, 0, 0};
-    for (size_t i = 1; i < m.size() && commas < 4; ++i) {
-      if (m[i] == ',' || m[i] == '.') ++commas;
-      else if (m[i] >= '0' && m[i] <= '9') a[commas] = a[commas] * 10 + m[i] - '0';
-    }
-    const unsigned type = commas == 0 ? 512u : (unsigned)(a[1] * 4 + a[2]);
-    const int level = m[0] - '0';
-    const int htsz = 19 + arg0 + (arg0 <= 6);
-    char b[64];
-    if (level == 0) snprintf(b, sizeof b, "0%d,0", arg0);
-    else if (level == 1) {
-      if (type & 2) return zpq_fail(ctx, ZPQ_ERR_METHOD, "E8E9 variant (exe hint) not implemented");
-      if (type < 40) snprintf(b, sizeof b, "x%d,0", arg0);
-      else if (type < 80) snprintf(b, sizeof b, "x%d,1,4,0,1,15", arg0);
-      else if (type < 128) snprintf(b, sizeof b, "x%d,1,4,0,2,16", arg0);
-      else if (type < 256) snprintf(b, sizeof b, "x%d,1,4,0,2,%d", arg0, htsz);
-      else if (type < 960) snprintf(b, sizeof b, "x%d,1,5,0,3,%d", arg0, htsz);
-      else snprintf(b, sizeof b, "x%d,1,6,0,3,%d", arg0, htsz);
-    } else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method level %d not implemented (levels 0 and 1 only)", level);
-    m = b;
-  }
-  memset(cfg->args, 0, sizeof cfg->args);
-  const char* p = m.c_str() + 1;
-  int i = 0;
-  while (i < 9 && ((*p >= '0' && *p <= '9') || *p == ',' || *p == '.')) {
-    if (*p >= '0' && *p <= '9') cfg->args[i] = cfg->args[i] * 10 + *p - '0';
-    else if (++i < 9) cfg->args[i] = 0;
-    ++p;
-  }
-  if (*p) return zpq_fail(ctx, ZPQ_ERR_METHOD, "context-model components ('%s') not implemented", p);
+  int rc = zpq_build_config(ctx, method, host_data, n, &cfg->xmethod, cfg->args, &cfg->header, &cfg->pcomp);
+  if (rc) return rc;
+  const std::string& m = cfg->xmethod;
+  cfg->ncomp = cfg->header.size() > 6 ? cfg->header[6] : 0;
+  const int pre = cfg->args[1];
   if (m[0] == '0') cfg->kind = KIND_STORE0;
-  else if (m[0] == 'x' && cfg->args[1] == 0) cfg->kind = KIND_STOREX;
-  else if (m[0] == 'x' && cfg->args[1] == 1 && cfg->args[0] <= 4) cfg->kind = KIND_LZ1;
+  else if (pre == 0) cfg->kind = KIND_STOREX;
+  else if (pre == 1 && cfg->args[0] <= 4) cfg->kind = KIND_LZ1;
+  else if (pre >= 4 && pre <= 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': E8E9 pre-processor not implemented", m.c_str());
   else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s' not implemented", m.c_str());
   if (cfg->kind != KIND_STORE0 && (u64)n > (1ull << (20 + cfg->args[0])))
     return zpq_fail(ctx, ZPQ_ERR_ARG, "block larger than 2^%d", 20 + cfg->args[0]);
   return ZPQ_OK;
 }
 
-// tag, "zPQ", level 2 (n == 0 components), type 1, header, segment start
+// tag, "zPQ", level (2 when there are no components: such headers need a level-2 reader), type 1,
+// header, segment start (Compressor::startBlock / startSegment as read back by Decompresser,
+// ZSFX/libzpaq.cpp:2239-2330)
 void build_prefix(std::vector<u8>& o, const Config& c, const char* filename, const char* comment, u32 n) {
   o.insert(o.end(), kTag, kTag + 13);
-  o.push_back('z'); o.push_back('P'); o.push_back('Q'); o.push_back(2); o.push_back(1);
-  if (c.kind == KIND_STORE0) {
-    const u8 h[9] = {7, 0, 0, 0, 0, 0, 0, 0, 0};                      // comp 0 0 0 0 0 hcomp end
-    o.insert(o.end(), h, h + 9);
-  } else {
-    const u8 h[16] = {0x0e, 0, 9, 16, 0, (u8)(c.kind == KIND_LZ1 ? 20 + c.args[0] : 0), 0, 0,
-                      0x12, 0x68, 0x87, 0xff, 0x58, 0x72, 0x38, 0};   // comp 9 16 0 pm 0 hcomp c-- *c=a a+= 255 d=a *d=c halt
-    o.insert(o.end(), h, h + 16);
-  }
+  o.push_back('z'); o.push_back('P'); o.push_back('Q'); o.push_back(c.ncomp ? 1 : 2); o.push_back(1);
+  o.insert(o.end(), c.header.begin(), c.header.end());
   o.push_back(1);
   if (filename) o.insert(o.end(), filename, filename + strlen(filename));
   o.push_back(0);
@@ -157,8 +127,9 @@ u32 framed_size(u32 prefix_len, u32 P, bool sha) {
 }  // namespace
 
 extern "C" size_t zpq_block_bound(size_t n, const char* filename, const char* comment) {
-  size_t p = zpq_lz77_bound(n) + 3 + 302;
-  return 13 + 5 + 16 + 1 + (filename ? strlen(filename) : 0) + 1 + 24 + (comment ? strlen(comment) + 1 : 0) + 2 + p +
+  // stored/LZ77 framing, or an arithmetic-coded stream (which may grow a little on incompressible input)
+  size_t p = zpq_lz77_bound(n) + 3 + 302 + n / 16 + 1024;
+  return 13 + 5 + 512 /* header: makeConfig's largest is 257 */ + 1 + (filename ? strlen(filename) : 0) + 1 + 24 + (comment ? strlen(comment) + 1 : 0) + 2 + p +
          4 * (p / 65536 + 2) + 4 + 21 + 1 + 64;
 }
 
@@ -171,17 +142,33 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   std::vector<size_t> lz_of(njobs, (size_t)-1);
   size_t lz_out_total = 0, prefix_total = 0;
   int first_err = ZPQ_OK;
+  std::vector<u8> hostbuf;
+  std::vector<size_t> cm_jobs;          // jobs whose Encoder is the context-mixing coder
+  size_t encin_total = 0;
   for (size_t i = 0; i < njobs; ++i) {
     jobs[i].out_len = 0;
-    jobs[i].status = parse_method(ctx, jobs[i].method, jobs[i].n, &cfg[i]);
-    if (jobs[i].status == ZPQ_OK && jobs[i].out_cap < zpq_block_bound(jobs[i].n, jobs[i].filename, jobs[i].comment))
+    const u8* host_data = nullptr;
+    if (jobs[i].method && jobs[i].method[0] >= '5' && jobs[i].method[0] <= '9' && jobs[i].n) {
+      hostbuf.resize(jobs[i].n);        // level 5 looks at the data to pick periodic models (host logic in libzpaq too)
+      ZPQ_HIP(ctx, hipMemcpyAsync(hostbuf.data(), jobs[i].in, jobs[i].n, hipMemcpyDeviceToHost, st));
+      ZPQ_HIP(ctx, hipStreamSynchronize(st));
+      host_data = hostbuf.data();
+    }
+    jobs[i].status = parse_method(ctx, jobs[i].method, host_data, jobs[i].n, &cfg[i]);
+    if (jobs[i].status == ZPQ_OK && jobs[i].out_cap + 512 < zpq_block_bound(jobs[i].n, jobs[i].filename, jobs[i].comment) + cfg[i].header.size())
       jobs[i].status = zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: out_cap below zpq_block_bound", i);
     if (jobs[i].status != ZPQ_OK) { if (!first_err) first_err = jobs[i].status; continue; }
     build_prefix(prefix[i], cfg[i], jobs[i].filename, jobs[i].comment, jobs[i].n);
     const u32 plen = (u32)prefix[i].size();
-    if (cfg[i].kind == KIND_LZ1) {   // postProcess(): 1, psize lo, psize hi, pcomp
-      prefix[i].push_back(1); prefix[i].push_back(302 & 255); prefix[i].push_back(302 >> 8);
-      prefix[i].insert(prefix[i].end(), kPcompLz1, kPcompLz1 + 302);
+    if (!cfg[i].pcomp.empty()) {   // postProcess(): 1, psize lo, psize hi, pcomp
+      const size_t ps = cfg[i].pcomp.size();
+      prefix[i].push_back(1); prefix[i].push_back((u8)(ps & 255)); prefix[i].push_back((u8)(ps >> 8));
+      prefix[i].insert(prefix[i].end(), cfg[i].pcomp.begin(), cfg[i].pcomp.end());
+    } else {
+      prefix[i].push_back(0);        // PASS
+    }
+    size_t body_cap = jobs[i].n;
+    if (cfg[i].kind == KIND_LZ1) {
       lz_of[i] = lz.size();
       zpq_lz77_job j;
       memset(&j, 0, sizeof j);
@@ -189,9 +176,12 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
       for (int k = 0; k < 9; ++k) j.args[k] = cfg[i].args[k];
       j.out_cap = (u32)((zpq_lz77_bound(jobs[i].n) + 15) & ~(size_t)15);
       lz_out_total += j.out_cap;
+      body_cap = j.out_cap;
       lz.push_back(j);
-    } else {
-      prefix[i].push_back(0);        // PASS
+    }
+    if (cfg[i].ncomp) {
+      cm_jobs.push_back(i);
+      encin_total += (prefix[i].size() - plen + body_cap + 64 + 15) & ~(size_t)15;
     }
     prefix[i].push_back((u8)(plen & 255)); prefix[i].push_back((u8)(plen >> 8));  // trailer: prefix_len (host bookkeeping)
     prefix_total += (prefix[i].size() + 15) & ~(size_t)15;
@@ -229,18 +219,21 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   size_t po = 0, nfr = 0;
   u32 maxP = 0;
   std::vector<size_t> fr_job;
-  for (size_t i = 0, s = 0; i < njobs; ++i) {
+  std::vector<size_t> sha_slot(njobs, (size_t)-1);
+  for (size_t i = 0, s = 0; i < njobs; ++i)
+    if (jobs[i].status == ZPQ_OK && jobs[i].dosha1) sha_slot[i] = s++;
+  for (size_t i = 0; i < njobs; ++i) {
     if (jobs[i].status != ZPQ_OK) continue;
     std::vector<u8>& pv = prefix[i];
     const u32 plen = pv[pv.size() - 2] | (u32)pv[pv.size() - 1] << 8;
     pv.resize(pv.size() - 2);
+    if (cfg[i].ncomp) continue;         // arithmetic-coded: assembled below
     memcpy(&pre_all[po], pv.data(), pv.size());
     FrameDev F;
     F.out = jobs[i].out; F.prefix = d_prefix + po; F.prefix_len = plen; F.pre_len = (u32)pv.size() - plen;
     if (cfg[i].kind == KIND_LZ1) { F.data = lz[lz_of[i]].d_out; F.data_len = lz[lz_of[i]].out_len; }
     else { F.data = jobs[i].in; F.data_len = jobs[i].n; }
-    F.digest = nullptr;
-    if (jobs[i].dosha1) { F.digest = d_dig + 20 * s; ++s; }
+    F.digest = jobs[i].dosha1 ? d_dig + 20 * sha_slot[i] : nullptr;
     const u32 P = F.pre_len + F.data_len;
     jobs[i].out_len = framed_size(plen, P, jobs[i].dosha1 != 0);
     if (jobs[i].out_len > jobs[i].out_cap) { jobs[i].status = ZPQ_ERR_CAPACITY; jobs[i].out_len = 0; if (!first_err) first_err = ZPQ_ERR_CAPACITY; continue; }
@@ -255,6 +248,55 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     if (!sha_job.empty()) ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev, 0));
     ZPQ_LAUNCH(ctx, "frame_kernel", st, frame_kernel, dim3((maxP + 255) / 256, (unsigned)nfr), dim3(256), d_frames);
     ZPQ_HIP(ctx, hipGetLastError());
+  }
+  // context-mixing blocks: the Encoder sees preamble + body; its output goes straight behind the prefix
+  if (!cm_jobs.empty()) {
+    u8* d_encin = (u8*)zpq_scratch(ctx, 11, encin_total + 64);
+    if (!d_encin) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "encoder input scratch");
+    std::vector<zpq_cm_job> cj(cm_jobs.size());
+    std::vector<u32> plens(cm_jobs.size());
+    size_t eo = 0;
+    for (size_t k = 0; k < cm_jobs.size(); ++k) {
+      const size_t i = cm_jobs[k];
+      const std::vector<u8>& pv = prefix[i];         // already without the bookkeeping trailer
+      u32 plen = 0;
+      {   // prefix length = up to and including the reserved 0 after the comment: recompute from the pieces
+        std::vector<u8> tmp; build_prefix(tmp, cfg[i], jobs[i].filename, jobs[i].comment, jobs[i].n); plen = (u32)tmp.size();
+      }
+      plens[k] = plen;
+      const u32 pre_len = (u32)pv.size() - plen;
+      const u8* body = cfg[i].kind == KIND_LZ1 ? lz[lz_of[i]].d_out : jobs[i].in;
+      const u32 body_len = cfg[i].kind == KIND_LZ1 ? lz[lz_of[i]].out_len : jobs[i].n;
+      u8* e = d_encin + eo;
+      ZPQ_HIP(ctx, hipMemcpyAsync(e, pv.data() + plen, pre_len, hipMemcpyHostToDevice, st));
+      if (body_len) ZPQ_HIP(ctx, hipMemcpyAsync(e + pre_len, body, body_len, hipMemcpyDeviceToDevice, st));
+      ZPQ_HIP(ctx, hipMemcpyAsync(jobs[i].out, pv.data(), plen, hipMemcpyHostToDevice, st));
+      memset(&cj[k], 0, sizeof cj[k]);
+      cj[k].header = cfg[i].header.data(); cj[k].header_len = (u32)cfg[i].header.size();
+      cj[k].d_in = e; cj[k].n = pre_len + body_len;
+      cj[k].d_out = jobs[i].out + plen; cj[k].out_cap = jobs[i].out_cap - plen - 32;
+      eo += (pre_len + body_len + 64 + 15) & ~(size_t)15;
+    }
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    int rc = zpq_cm_encode_dev(ctx, cj.data(), cj.size());
+    if (rc && !first_err) first_err = rc;
+    if (!sha_job.empty()) ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev, 0));
+    for (size_t k = 0; k < cm_jobs.size(); ++k) {
+      const size_t i = cm_jobs[k];
+      if (cj[k].status != ZPQ_OK) { jobs[i].status = cj[k].status; jobs[i].out_len = 0; if (!first_err) first_err = cj[k].status; continue; }
+      u8* t = jobs[i].out + plens[k] + cj[k].out_len;       // the coder already wrote the four 0 bytes
+      static const u8 m253 = 253, m254 = 254, m255 = 255;
+      if (jobs[i].dosha1) {
+        ZPQ_HIP(ctx, hipMemcpyAsync(t, &m253, 1, hipMemcpyHostToDevice, st));
+        ZPQ_HIP(ctx, hipMemcpyAsync(t + 1, d_dig + 20 * sha_slot[i], 20, hipMemcpyDeviceToDevice, st));
+        ZPQ_HIP(ctx, hipMemcpyAsync(t + 21, &m255, 1, hipMemcpyHostToDevice, st));
+        jobs[i].out_len = plens[k] + cj[k].out_len + 22;
+      } else {
+        ZPQ_HIP(ctx, hipMemcpyAsync(t, &m254, 1, hipMemcpyHostToDevice, st));
+        ZPQ_HIP(ctx, hipMemcpyAsync(t + 1, &m255, 1, hipMemcpyHostToDevice, st));
+        jobs[i].out_len = plens[k] + cj[k].out_len + 2;
+      }
+    }
   }
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   return first_err;
@@ -333,6 +375,9 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
       while (curr == 0 && q < n) curr = a[q++];
       while (curr && q < n) curr = curr << 8 | a[q++];
       if (curr) { bad(ZPQ_ERR_FORMAT, "unterminated coded data"); continue; }
+      // the coder's last byte (Encoder::flush) may itself be 0: then the scan stopped one short of the
+      // real terminator.  What follows the terminator is 253 or 254, never 0.
+      while (q < n && a[q] == 0) ++q;
       P.payload.assign(a + p, a + q);
       p = q;
     } else

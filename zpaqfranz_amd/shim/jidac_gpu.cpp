@@ -97,6 +97,7 @@ bool parse_block(const uint8_t* a, size_t n, RawBlock& rb) {
     uint32_t curr = 0;
     while (curr == 0 && p < n) curr = a[p++];
     while (curr && p < n) curr = curr << 8 | a[p++];
+    while (p < n && a[p] == 0) ++p;      // the coder's own last byte may be 0 (the marker that follows never is)
   } else {
     for (;;) {
       if (p + 4 > n) return false;
