@@ -209,16 +209,19 @@ __device__ __forceinline__ bool lane_group(const u32x4 d, u64& pos, const u64 fi
   }
   const bool maybe = (hmin < P.thresh && s.sz + 16 >= P.minf) || s.sz + 16 >= P.maxf || pos + 16 == file_end;
   if (maybe) {                            // rare: locate the first cut of this group exactly
-    u32 hh = s.h, sz = s.sz; int cutj = -1;
+    u32 hh = s.h, sz = s.sz; int cutj = -1; bool trig = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       hh = (hh + c[j] + 1u) * (c[j] == pr[j] ? 314159265u : 271828182u);
       ++sz;
-      if (cutj < 0 && (sz >= P.maxf || (hh < P.thresh && sz >= P.minf) || pos + j + 1 == file_end)) cutj = j;
+      if (cutj < 0 && (sz >= P.maxf || (hh < P.thresh && sz >= P.minf) || pos + j + 1 == file_end)) {
+        cutj = j;
+        trig = hh < P.thresh && sz >= P.minf;
+      }
     }
     if (cutj >= 0) {
       const u64 E = pos + (u64)cutj;
-      on_cut(E);
+      on_cut(E, trig);
       o.clear();          // also wipes what the bytes after the cut wrote: they are re-walked from E+1
       s.h = 0; s.c1 = 0; s.sz = 0;
       pos = E + 1;
@@ -247,7 +250,8 @@ struct LaneStream {
 
 // Advances this lane's stream by 64 bytes (16 or 1 near the end of [pos, lim)).  Must be called by
 // every lane of the wave every step, with PH cycling 0,1,2 (finished lanes pass pos >= lim and only
-// take part in the refill).  on_cut(E) is called for every cut.
+// take part in the refill).  on_cut(E, trig) is called for every cut (trig: the hash fired, as opposed to
+// a cut forced by the size limit or the end of the file).
 template <int PH, class OnCut>
 __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStream& ls, u64& pos, const u64 lim,
                                           const u64 file_end, const FragP& P, LaneO1& o, LaneState& s, OnCut&& on_cut) {
@@ -278,7 +282,7 @@ __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStrea
       s.h = (s.h + c + 1u) * (c == pr ? 314159265u : 271828182u);
       s.c1 = c; ++s.sz;
       if (s.sz >= P.maxf || (s.h < P.thresh && s.sz >= P.minf) || pos + 1 == file_end) {
-        on_cut(pos);
+        on_cut(pos, s.h < P.thresh && s.sz >= P.minf);
         o.clear();
         s.h = 0; s.c1 = 0; s.sz = 0;
       }
@@ -296,10 +300,12 @@ __device__ __forceinline__ void lane_step(const u8* __restrict__ data, LaneStrea
 // A lane fragments its segment from the segment start as if a fragment began there, records the cuts
 // that fall inside the segment, and then keeps walking -- its state at the segment end is exactly what
 // the seam needs -- until the crossing fragment ends at a place where the next lane could have cut
-// too (>= min_fragment behind the boundary; at most two cuts).  Crossing fragments are ~64 KiB on
+// too (a hash-triggered cut >= min_fragment behind the boundary; cuts forced by the size limit are walked
+// through, at most four cuts).  Crossing fragments are ~64 KiB on
 // average but exponentially distributed, hence the dynamic hand-out: a wave never idles behind its
 // slowest lane.
-struct CrossOut { u64 x[2]; u32 n; u32 pad; };
+constexpr u32 kCrossMax = 4;
+struct CrossOut { u64 x[kCrossMax]; u32 n; u32 pad; };
 __device__ unsigned long long g_frag_stats[8];   // ZPQ_FRAG_STATS=1: [0] seams in step, [1] cross unusable, [2] lookups missed, [3] exact evals, [4] exact bytes
 
 __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
   LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
   o.clear();
   bool active = false, exhausted = false;
-  u64 s = 0, pos = 0, lim = 0, fe = 0, g = 0, segend = 0, x0 = 0, x1 = 0;
+  u64 s = 0, pos = 0, lim = 0, fe = 0, g = 0, segend = 0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
   u32 cnt = 0, nx = 0;
   u32* out = spec_rel;
   LaneState st{0, 0, 0};
@@ -328,9 +334,9 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
         fe = file_off[f + 1];                                                                                 \
         g = fs + (s - seg_base[f]) * P.seg;                                                                   \
         segend = g + P.seg < fe ? g + P.seg : fe;                                                             \
-        const u64 far = segend + (u64)P.minf + (u64)P.maxf + 64; /* two crossing fragments at most */         \
+        const u64 far = segend + (u64)P.minf + (u64)kCrossMax * P.maxf + 64; /* kCrossMax crossing fragments */ \
         lim = far < fe ? far : fe;                                                                            \
-        pos = g; cnt = 0; nx = 0; x0 = x1 = 0;                                                                \
+        pos = g; cnt = 0; nx = 0; x0 = x1 = x2 = x3 = 0;                                                      \
         out = spec_rel + s * (u64)spec_cap;                                                                   \
         ls.at = ~0ull;                                                                                        \
         active = true; /* o1[] and the hash state are clean: lanes stop on a cut */                           \
@@ -341,21 +347,24 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
     if (!__any(active)) break;                                                                                \
     bool done = false;                                                                                        \
     /* every lane steps every iteration; idle ones have pos >= lim and only take part in the refill */        \
-    lane_step<PH>(data, ls, pos, lim, fe, P, o, st, [&](u64 E) {                                              \
+    lane_step<PH>(data, ls, pos, lim, fe, P, o, st, [&](u64 E, bool trig) {                                   \
       if (E < segend) {                                                                                       \
         if (cnt < spec_cap) out[cnt] = (u32)(E - g);                                                          \
         ++cnt;                                                                                                \
         if (E + 1 == segend) done = true; /* cut on the boundary: the next lane starts in step */             \
       } else {                                                                                                \
-        if (nx == 0) x0 = E; else x1 = E;                                                                     \
+        if (nx == 0) x0 = E; else if (nx == 1) x1 = E; else if (nx == 2) x2 = E; else x3 = E;                 \
         ++nx;                                                                                                 \
-        if (E + 1 >= segend + (u64)P.minf || nx == 2) done = true;                                            \
+        /* a cut the size limit forced is one no speculating lane made: keep walking (this lane IS the    */ \
+        /* true chain) until the hash fires where the lane of that segment could have cut as well         */ \
+        if ((trig && E + 1 >= segend + (u64)P.minf) || nx == kCrossMax) done = true;                          \
       }                                                                                                       \
       if (E + 1 == fe) done = true;                                                                           \
     });                                                                                                       \
     if (active && (done || pos >= lim)) {                                                                     \
       spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;                                                          \
-      CrossOut co; co.x[0] = x0; co.x[1] = x1; co.n = (done && cnt <= spec_cap) ? nx : 0xffffffffu; co.pad = 0; \
+      CrossOut co; co.x[0] = x0; co.x[1] = x1; co.x[2] = x2; co.x[3] = x3;                                    \
+      co.n = (done && cnt <= spec_cap) ? nx : 0xffffffffu; co.pad = 0;                                        \
       cross[s] = co;                                                                                          \
       active = false;                                                                                         \
       lim = pos;                                                                                              \
@@ -409,12 +418,12 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
       // The lane that produced this list was in the true state from cut `from` on (or from the segment
       // start when from == 0), so the fragment(s) it walked across the boundary are true as well.
       const CrossOut co = cross[sidx];
-      if (co.n == 0xffffffffu || co.n == 0 || co.n > 2) {
+      if (co.n == 0xffffffffu || co.n == 0 || co.n > kCrossMax) {
         if (lane == 0) atomicAdd(&g_frag_stats[1], 1ull);
         synced = false;       // nothing usable: go on exactly from S
         continue;
       }
-      if (lane == 0) { out[cnt] = co.x[0]; if (co.n == 2) out[cnt + 1] = co.x[1]; }
+      if ((u32)lane < co.n) out[cnt + lane] = co.x[lane];
       cnt += co.n;
       E = co.x[co.n - 1];
       S = E + 1;
