@@ -331,9 +331,10 @@ def main():
         return outs[-1] if n else 0
 
     stagger = [0.0]
-    if depth > 1:            # one untimed serial step per context: sizes scratch, measures the step for the stagger
+    if depth > 1:            # one untimed serial step per context sizes its scratch; a second, warm one gives the stagger
         for p_ in pipes:
-            t_ = time.perf_counter(); p_.step(); stagger[0] = time.perf_counter() - t_
+            p_.step()
+        t_ = time.perf_counter(); pipes[0].step(); stagger[0] = time.perf_counter() - t_
     run_steps(a.warmup)
     for e_ in engines:
         e_.profile(not a.no_kernel_timing)

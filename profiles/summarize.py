@@ -45,6 +45,22 @@ def main(root, tag):
         for name, calls, sm, av in rows:
             out.append("%-34s %6d %16.1f %16.1f" % (short(name)[:34], calls, sm, av))
         out.append("")
+    # bytes per launch for bench.py's roofline.traffic: FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE
+    per = {}
+    for sub, ctr, mul in (("prof_fetch", "FETCH_SIZE", 2.0), ("prof_write", "WRITE_SIZE", 1.0)):
+        cur = q(os.path.join(root, sub))
+        if not cur:
+            continue
+        for name, calls, sm in cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
+            k = short(name)
+            k = "fragment_resume_kernel" if k.startswith("fragment_spec_kernel<true") else k.split("<")[0]   # names bench.py uses
+            per[k] = per.get(k, 0) + int(sm * 1024 * mul / max(1, calls))
+    if per:
+        import json
+        json.dump({"source": "profiles/%s_rocprof_summary.txt: per launch, FETCH_SIZE*2 (gfx950 correction, calibrated on the copyBuffer "
+                             "dispatches of the same run) + WRITE_SIZE" % tag,
+                   "bytes_per_launch": dict(sorted(per.items(), key=lambda kv: -kv[1]))},
+                  open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json"), "w"), indent=1)
     txt = "\n".join(out)
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_rocprof_summary.txt" % tag), "w").write(txt)
     print(txt)

@@ -132,6 +132,14 @@ def test_fragmenter_lanes_pull_many_segments(eng, monkeypatch):
     monkeypatch.delenv("ZPQ_FRAG_MAX_WAVES")
     monkeypatch.delenv("ZPQ_FRAG_SEG")
     assert eng.fragment_files(files) == want
+    # long crossing walks are parked and resumed by a second launch: park nearly all of them / none of them
+    for budget in ("4096", "70000", "0"):
+        monkeypatch.setenv("ZPQ_FRAG_BUDGET", budget)
+        assert eng.fragment_files(files) == want
+    monkeypatch.setenv("ZPQ_FRAG_BUDGET", "1000")
+    monkeypatch.setenv("ZPQ_FRAG_SEG", "65536")
+    monkeypatch.setenv("ZPQ_FRAG_MAX_WAVES", "2")
+    assert eng.fragment_files(files) == want
 
 
 def test_fragmenter_periodic_and_constant_runs(eng):

@@ -308,16 +308,26 @@ constexpr u32 kCrossMax = 4;
 struct CrossOut { u64 x[kCrossMax]; u32 n; u32 pad; };
 __device__ unsigned long long g_frag_stats[8];   // ZPQ_FRAG_STATS=1: [0] seams in step, [1] cross unusable, [2] lookups missed, [3] exact evals, [4] exact bytes
 
+// A lane whose crossing walk exceeds `budget` bytes parks its state (o1[] table, hash, position) and takes the
+// next segment; a second launch (RESUME) of a few waves picks the parked walks up again.  Long crossings are
+// rare (exponential tail, plus fragments forced by the size limit) but a lane walks only 10-40 MB/s: left in
+// place they would keep nearly every wave of the first launch resident with two or three live lanes.
+struct Parked { u64 s, pos, x[kCrossMax]; u32 h, c1, sz, nx, cnt, pad; u32 tab[64]; };
+
+template <bool RESUME>
 __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict__ data, u64 readable, const u64* __restrict__ file_off,
                                                             const u32* __restrict__ seg_file,
                                                             const u64* __restrict__ seg_base, u64 nseg, FragP P,
                                                             u32 spec_cap, u32* __restrict__ spec_rel,
                                                             u32* __restrict__ spec_cnt, CrossOut* __restrict__ cross,
-                                                            unsigned long long* __restrict__ counter) {
+                                                            unsigned long long* __restrict__ counters, Parked* __restrict__ parked,
+                                                            u64 budget) {
   __shared__ u8 tab[16384];
   const u32 lane = (u32)lane_id();
   LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
+  lds_u32* const orow = (lds_u32*)(o.t + o.lanebase);      // this lane's 64 table words sit 256 bytes apart
   o.clear();
+  const u64 nwork = RESUME ? counters[1] : nseg;           // counters: [0] segments handed out, [1] parked, [2] resumed
   bool active = false, exhausted = false;
   u64 s = 0, pos = 0, lim = 0, fe = 0, g = 0, segend = 0, x0 = 0, x1 = 0, x2 = 0, x3 = 0;
   u32 cnt = 0, nx = 0;
@@ -327,8 +337,16 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
 #define ZPQ_FRAG_STEP(PH)                                                                                     \
   {                                                                                                           \
     if (!active && !exhausted) {                                                                              \
-      s = atomicAdd(counter, 1ull);                                                                           \
-      if (s < nseg) {                                                                                         \
+      const u64 w = atomicAdd(&counters[RESUME ? 2 : 0], 1ull);                                               \
+      if (w < nwork) {                                                                                        \
+        if (RESUME) {                                                                                         \
+          const Parked* pk = parked + w;                                                                      \
+          s = pk->s; pos = pk->pos; x0 = pk->x[0]; x1 = pk->x[1]; x2 = pk->x[2]; x3 = pk->x[3];               \
+          st.h = pk->h; st.c1 = pk->c1; st.sz = pk->sz; nx = pk->nx; cnt = pk->cnt;                           \
+          _Pragma("unroll") for (int a = 0; a < 64; ++a) orow[a * 64] = pk->tab[a];                           \
+        } else {                                                                                              \
+          s = w;                                                                                              \
+        }                                                                                                     \
         const u32 f = seg_file[s];                                                                            \
         const u64 fs = file_off[f];                                                                           \
         fe = file_off[f + 1];                                                                                 \
@@ -336,10 +354,10 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
         segend = g + P.seg < fe ? g + P.seg : fe;                                                             \
         const u64 far = segend + (u64)P.minf + (u64)kCrossMax * P.maxf + 64; /* kCrossMax crossing fragments */ \
         lim = far < fe ? far : fe;                                                                            \
-        pos = g; cnt = 0; nx = 0; x0 = x1 = x2 = x3 = 0;                                                      \
+        if (!RESUME) { pos = g; cnt = 0; nx = 0; x0 = x1 = x2 = x3 = 0; }                                     \
         out = spec_rel + s * (u64)spec_cap;                                                                   \
         ls.at = ~0ull;                                                                                        \
-        active = true; /* o1[] and the hash state are clean: lanes stop on a cut */                           \
+        active = true; /* fresh segments: o1[] and the hash state are clean, lanes stop on a cut */           \
       } else {                                                                                                \
         exhausted = true;                                                                                     \
       }                                                                                                       \
@@ -362,10 +380,21 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
       if (E + 1 == fe) done = true;                                                                           \
     });                                                                                                       \
     if (active && (done || pos >= lim)) {                                                                     \
-      spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;                                                          \
+      if (!RESUME) spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;                                             \
       CrossOut co; co.x[0] = x0; co.x[1] = x1; co.x[2] = x2; co.x[3] = x3;                                    \
       co.n = (done && cnt <= spec_cap) ? nx : 0xffffffffu; co.pad = 0;                                        \
       cross[s] = co;                                                                                          \
+      active = false;                                                                                         \
+      lim = pos;                                                                                              \
+    } else if (!RESUME && active && pos >= segend + budget) {                                                 \
+      /* park: the segment's own list is complete, only the crossing walk is left */                          \
+      spec_cnt[s] = cnt < spec_cap ? cnt : spec_cap;                                                          \
+      Parked* pk = parked + atomicAdd(&counters[1], 1ull);                                                    \
+      pk->s = s; pk->pos = pos; pk->x[0] = x0; pk->x[1] = x1; pk->x[2] = x2; pk->x[3] = x3;                   \
+      pk->h = st.h; pk->c1 = st.c1; pk->sz = st.sz; pk->nx = nx; pk->cnt = cnt; pk->pad = 0;                  \
+      _Pragma("unroll") for (int a = 0; a < 64; ++a) pk->tab[a] = orow[a * 64];                               \
+      o.clear();                                                                                              \
+      st.h = 0; st.c1 = 0; st.sz = 0;                                                                         \
       active = false;                                                                                         \
       lim = pos;                                                                                              \
     }                                                                                                         \
@@ -545,12 +574,13 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
 
   // device scratch: [file_off | seg_base | cut_base | frag_base | seg_file | spec_cnt | cut_cnt] , spec_rel, cuts
   const size_t nf1 = nfiles + 1;
-  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 8 + 256;
+  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 32 + 256;
   u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
-  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4 + nseg * sizeof(CrossOut) + 256);
+  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4 + nseg * (sizeof(CrossOut) + sizeof(Parked)) + 512);
   u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
   if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
   CrossOut* d_cross = (CrossOut*)(d_spec_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
+  Parked* d_parked = (Parked*)(d_cross + nseg);
   u64* d_file_off = (u64*)meta;
   u64* d_seg_base = d_file_off + nf1;
   u64* d_cut_base = d_seg_base + nf1;
@@ -560,7 +590,7 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
   u32* d_cut_cnt = d_spec_cnt + nseg;
   unsigned long long* d_counter = (unsigned long long*)(((uintptr_t)(d_cut_cnt + nfiles) + 7) & ~(uintptr_t)7);
   hipStream_t st = ctx->stream;
-  ZPQ_HIP(ctx, hipMemsetAsync(d_counter, 0, 8, st));
+  ZPQ_HIP(ctx, hipMemsetAsync(d_counter, 0, 24, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_file_off, file_off, nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_base, seg_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
@@ -568,8 +598,16 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
 
   u64 want_waves = (nseg + 63) / 64;
   if (const char* e = getenv("ZPQ_FRAG_MAX_WAVES")) { const int v = atoi(e); if (v >= 1) cap_waves = std::min<u64>(cap_waves, (u64)v); }  // tests
-  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64), d_base,
-             total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter);
+  u64 budget = 256 << 10;      // bytes a lane may walk past its segment before it parks the walk
+  if (const char* e = getenv("ZPQ_FRAG_BUDGET")) { const long long v = atoll(e); budget = v > 0 ? (u64)v : ~0ull >> 1; }
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel<false>, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64),
+             d_base, total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter,
+             d_parked, budget);
+  ZPQ_HIP(ctx, hipGetLastError());
+  // parked walks: a few waves, every lane live (waves that find nothing exit at once)
+  ZPQ_LAUNCH(ctx, "fragment_resume_kernel", st, fragment_spec_kernel<true>,
+             dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * 2))), dim3(64), d_base, total,
+             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
              readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_cut_base, d_cuts,
