@@ -105,6 +105,7 @@ struct Vm {                       // one ZPAQL machine (HCOMP or PCOMP)
   u32 a, b, c, d, f;
   u8* out; u32 out_cap, out_len;  // OUT instruction target (PCOMP only)
   int err;
+  u32 in_lds;                     // bit 0: prog points into LDS, bit 1: H does (set by the kernel that put them there)
 };
 
 struct CmJobDev {
@@ -125,18 +126,24 @@ __device__ __forceinline__ int clamp512k(int x) { return x < -(1 << 19) ? -(1 <<
 
 // ZPAQL interpreter (ZSFX/libzpaq.cpp:1033-1254).  Operand encodings are regular: op&7 selects
 // A B C D *B *C *D N for the two-operand groups.
-__device__ void vm_run(Vm& z, u32 input) {
+template <class ProgPtr, class HPtr>
+__device__ void vm_body(Vm& z, u32 input, ProgPtr P, HPtr H) {
   // everything the loop touches is copied to locals first: a byte store into M[] may alias *z as far as the
   // compiler can tell, and it would otherwise re-load the pointers and masks from HBM after every store
-  const u8* const P = z.prog;
   const u32 plen = z.plen, hmask = z.hmask, mmask = z.mmask;
-  u32* const H = z.H; u8* const M = z.M; u32* const R = z.R;
+  typedef __attribute__((address_space(1))) u8 g_u8;
+  typedef __attribute__((address_space(1))) u32 g_u32;
+  g_u8* const M = (g_u8*)z.M; g_u32* const R = (g_u32*)z.R;      // always in HBM: global_*, not flat_* instructions
   u32 out_len = z.out_len; const u32 out_cap = z.out_cap; u8* const outp = z.out;
   int err = 0;
   u32 pc = 0, a = input, b = z.b, c = z.c, d = z.d, f = z.f;
   for (int guard = 0; guard < (1 << 30); ++guard) {
+    // The machine runs on one lane (or on lanes in identical states): telling the compiler that the
+    // opcode, the program counter and the flag are wave-uniform turns the dispatch below into scalar
+    // branches instead of a tree of exec-mask splits.
+    pc = (u32)__builtin_amdgcn_readfirstlane((int)pc);
     if (pc >= plen) { err = 1; break; }
-    const u32 op = P[pc++];
+    const u32 op = (u32)__builtin_amdgcn_readfirstlane((int)(u32)P[pc++]);
     if (op == 56) break;                                     // HALT
     if (op >= 64 && op < 240 && (op < 120 || op >= 128)) {
       const u32 sel = op & 7, grp = op >> 3;
@@ -169,15 +176,15 @@ __device__ void vm_run(Vm& z, u32 input) {
       case 24: { u32 t = a; a = d; d = t; } break; case 25: ++d; break; case 26: --d; break; case 27: d = ~d; break; case 28: d = 0; break;
       case 31: d = R[P[pc++]]; break;
       // a byte of M swaps with the LOW byte of A only (swap(U8&), ZSFX/libzpaq.h:1073)
-      case 32: { u8& x = M[b & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 32: { auto& x = M[b & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
       case 33: ++M[b & mmask]; break; case 34: --M[b & mmask]; break;
       case 35: M[b & mmask] = ~M[b & mmask]; break; case 36: M[b & mmask] = 0; break;
-      case 39: if (f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;          // JT
-      case 40: { u8& x = M[c & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
+      case 39: if (__builtin_amdgcn_readfirstlane((int)f)) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;          // JT
+      case 40: { auto& x = M[c & mmask]; u32 t = x; x = (u8)a; a = (a & 0xffffff00u) | t; } break;
       case 41: ++M[c & mmask]; break; case 42: --M[c & mmask]; break;
       case 43: M[c & mmask] = ~M[c & mmask]; break; case 44: M[c & mmask] = 0; break;
-      case 47: if (!f) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;         // JF
-      case 48: { u32& x = H[d & hmask]; u32 t = x; x = a; a = t; } break;
+      case 47: if (!__builtin_amdgcn_readfirstlane((int)f)) pc += ((P[pc] + 128) & 255) - 127; else ++pc; break;         // JF
+      case 48: { auto& x = H[d & hmask]; u32 t = x; x = a; a = t; } break;
       case 49: ++H[d & hmask]; break; case 50: --H[d & hmask]; break;
       case 51: H[d & hmask] = ~H[d & hmask]; break; case 52: H[d & hmask] = 0; break;
       case 55: R[P[pc++]] = a; break;
@@ -192,6 +199,19 @@ __device__ void vm_run(Vm& z, u32 input) {
   }
   z.a = a; z.b = b; z.c = c; z.d = d; z.f = f; z.out_len = out_len;
   if (err) z.err = 1;
+}
+
+// The wave coder keeps the HCOMP program and a small H[] in LDS: give those the ds_* path (a flat access
+// also waits for every outstanding global access, and the other way round).
+__device__ void vm_run(Vm& z, u32 input) {
+  typedef __attribute__((address_space(3))) const u8 l_cu8;
+  typedef __attribute__((address_space(3))) u32 l_u32;
+  typedef __attribute__((address_space(1))) const u8 g_cu8;
+  typedef __attribute__((address_space(1))) u32 g_u32;
+  const bool pl = z.in_lds & 1, hl = z.in_lds & 2;
+  if (pl && hl) vm_body(z, input, (l_cu8*)z.prog, (l_u32*)z.H);
+  else if (!pl && !hl) vm_body(z, input, (g_cu8*)z.prog, (g_u32*)z.H);
+  else vm_body(z, input, z.prog, z.H);
 }
 
 // find(): ZSFX/libzpaq.cpp:2064-2080
@@ -435,9 +455,36 @@ __device__ __forceinline__ int wave_sum_to_last(int v) {   // lane 63 ends up wi
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ u32 rlu(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
 
+// Table memory is addressed through address-space qualified pointers: global_* for the component
+// arrays in HBM, ds_* for the model tables in LDS.  A flat_* access would make every wait a wait for
+// both kinds.
+typedef __attribute__((address_space(1))) u32 g_u32;
+typedef __attribute__((address_space(1))) u16 g_u16;
+typedef __attribute__((address_space(1))) u8 g_u8;
+typedef __attribute__((address_space(3))) const Tables lds_tables;
+
+// find(): ZSFX/libzpaq.cpp:2064-2080
+__device__ u32 cm_find_g(g_u8* ht, u32 ht_size, int sizebits, u32 cxt) {
+  const u32 chk = (cxt >> sizebits) & 255;
+  const u32 h0 = (cxt * 16) & (ht_size - 16);
+  if (ht[h0] == chk) return h0;
+  const u32 h1 = h0 ^ 16;
+  if (ht[h1] == chk) return h1;
+  const u32 h2 = h0 ^ 32;
+  if (ht[h2] == chk) return h2;
+  u32 r;
+  if (ht[h0 + 1] <= ht[h1 + 1] && ht[h0 + 1] <= ht[h2 + 1]) r = h0;
+  else if (ht[h1 + 1] < ht[h2 + 1]) r = h1;
+  else r = h2;
+  for (int i = 0; i < 16; ++i) ht[r + i] = 0;
+  ht[r] = (u8)chk;
+  return r;
+}
+
 struct WavePred {
-  const Tables* T;
+  lds_tables* T;
   Comp C;              // this lane's component (type NONE beyond n)
+  g_u32* cm; g_u8* ht; g_u16* a16;     // C.cm / C.ht / C.a16 as global pointers
   int p;               // this lane's stretched prediction p[i]
   u32 h;               // this lane's context H[i]
   u32 c8, hmap4;
@@ -454,34 +501,33 @@ struct WavePred {
     switch (C.type) {
       case CM:
         C.cxt = h ^ hmap4;
-        v0 = C.cm[C.cxt & C.cm_mask];
+        v0 = cm[C.cxt & C.cm_mask];
         p = stretch(v0 >> 17);
         break;
       case ICM:
-        if (nib) C.c = cm_find(C.ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
-        C.cxt = C.ht[C.c + (hmap4 & 15)];
-        v0 = C.cm[C.cxt & C.cm_mask];
+        if (nib) C.c = cm_find_g(ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
+        C.cxt = ht[C.c + (hmap4 & 15)];
+        v0 = cm[C.cxt & C.cm_mask];
         p = stretch(v0 >> 8);
         break;
       case MATCH:
         if (C.a == 0) p = 0;
         else {
-          C.c = (C.ht[(C.limit - C.b) & C.ht_mask] >> (7 - C.cxt)) & 1;
+          C.c = (ht[(C.limit - C.b) & C.ht_mask] >> (7 - C.cxt)) & 1;
           p = stretch((u32)(T->dt2k[C.a] * ((int)C.c * -2 + 1)) & 32767u);
         }
         break;
       case MIX2:
         C.cxt = (h + (c8 & C.a5)) & (C.c - 1);
-        v0 = C.a16[C.cxt];
+        v0 = a16[C.cxt];
         break;
       case MIX:
         C.cxt = ((h + (c8 & C.a5)) & (C.c - 1)) * C.a3;
         break;
       case ISSE: {
-        if (nib) C.c = cm_find(C.ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
-        C.cxt = C.ht[C.c + (hmap4 & 15)];
-        const int* wt = (const int*)&C.cm[C.cxt * 2];
-        v0 = (u32)wt[0]; w1 = wt[1];
+        if (nib) C.c = cm_find_g(ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
+        C.cxt = ht[C.c + (hmap4 & 15)];
+        v0 = cm[C.cxt * 2]; w1 = (int)cm[C.cxt * 2 + 1];
       } break;
       case SSE:
         C.cxt = (h + c8) * 32;
@@ -499,7 +545,7 @@ struct WavePred {
       } else if (t == MIX) {
         const int m_in = (int)rlu(C.a3, i);
         const u32 base = rlu(C.cxt, i);
-        const u32* wtab = (const u32*)(((u64)rlu((u32)((u64)C.cm >> 32), i) << 32) | rlu((u32)(u64)C.cm, i));
+        g_u32* wtab = (g_u32*)(((u64)rlu((u32)((u64)cm >> 32), i) << 32) | rlu((u32)(u64)cm, i));
         int term = 0;
         if (lane >= j && lane < j + m_in) term = ((int)wtab[base + (u32)(lane - j)] >> 8) * p;
         const int s = rl(wave_sum_to_last(term), 63);
@@ -520,7 +566,7 @@ struct WavePred {
         pq >>= 6;
         if (lane == i) {
           C.cxt += (u32)pq;
-          const u32 e0 = C.cm[C.cxt & C.cm_mask], e1 = C.cm[(C.cxt + 1) & C.cm_mask];
+          const u32 e0 = cm[C.cxt & C.cm_mask], e1 = cm[(C.cxt + 1) & C.cm_mask];
           p = stretch(((e0 >> 10) * (u32)(64 - wt) + (e1 >> 10) * (u32)wt) >> 13);
           C.cxt += (u32)(wt >> 5);
         }
@@ -533,15 +579,15 @@ struct WavePred {
   int vmerr;           // HCOMP machine fault (uniform)
 
   __device__ void train_entry(int y) {   // train(), ZSFX/libzpaq.h:1151-1157; the product wraps in 32 bits
-    u32& pn = C.cm[C.cxt & C.cm_mask];
-    const u32 cur = pn;
+    g_u32* pn = &cm[C.cxt & C.cm_mask];
+    const u32 cur = *pn;
     const u32 count = cur & 0x3ff;
     const int error = y * 32767 - (int)(cur >> 17);
-    pn = cur + (((u32)error * (u32)T->dt[count] & 0xfffffc00u) + (count < C.limit));
+    *pn = cur + (((u32)error * (u32)T->dt[count] & 0xfffffc00u) + (count < C.limit));
   }
 
   __device__ void update(int y, Vm& z) {   // update0, ZSFX/libzpaq.cpp:1946-2058
-    const u8* ns = T->ns;
+    const __attribute__((address_space(3))) u8* ns = T->ns;
     // MIX: every input lane trains its own weight with the mixer's error
     for (unsigned long long m = dep; m; m &= m - 1) {
       const int i = __builtin_ctzll(m);
@@ -549,10 +595,10 @@ struct WavePred {
       const int j = (int)rlu(C.a2, i), m_in = (int)rlu(C.a3, i);
       const int err = ((y * 32767 - squash(rl(p, i))) * (int)rlu(C.a4, i)) >> 4;
       const u32 base = rlu(C.cxt, i);
-      int* wtab = (int*)(((u64)rlu((u32)((u64)C.cm >> 32), i) << 32) | rlu((u32)(u64)C.cm, i));
+      g_u32* wtab = (g_u32*)(((u64)rlu((u32)((u64)cm >> 32), i) << 32) | rlu((u32)(u64)cm, i));
       if (lane >= j && lane < j + m_in) {
-        int* w = &wtab[base + (u32)(lane - j)];
-        *w = clamp512k(*w + ((err * p + (1 << 12)) >> 13));
+        g_u32* w = &wtab[base + (u32)(lane - j)];
+        *w = (u32)clamp512k((int)*w + ((err * p + (1 << 12)) >> 13));
       }
     }
     // predictions of this lane's input components (they do not change during update); fetched with
@@ -561,24 +607,24 @@ struct WavePred {
     switch (C.type) {
       case CM: train_entry(y); break;
       case ICM: {
-        C.ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
-        u32& pn = C.cm[C.cxt & C.cm_mask];
-        pn += (u32)((int)(y * 32767 - (int)(pn >> 8)) >> 2);
+        ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
+        g_u32* pn = &cm[C.cxt & C.cm_mask];
+        *pn += (u32)((int)(y * 32767 - (int)(*pn >> 8)) >> 2);
       } break;
       case MATCH: {
         if ((int)C.c != y) C.a = 0;
-        u8& cur = C.ht[C.limit & C.ht_mask];
-        cur = (u8)(cur + cur + y);
+        g_u8* cur = &ht[C.limit & C.ht_mask];
+        *cur = (u8)(*cur + *cur + y);
         if (++C.cxt == 8) {
           C.cxt = 0;
           ++C.limit;
           C.limit &= (1u << C.a2) - 1;
           if (C.a == 0) {
-            C.b = C.limit - C.cm[h & C.cm_mask];
+            C.b = C.limit - cm[h & C.cm_mask];
             if (C.b & C.ht_mask)
-              while (C.a < 255 && C.ht[(C.limit - C.a - 1) & C.ht_mask] == C.ht[(C.limit - C.a - C.b - 1) & C.ht_mask]) ++C.a;
+              while (C.a < 255 && ht[(C.limit - C.a - 1) & C.ht_mask] == ht[(C.limit - C.a - C.b - 1) & C.ht_mask]) ++C.a;
           } else C.a += C.a < 255;
-          C.cm[h & C.cm_mask] = C.limit;
+          cm[h & C.cm_mask] = C.limit;
         }
       } break;
       case MIX2: {
@@ -587,14 +633,13 @@ struct WavePred {
         w += (err * (pa2 - pa3) + (1 << 12)) >> 13;
         if (w < 0) w = 0;
         if (w > 65535) w = 65535;
-        C.a16[C.cxt] = (u16)w;
+        a16[C.cxt] = (u16)w;
       } break;
       case ISSE: {
         const int err = y * 32767 - squash(p);
-        int* wt = (int*)&C.cm[C.cxt * 2];
-        wt[0] = clamp512k((int)v0 + ((err * pa2 + (1 << 12)) >> 13));
-        wt[1] = clamp512k(w1 + ((err + 16) >> 5));
-        C.ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
+        cm[C.cxt * 2] = (u32)clamp512k((int)v0 + ((err * pa2 + (1 << 12)) >> 13));
+        cm[C.cxt * 2 + 1] = (u32)clamp512k(w1 + ((err + 16) >> 5));
+        ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
       } break;
       case SSE: train_entry(y); break;
       default: break;
@@ -618,10 +663,11 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
   CmJobDev& J = jobs[blockIdx.x];
   const int lane = (int)threadIdx.x;
   WavePred pr;
-  pr.T = J.T; pr.lane = lane; pr.c8 = 1; pr.hmap4 = 1; pr.v0 = 0; pr.w1 = 0; pr.h = 0;
+  pr.lane = lane; pr.c8 = 1; pr.hmap4 = 1; pr.v0 = 0; pr.w1 = 0; pr.h = 0;
   pr.dep = J.dep; pr.n_last = J.n - 1;
   if ((u32)lane < J.n) { pr.C = J.comp[lane]; pr.p = J.p[lane]; }
   else { memset(&pr.C, 0, sizeof pr.C); pr.p = 0; }
+  pr.cm = (g_u32*)pr.C.cm; pr.ht = (g_u8*)pr.C.ht; pr.a16 = (g_u16*)pr.C.a16;
   // the HCOMP machine runs once per byte on lane 0: its program and (when small) its H[] live in LDS
   __shared__ u8 s_prog[4096];
   __shared__ u32 s_H[1024];
@@ -629,16 +675,16 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
   {
     const u32* src = (const u32*)J.T; u32* dst = (u32*)&s_T;
     for (u32 i = (u32)lane; i < sizeof(Tables) / 4; i += 64) dst[i] = src[i];
-    pr.T = &s_T;
+    pr.T = (lds_tables*)&s_T;
   }
   Vm z = J.vm;
   if (z.plen <= sizeof s_prog) {
     for (u32 i = (u32)lane; i < z.plen; i += 64) s_prog[i] = z.prog[i];
-    z.prog = s_prog;
+    z.prog = s_prog; z.in_lds |= 1;
   }
   if (z.hmask < 1024) {
     for (u32 i = (u32)lane; i <= z.hmask; i += 64) s_H[i] = 0;      // H[] starts zeroed (ZPAQL::init)
-    z.H = s_H;
+    z.H = s_H; z.in_lds |= 2;
   }
   __syncthreads();
   pr.vmerr = 0;
