@@ -214,6 +214,11 @@ int zpq_cm_tables(uint16_t* squash, int16_t* stretch, int32_t* dt, int32_t* dt2k
 int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm,
                       const uint8_t* d_in, uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len);
 
+/* ---- E8E9 pre-processor (row a7) ------------------------------------------------------------- */
+/* libzpaq's e8e9() (ZSFX/libzpaq.cpp:6117-6126) over d_buf[0..n) in place: the x86 CALL/JMP filter
+ * compressBlock applies before modelling when the type hint has the exe bit. */
+int zpq_e8e9_dev(zpq_ctx* ctx, uint8_t* d_buf, size_t n);
+
 /* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */
 /* compressBlock()'s expansion of "0".."5"[B][,R,t] into the x/0 method it stands for
  * (libzpaq 7.15 compressBlock; the snapshot's ZSFX/libzpaq.cpp ends before it, see config.hip).

@@ -175,6 +175,29 @@ def test_fragmenter_other_fragment_settings(eng, fragment, minf, maxf):
 
 
 # ---------------------------------------------------------------------------------------------------
+# row a7: E8E9 pre-processor, against the REAL reference e8e9() (oracle/_ref) and the restatement
+# ---------------------------------------------------------------------------------------------------
+def test_e8e9_forward_equals_reference(eng):
+    rng = np.random.default_rng(88)
+    cases = [b"", b"\xe8", b"\xe8\0\0\0\0", b"\xe9\x01\x02\x03\xff", bytes([0xe8]) * 5000, b"\xe8\xff" * 3000, b"\xe8\x00\xe9\xff\xff" * 2000]
+    # x86-like: opcodes every few bytes, high operand byte 00/ff often, chains of adjacent opcodes
+    a = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    idx = rng.integers(0, len(a) - 8, 400000)
+    a[idx] = np.where(rng.integers(0, 2, len(idx)) == 0, 0xe8, 0xe9)
+    a[idx + 4] = np.where(rng.integers(0, 3, len(idx)) == 0, 0xff, 0x00)
+    cases.append(a.tobytes())
+    b = rng.integers(0, 4, 1 << 20, dtype=np.uint8)
+    cases.append(bytes(np.choose(b, [0xe8, 0xe9, 0x00, 0xff]).astype(np.uint8)))      # dense chains
+    cases.append(datagen.binary_like((1 << 20) + 3, 89))
+    for c in cases:
+        got = eng.e8e9(c)
+        assert got == orc.e8e9(c)
+        if orc.have_ref():
+            assert got == orc.ref_e8e9(c)
+        assert orc.e8e9_inverse(got) == c
+
+
+# ---------------------------------------------------------------------------------------------------
 # row a3: dedup
 # ---------------------------------------------------------------------------------------------------
 def test_dedup_first_occurrence(eng):

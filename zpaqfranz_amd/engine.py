@@ -100,6 +100,7 @@ def load():
     L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_compress_blocks.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_decompress_blocks.argtypes = [C.c_void_p, C.POINTER(UnblockJob), C.c_size_t, C.c_int]
+    L.zpq_e8e9_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.zpq_expand_method.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.zpq_make_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zpq_compile_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -215,6 +216,12 @@ class Engine:
         return self.alloc(len(data)).upload(data)
 
     # ---- hashing ------------------------------------------------------------------------------
+    def e8e9(self, data):
+        """libzpaq e8e9() on the device (host convenience used by the tests)."""
+        d = self.upload(data)
+        self._ck(self.L.zpq_e8e9_dev(self.ctx, d.ptr, len(data)))
+        return d.download(len(data))
+
     def sha1_many(self, bufs):
         return self._many(bufs, 20, self.L.zpq_sha1_many)
 
