@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_parity.py -x -q --durations=3 -k "e8e9" > gpurun_out/t4.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t4.log
+ZPQ_CM_STATS=1 timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -s -k "level5_prefix" > gpurun_out/t4.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t4.log

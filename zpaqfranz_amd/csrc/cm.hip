@@ -481,6 +481,19 @@ __device__ u32 cm_find_g(g_u8* ht, u32 ht_size, int sizebits, u32 cxt) {
   return r;
 }
 
+// All memory a bit decision needs is fetched in ONE round: every address is computed first, then every
+// lane issues its loads back to back with no branch in between (a load behind a divergent branch is
+// waited for before the next branch may issue its own) -- the table entry of a CM/ICM, the weight pair
+// of an ISSE, the weight of a MIX2, the weight each lane contributes to each of the (up to kMaxMix)
+// mixers, its entry of the 33-entry row of each of the (up to kMaxSse) SSE stages.  Bit-history buckets
+// (ICM/ISSE) are fetched once per nibble -- the three candidate rows of find() in one round -- and the
+// chosen 16-byte row then lives in registers.  After the bit is known nothing is loaded: every new
+// value is computed from registers and stored without waiting.
+constexpr int kMaxMix = 4, kMaxSse = 2;
+__device__ unsigned long long g_cm_prof[8];   // ZPQ_CM_STATS=1: cycles in find / addresses+loads / leaves / dependents / update / vm / total / bytes
+typedef __attribute__((address_space(1))) u64_u g_u64_u;
+typedef __attribute__((address_space(1))) u32x4_u g_u32x4_u;
+
 struct WavePred {
   lds_tables* T;
   Comp C;              // this lane's component (type NONE beyond n)
@@ -488,70 +501,161 @@ struct WavePred {
   int p;               // this lane's stretched prediction p[i]
   u32 h;               // this lane's context H[i]
   u32 c8, hmap4;
-  u32 v0;              // value loaded for the prediction (CM/ICM/SSE: table entry; ISSE: weight 0; MIX2: weight)
-  int w1;              // ISSE weight 1
+  u32 va, vb;          // round A: table entry (CM, ICM), weights (ISSE: va, vb), weight (MIX2)
+  g_u8* pa;            // where va came from
+  u32 row[4];          // ICM/ISSE: the bucket of this nibble (ht[C.c .. C.c+15])
+  u32 st;              // ICM/ISSE: bit-history state of this bit
+  u32 mbyte;           // MATCH: the predicted byte
+  u32 mcur;            // MATCH: the byte being assembled
+  int wm[kMaxMix]; g_u32* pm[kMaxMix];        // this lane's weight in mixer slot k, and its address
+  u32 se[kMaxSse];                            // lane l holds entry l of SSE slot k's row
   unsigned long long dep;   // components whose prediction depends on earlier ones, in order
+  g_u8* dummy;         // any readable 64 bytes in HBM
   int lane;
+  u32 n_last;          // index of the last component (the model's output)
+  int vmerr;           // HCOMP machine fault (uniform)
+  unsigned long long prof[6];
 
-  __device__ int squash(int x) const { return T->squash[x + 2048]; }
-  __device__ int stretch(u32 x) const { return T->stretch[x]; }
+  __device__ __forceinline__ int squash(int x) const { return T->squash[x + 2048]; }
+  __device__ __forceinline__ int stretch(u32 x) const { return T->stretch[x]; }
+  __device__ __forceinline__ static u32 row_get(const u32 (&r)[4], u32 idx) {
+    const u32 w = idx < 4 ? r[0] : idx < 8 ? r[1] : idx < 12 ? r[2] : r[3];
+    return (w >> (8 * (idx & 3))) & 255u;
+  }
+  __device__ __forceinline__ static void row_set(u32 (&r)[4], u32 idx, u32 v) {
+    // value selects only: a select between ADDRESSES of the four words would push the whole predictor
+    // out of registers into scratch memory
+    const u32 sh = 8 * (idx & 3), m = ~(255u << sh), x = v << sh, k = idx >> 2;
+    const u32 n0 = (r[0] & m) | x, n1 = (r[1] & m) | x, n2 = (r[2] & m) | x, n3 = (r[3] & m) | x;
+    r[0] = k == 0 ? n0 : r[0]; r[1] = k == 1 ? n1 : r[1]; r[2] = k == 2 ? n2 : r[2]; r[3] = k == 3 ? n3 : r[3];
+  }
+  __device__ __forceinline__ static g_u32* lane_ptr(g_u32* q, int i) {      // lane i's pointer, on every lane
+    return (g_u32*)(((u64)rlu((u32)((u64)q >> 32), i) << 32) | rlu((u32)(u64)q, i));
+  }
 
-  __device__ int predict() {            // predict0, ZSFX/libzpaq.cpp:1846-1943
-    const bool nib = c8 == 1 || (c8 & 0xf0) == 16;
+  // find() (ZSFX/libzpaq.cpp:2064-2080) for every ICM/ISSE lane at once: the three candidate buckets
+  // arrive together, the choice and the replacement are register work, a replaced bucket is stored
+  __device__ __forceinline__ void find_rows() {
+    const bool mine = C.type == ICM || C.type == ISSE;
+    const u32 cxt = h + 16 * c8;
+    const u32 chk = (cxt >> (C.a1 + 2)) & 255;
+    const u32 h0 = (cxt * 16) & (C.ht_mask + 1 - 16), h1 = h0 ^ 16, h2 = h0 ^ 32;
+    g_u8* base = mine ? ht : dummy;
+    const u32x4 r0 = *(const g_u32x4_u*)(base + (mine ? h0 : 0));
+    const u32x4 r1 = *(const g_u32x4_u*)(base + (mine ? h1 : 16));
+    const u32x4 r2 = *(const g_u32x4_u*)(base + (mine ? h2 : 32));
+    if (!mine) return;
+    u32 sel;
+    bool fresh = false;
+    if ((r0.x & 255) == chk) sel = 0;
+    else if ((r1.x & 255) == chk) sel = 1;
+    else if ((r2.x & 255) == chk) sel = 2;
+    else {
+      const u32 q0 = (r0.x >> 8) & 255, q1 = (r1.x >> 8) & 255, q2 = (r2.x >> 8) & 255;
+      sel = (q0 <= q1 && q0 <= q2) ? 0 : (q1 < q2 ? 1 : 2);
+      fresh = true;
+    }
+    C.c = sel == 0 ? h0 : sel == 1 ? h1 : h2;
+    if (fresh) {
+      row[0] = chk; row[1] = row[2] = row[3] = 0;
+      u32x4 z; z.x = chk; z.y = z.z = z.w = 0;
+      *(g_u32x4_u*)(ht + C.c) = z;
+    } else {
+      const u32x4 r = sel == 0 ? r0 : sel == 1 ? r1 : r2;
+      row[0] = r.x; row[1] = r.y; row[2] = r.z; row[3] = r.w;
+    }
+  }
+
+  __device__ __forceinline__ int predict() {            // predict0, ZSFX/libzpaq.cpp:1846-1943
+    unsigned long long tq = __builtin_readcyclecounter();
+    if (c8 == 1 || (c8 & 0xf0) == 16) find_rows();
+    { const unsigned long long t = __builtin_readcyclecounter(); prof[0] += t - tq; tq = t; }
+    // ---- every address first ---------------------------------------------------------------------
+    pa = dummy;
     switch (C.type) {
-      case CM:
-        C.cxt = h ^ hmap4;
-        v0 = cm[C.cxt & C.cm_mask];
-        p = stretch(v0 >> 17);
-        break;
-      case ICM:
-        if (nib) C.c = cm_find_g(ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
-        C.cxt = ht[C.c + (hmap4 & 15)];
-        v0 = cm[C.cxt & C.cm_mask];
-        p = stretch(v0 >> 8);
-        break;
+      case CM: C.cxt = h ^ hmap4; pa = (g_u8*)&cm[C.cxt & C.cm_mask]; break;
+      case ICM: st = row_get(row, hmap4 & 15); C.cxt = st; pa = (g_u8*)&cm[st & C.cm_mask]; break;
+      case ISSE: st = row_get(row, hmap4 & 15); C.cxt = st; pa = (g_u8*)&cm[st * 2]; break;
+      case MIX2: C.cxt = (h + (c8 & C.a5)) & (C.c - 1); pa = (g_u8*)&a16[C.cxt]; break;
+      case MIX: C.cxt = ((h + (c8 & C.a5)) & (C.c - 1)) * C.a3; break;
+      case SSE: C.cxt = (h + c8) * 32; break;
+      default: break;
+    }
+    g_u32* ps[kMaxSse];
+#pragma unroll
+    for (int s = 0; s < kMaxMix; ++s) pm[s] = (g_u32*)dummy;
+#pragma unroll
+    for (int s = 0; s < kMaxSse; ++s) ps[s] = (g_u32*)dummy;
+    {
+      int kmix = 0, ksse = 0;
+      for (unsigned long long m = dep; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        const u32 t = rlu(C.type, i);
+        if (t == MIX) {
+          const int j = (int)rlu(C.a2, i), m_in = (int)rlu(C.a3, i);
+          const int k = lane - j;
+          g_u32* q = lane_ptr(cm, i) + rlu(C.cxt, i) + (u32)((k >= 0 && k < m_in) ? k : 0);
+#pragma unroll
+          for (int s = 0; s < kMaxMix; ++s) if (s == kmix) pm[s] = q;
+          ++kmix;
+        } else if (t == SSE) {
+          g_u32* q = lane_ptr(cm, i) + ((rlu(C.cxt, i) + (u32)(lane < 33 ? lane : 32)) & rlu(C.cm_mask, i));
+#pragma unroll
+          for (int s = 0; s < kMaxSse; ++s) if (s == ksse) ps[s] = q;
+          ++ksse;
+        }
+      }
+    }
+    // ---- round A: every load of this bit, back to back ---------------------------------------------
+    {
+      const u64 two = *(const g_u64_u*)pa;
+      u32 t0[kMaxMix], t1[kMaxSse];
+#pragma unroll
+      for (int s = 0; s < kMaxMix; ++s) t0[s] = *pm[s];
+#pragma unroll
+      for (int s = 0; s < kMaxSse; ++s) t1[s] = *ps[s];
+      va = (u32)two; vb = (u32)(two >> 32);
+#pragma unroll
+      for (int s = 0; s < kMaxMix; ++s) wm[s] = (int)t0[s];
+#pragma unroll
+      for (int s = 0; s < kMaxSse; ++s) se[s] = t1[s];
+    }
+    { const unsigned long long t = __builtin_readcyclecounter(); prof[1] += t - tq; tq = t; }
+    // ---- leaves --------------------------------------------------------------------------------------
+    switch (C.type) {
+      case CM: p = stretch(va >> 17); break;
+      case ICM: p = stretch(va >> 8); break;
       case MATCH:
         if (C.a == 0) p = 0;
         else {
-          C.c = (ht[(C.limit - C.b) & C.ht_mask] >> (7 - C.cxt)) & 1;
+          C.c = (mbyte >> (7 - C.cxt)) & 1;
           p = stretch((u32)(T->dt2k[C.a] * ((int)C.c * -2 + 1)) & 32767u);
         }
         break;
-      case MIX2:
-        C.cxt = (h + (c8 & C.a5)) & (C.c - 1);
-        v0 = a16[C.cxt];
-        break;
-      case MIX:
-        C.cxt = ((h + (c8 & C.a5)) & (C.c - 1)) * C.a3;
-        break;
-      case ISSE: {
-        if (nib) C.c = cm_find_g(ht, C.ht_mask + 1, C.a1 + 2, h + 16 * c8);
-        C.cxt = ht[C.c + (hmap4 & 15)];
-        v0 = cm[C.cxt * 2]; w1 = (int)cm[C.cxt * 2 + 1];
-      } break;
-      case SSE:
-        C.cxt = (h + c8) * 32;
-        break;
+      case MIX2: va &= 0xffffu; break;    // 2-byte entry (the load started at its address)
       default: break;
     }
-    // dependent components, in index order
+    { const unsigned long long t = __builtin_readcyclecounter(); prof[2] += t - tq; tq = t; }
+    // ---- dependent components, in index order (registers only) ---------------------------------------
+    int kmix = 0, ksse = 0;
     for (unsigned long long m = dep; m; m &= m - 1) {
       const int i = __builtin_ctzll(m);
       const u32 t = rlu(C.type, i);
       const int j = (int)rlu(C.a2, i);
       if (t == ISSE) {
-        const int r = clamp2k(((int)rlu(v0, i) * rl(p, j) + rl(w1, i) * 64) >> 16);
+        const int r = clamp2k(((int)rlu(va, i) * rl(p, j) + (int)rlu(vb, i) * 64) >> 16);
         if (lane == i) p = r;
       } else if (t == MIX) {
         const int m_in = (int)rlu(C.a3, i);
-        const u32 base = rlu(C.cxt, i);
-        g_u32* wtab = (g_u32*)(((u64)rlu((u32)((u64)cm >> 32), i) << 32) | rlu((u32)(u64)cm, i));
-        int term = 0;
-        if (lane >= j && lane < j + m_in) term = ((int)wtab[base + (u32)(lane - j)] >> 8) * p;
-        const int s = rl(wave_sum_to_last(term), 63);
-        if (lane == i) p = clamp2k(s >> 8);
+        int w = 0;
+#pragma unroll
+        for (int s = 0; s < kMaxMix; ++s) if (s == kmix) w = wm[s];
+        ++kmix;
+        const int term = (lane >= j && lane < j + m_in) ? (w >> 8) * p : 0;
+        const int sum = rl(wave_sum_to_last(term), 63);
+        if (lane == i) p = clamp2k(sum >> 8);
       } else if (t == MIX2) {
-        const int w = (int)rlu(v0, i);
+        const int w = (int)rlu(va, i);
         const int r = (w * rl(p, j) + (65536 - w) * rl(p, (int)rlu(C.a3, i))) >> 16;
         if (lane == i) p = r;
       } else if (t == AVG) {
@@ -559,63 +663,65 @@ struct WavePred {
         const int r = (rl(p, a1) * wgt + rl(p, j) * (256 - wgt)) >> 8;
         if (lane == i) p = r;
       } else if (t == SSE) {
+        u32 e = 0;
+#pragma unroll
+        for (int s = 0; s < kMaxSse; ++s) if (s == ksse) e = se[s];
+        ++ksse;
         int pq = rl(p, j) + 992;
         if (pq < 0) pq = 0;
         if (pq > 1983) pq = 1983;
         const int wt = pq & 63;
         pq >>= 6;
+        const u32 e0 = rlu(e, pq), e1 = rlu(e, pq + 1);
         if (lane == i) {
           C.cxt += (u32)pq;
-          const u32 e0 = cm[C.cxt & C.cm_mask], e1 = cm[(C.cxt + 1) & C.cm_mask];
           p = stretch(((e0 >> 10) * (u32)(64 - wt) + (e1 >> 10) * (u32)wt) >> 13);
           C.cxt += (u32)(wt >> 5);
+          va = (wt >> 5) ? e1 : e0;                    // the entry train() will touch
         }
       }
     }
+    { const unsigned long long t = __builtin_readcyclecounter(); prof[3] += t - tq; }
     return squash(rl(p, (int)n_last));
   }
 
-  u32 n_last;          // index of the last component (the model's output)
-  int vmerr;           // HCOMP machine fault (uniform)
-
-  __device__ void train_entry(int y) {   // train(), ZSFX/libzpaq.h:1151-1157; the product wraps in 32 bits
-    g_u32* pn = &cm[C.cxt & C.cm_mask];
-    const u32 cur = *pn;
+  __device__ __forceinline__ u32 trained(u32 cur, int y, u32 limit) const {   // train(), ZSFX/libzpaq.h:1151-1157 (wraps in 32 bits)
     const u32 count = cur & 0x3ff;
     const int error = y * 32767 - (int)(cur >> 17);
-    *pn = cur + (((u32)error * (u32)T->dt[count] & 0xfffffc00u) + (count < C.limit));
+    return cur + (((u32)error * (u32)T->dt[count] & 0xfffffc00u) + (count < limit));
   }
 
-  __device__ void update(int y, Vm& z) {   // update0, ZSFX/libzpaq.cpp:1946-2058
+  __device__ __forceinline__ void update(int y, Vm& z) {   // update0, ZSFX/libzpaq.cpp:1946-2058 -- stores only
     const __attribute__((address_space(3))) u8* ns = T->ns;
-    // MIX: every input lane trains its own weight with the mixer's error
+    unsigned long long tq = __builtin_readcyclecounter();
+    int kmix = 0;
     for (unsigned long long m = dep; m; m &= m - 1) {
       const int i = __builtin_ctzll(m);
       if (rlu(C.type, i) != MIX) continue;
       const int j = (int)rlu(C.a2, i), m_in = (int)rlu(C.a3, i);
       const int err = ((y * 32767 - squash(rl(p, i))) * (int)rlu(C.a4, i)) >> 4;
-      const u32 base = rlu(C.cxt, i);
-      g_u32* wtab = (g_u32*)(((u64)rlu((u32)((u64)cm >> 32), i) << 32) | rlu((u32)(u64)cm, i));
-      if (lane >= j && lane < j + m_in) {
-        g_u32* w = &wtab[base + (u32)(lane - j)];
-        *w = (u32)clamp512k((int)*w + ((err * p + (1 << 12)) >> 13));
-      }
+      int w = 0; g_u32* q = (g_u32*)dummy;
+#pragma unroll
+      for (int s = 0; s < kMaxMix; ++s) if (s == kmix) { w = wm[s]; q = pm[s]; }
+      ++kmix;
+      if (lane >= j && lane < j + m_in) *q = (u32)clamp512k(w + ((err * p + (1 << 12)) >> 13));
     }
-    // predictions of this lane's input components (they do not change during update); fetched with
-    // every lane active, a cross-lane read inside the divergent switch would see inactive sources
+    // predictions of this lane's input components, fetched with every lane active
     const int pa2 = __shfl(p, (int)(C.a2 & 63)), pa3 = __shfl(p, (int)(C.a3 & 63));
     switch (C.type) {
-      case CM: train_entry(y); break;
+      case CM: *(g_u32*)pa = trained(va, y, C.limit); break;
       case ICM: {
-        ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
-        g_u32* pn = &cm[C.cxt & C.cm_mask];
-        *pn += (u32)((int)(y * 32767 - (int)(*pn >> 8)) >> 2);
+        const u32 nst = ns[st * 4 + y];
+        row_set(row, hmap4 & 15, nst);
+        ht[C.c + (hmap4 & 15)] = (u8)nst;
+        *(g_u32*)pa = va + (u32)((int)(y * 32767 - (int)(va >> 8)) >> 2);
       } break;
       case MATCH: {
         if ((int)C.c != y) C.a = 0;
-        g_u8* cur = &ht[C.limit & C.ht_mask];
-        *cur = (u8)(*cur + *cur + y);
+        mcur = (mcur + mcur + (u32)y) & 255u;
         if (++C.cxt == 8) {
+          ht[C.limit & C.ht_mask] = (u8)mcur;
+          mcur = 0;
           C.cxt = 0;
           ++C.limit;
           C.limit &= (1u << C.a2) - 1;
@@ -625,11 +731,12 @@ struct WavePred {
               while (C.a < 255 && ht[(C.limit - C.a - 1) & C.ht_mask] == ht[(C.limit - C.a - C.b - 1) & C.ht_mask]) ++C.a;
           } else C.a += C.a < 255;
           cm[h & C.cm_mask] = C.limit;
+          mbyte = ht[(C.limit - C.b) & C.ht_mask];
         }
       } break;
       case MIX2: {
         const int err = ((y * 32767 - squash(p)) * (int)C.a4) >> 5;
-        int w = (int)v0;
+        int w = (int)va;
         w += (err * (pa2 - pa3) + (1 << 12)) >> 13;
         if (w < 0) w = 0;
         if (w > 65535) w = 65535;
@@ -637,13 +744,17 @@ struct WavePred {
       } break;
       case ISSE: {
         const int err = y * 32767 - squash(p);
-        cm[C.cxt * 2] = (u32)clamp512k((int)v0 + ((err * pa2 + (1 << 12)) >> 13));
-        cm[C.cxt * 2 + 1] = (u32)clamp512k(w1 + ((err + 16) >> 5));
-        ht[C.c + (hmap4 & 15)] = ns[C.cxt * 4 + y];
+        g_u32* wt = (g_u32*)pa;
+        wt[0] = (u32)clamp512k((int)va + ((err * pa2 + (1 << 12)) >> 13));
+        wt[1] = (u32)clamp512k((int)vb + ((err + 16) >> 5));
+        const u32 nst = ns[st * 4 + y];
+        row_set(row, hmap4 & 15, nst);
+        ht[C.c + (hmap4 & 15)] = (u8)nst;
       } break;
-      case SSE: train_entry(y); break;
+      case SSE: cm[C.cxt & C.cm_mask] = trained(va, y, C.limit); break;
       default: break;
     }
+    { const unsigned long long t = __builtin_readcyclecounter(); prof[4] += t - tq; tq = t; }
     c8 += c8 + (u32)y;
     if (c8 >= 256) {
       if (lane == 0) vm_run(z, c8 - 256);
@@ -653,21 +764,31 @@ struct WavePred {
       hmap4 = 1;
       c8 = 1;
       h = ((volatile u32*)z.H)[(u32)lane & z.hmask];
+      prof[5] += __builtin_readcyclecounter() - tq;
     } else if (c8 >= 16 && c8 < 32) hmap4 = (hmap4 & 0xf) << 5 | (u32)y << 4 | 1;
     else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (u32)y) & 0xf);
   }
-
 };
 
 __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode) {
   CmJobDev& J = jobs[blockIdx.x];
   const int lane = (int)threadIdx.x;
   WavePred pr;
-  pr.lane = lane; pr.c8 = 1; pr.hmap4 = 1; pr.v0 = 0; pr.w1 = 0; pr.h = 0;
+  pr.lane = lane; pr.c8 = 1; pr.hmap4 = 1; pr.va = 0; pr.vb = 0; pr.h = 0;
   pr.dep = J.dep; pr.n_last = J.n - 1;
+  pr.dummy = (g_u8*)J.T; pr.pa = pr.dummy; pr.st = 0; pr.mcur = 0;
+  pr.row[0] = pr.row[1] = pr.row[2] = pr.row[3] = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxMix; ++k) { pr.wm[k] = 0; pr.pm[k] = (g_u32*)pr.dummy; }
+#pragma unroll
+  for (int k = 0; k < kMaxSse; ++k) pr.se[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pr.prof[k] = 0;
+  const unsigned long long tk_ = __builtin_readcyclecounter();
   if ((u32)lane < J.n) { pr.C = J.comp[lane]; pr.p = J.p[lane]; }
   else { memset(&pr.C, 0, sizeof pr.C); pr.p = 0; }
   pr.cm = (g_u32*)pr.C.cm; pr.ht = (g_u8*)pr.C.ht; pr.a16 = (g_u16*)pr.C.a16;
+  pr.mbyte = pr.C.type == MATCH ? pr.ht[0] : 0;      // (limit - b) & mask == 0 at the start
   // the HCOMP machine runs once per byte on lane 0: its program and (when small) its H[] live in LDS
   __shared__ u8 s_prog[4096];
   __shared__ u32 s_H[1024];
@@ -738,7 +859,13 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
     if (bad) status = ZPQ_ERR_FORMAT;
   }
   if (pr.vmerr) status = ZPQ_ERR_FORMAT;
-  if (lane == 0) { J.result[0] = op; J.result[1] = (u32)status; }
+  if (lane == 0) {
+    J.result[0] = op; J.result[1] = (u32)status;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_cm_prof[k], pr.prof[k]);
+    atomicAdd(&g_cm_prof[6], __builtin_readcyclecounter() - tk_);
+    atomicAdd(&g_cm_prof[7], (unsigned long long)(encode ? J.in_len : op));
+  }
 }
 
 // Component array initialisation (Predictor::init, ZSFX/libzpaq.cpp:1757-1845), parallel over elements.
@@ -947,13 +1074,23 @@ int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
   }
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   bool wave_ok = getenv("ZPQ_CM_ONE_LANE") == nullptr;
-  for (size_t i = 0; i < njobs; ++i) if (ph[i].n > 64) wave_ok = false;
+  for (size_t i = 0; i < njobs; ++i) {
+    int nm = 0, nsse = 0;
+    for (auto& c : ph[i].comps) { nm += c[0] == MIX; nsse += c[0] == SSE; }
+    if (ph[i].n > 64 || nm > kMaxMix || nsse > kMaxSse) wave_ok = false;
+  }
   if (wave_ok) ZPQ_LAUNCH(ctx, "cm_wave_kernel", st, cm_wave_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
   else ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
   ZPQ_HIP(ctx, hipGetLastError());
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  if (getenv("ZPQ_CM_STATS")) {
+    unsigned long long c[8] = {0};
+    (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cm_prof), sizeof c);
+    fprintf(stderr, "[cm stats] cumulative cycles: find=%llu loads=%llu leaves=%llu dependents=%llu update=%llu vm=%llu total=%llu bytes=%llu\n",
+            c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+  }
   int first = ZPQ_OK;
   for (size_t i = 0; i < njobs; ++i) {
     jobs[i].out_len = res[2 * i];
