@@ -71,8 +71,19 @@ struct LzJobDev {
 };
 
 __device__ __forceinline__ int lg32(u32 x) { return x ? 32 - __builtin_clz(x) : 0; }  // lg(), :6224-6233
-__device__ __forceinline__ u64 load8(const u8* p) { return *(const u64_u*)p; }
-__device__ __forceinline__ u32x4 load16(const u8* p) { return *(const u32x4_u*)p; }
+// Input, hash tables and token lists are addressed as GLOBAL memory, the collision masks as LDS: with generic
+// pointers every access becomes a flat_* instruction, and a wait for one kind then waits for the other too --
+// this parse is bound by exactly those waits.
+typedef __attribute__((address_space(1))) const u8 g_cu8;
+typedef __attribute__((address_space(1))) u32 g_u32;
+typedef __attribute__((address_space(1))) const u32 g_cu32;
+typedef __attribute__((address_space(1))) const u64 g_cu64;
+typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
+typedef __attribute__((address_space(1))) const u64_u g_cu64_u;
+typedef __attribute__((address_space(1))) const u32x4_u g_cu32x4_u;
+typedef __attribute__((address_space(3))) unsigned long long l_u64;
+__device__ __forceinline__ u64 load8(g_cu8* p) { return *(g_cu64_u*)p; }
+__device__ __forceinline__ u32x4 load16(g_cu8* p) { return *(g_cu32x4_u*)p; }
 
 // h1 as LZBuffer holds it when it reaches position q (:6444): the rolling hash over the last
 // minMatch update steps, i.e. over in[U..U+minMatch-1] with U = min(q, upd_limit); partial for U < minMatch.
@@ -82,7 +93,8 @@ __device__ __forceinline__ u32 hash_at(const LzCfg& C, u32 q) {
   const u32 F = 5u << C.shift1;
   u32 h = 0;
   const u32 t0 = U > mm ? U - mm : 0;
-  for (u32 t = t0; t < U; ++t) h = h * F + (C.in[t + mm] + 1u) * 123456791u;
+  g_cu8* in = (g_cu8*)C.in;
+  for (u32 t = t0; t < U; ++t) h = h * F + (in[t + mm] + 1u) * 123456791u;
   return h & ((1u << C.htbits) - 1u);
 }
 
@@ -112,7 +124,7 @@ __device__ __forceinline__ u32 byte32(const u32x4& lo, const u32x4& hi, u32 idx)
 }
 
 // Whole-wave compare for long matches: 512 bytes per step.  All arguments wave-uniform.
-__device__ __forceinline__ u32 coop_match_len(const u8* in, u32 p, u32 q, u32 limit, u32 from = 0) {
+__device__ __forceinline__ u32 coop_match_len(g_cu8* in, u32 p, u32 q, u32 limit, u32 from = 0) {
   const u32 lane = (u32)lane_id();
   u32 base = from;
   while (base < limit) {
@@ -132,13 +144,13 @@ __device__ __forceinline__ u32 coop_match_len(const u8* in, u32 p, u32 q, u32 li
 }
 
 template <int NB> struct GroupLoad;
-template <> struct GroupLoad<1> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[1]) { e[0] = __builtin_nontemporal_load(p); } };
-template <> struct GroupLoad<2> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[2]) {
-  u64 v = __builtin_nontemporal_load((const u64*)p); e[0] = (u32)v; e[1] = (u32)(v >> 32); } };
-template <> struct GroupLoad<4> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[4]) {
-  u32x4 v = __builtin_nontemporal_load((const u32x4*)p); e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; } };
-template <> struct GroupLoad<8> { static __device__ __forceinline__ void ld(const u32* p, u32 (&e)[8]) {
-  u32x4 v = __builtin_nontemporal_load((const u32x4*)p), w = __builtin_nontemporal_load((const u32x4*)p + 1);
+template <> struct GroupLoad<1> { static __device__ __forceinline__ void ld(g_cu32* p, u32 (&e)[1]) { e[0] = __builtin_nontemporal_load(p); } };
+template <> struct GroupLoad<2> { static __device__ __forceinline__ void ld(g_cu32* p, u32 (&e)[2]) {
+  u64 v = __builtin_nontemporal_load((g_cu64*)p); e[0] = (u32)v; e[1] = (u32)(v >> 32); } };
+template <> struct GroupLoad<4> { static __device__ __forceinline__ void ld(g_cu32* p, u32 (&e)[4]) {
+  u32x4 v = __builtin_nontemporal_load((g_cu32x4*)p); e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; } };
+template <> struct GroupLoad<8> { static __device__ __forceinline__ void ld(g_cu32* p, u32 (&e)[8]) {
+  u32x4 v = __builtin_nontemporal_load((g_cu32x4*)p), w = __builtin_nontemporal_load((g_cu32x4*)p + 1);
   e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w; } };
 
 struct TokSink { u32* pos; u32* len; u32* off; u32 cap; u32 n; };
@@ -158,14 +170,17 @@ struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 // from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
 // matches ends where a speculative match ends and returns that token's index (else -1).
 template <int NB>
-__device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
-                       SpecList* spec, unsigned long long* T) {
+__device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
+                       SpecList* spec, unsigned long long* T_generic) {
   const u32 lane = (u32)lane_id();
-  const u8* in = C.in;
+  g_cu8* in = (g_cu8*)C.in;
+  g_u32* ht = (g_u32*)ht_generic;
+  g_u32* const sink_pos = (g_u32*)sink.pos; g_u32* const sink_len = (g_u32*)sink.len; g_u32* const sink_off = (g_u32*)sink.off;
+  l_u64* T = (l_u64*)T_generic;
   const u32 n = C.n;
   const u32 mask = (1u << C.checkbits) - 1u;
   const u32 mm = C.minMatch;
-  volatile unsigned long long* Tv = T;
+  volatile l_u64* Tv = T;
   const bool fast_hash = mm <= 8;
   const u32 hfrozen = hash_at(C, C.upd_limit);   // h1 once updates have stopped (q > upd_limit)
 #ifdef ZPQ_LZ_PROFILE
@@ -193,7 +208,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
 
     LZ_T(0);
     u32 ent[NB];
-    if (look) GroupLoad<NB>::ld(ht + grp, ent);   // bypasses L1: the table is rewritten by this wave
+    if (look) GroupLoad<NB>::ld((g_cu32*)(ht + grp), ent);   // bypasses L1: the table is rewritten by this wave
     else {
 #pragma unroll
       for (int j = 0; j < NB; ++j) ent[j] = 0;
@@ -202,7 +217,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
     bool superseded = false;
     {
       const u32 tk = (grp >> 3) & 255u;
-      if (inb) atomicOr((unsigned long long*)&T[tk], 1ull << lane);
+      if (inb) __hip_atomic_fetch_or(&T[tk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       __builtin_amdgcn_wave_barrier();
       unsigned long long cm = inb ? Tv[tk] : 0ull;
       cm &= ~(1ull << lane);
@@ -255,7 +270,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
         const u32 p = e >> C.checkbits;
         if (p < q) cp[k] = p;
       }
-      const u8* src = in + (cp[k] != kNoCand ? cp[k] : 0u);
+      g_cu8* src = in + (cp[k] != kNoCand ? cp[k] : 0u);
       ca[k] = load16(src); cb[k] = load16(src + 16);
     }
 #pragma unroll
@@ -382,7 +397,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
         tlen = f ? l1 : l0; toff = f ? o1 : o0;
       }
       if (tlen) {
-        if (lane == 0 && sink.n < sink.cap) { sink.pos[sink.n] = cur; sink.len[sink.n] = tlen; sink.off[sink.n] = toff; }
+        if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
         ++sink.n;
         lit = 0;
         cur += tlen;
@@ -392,7 +407,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht, u32 wbase, u32 x1, 
           int found = -1;
           for (;;) {
             const u32 jj = spec->j + lane;
-            const u32 e = jj < spec->n ? spec->pos[jj] + spec->len[jj] : 0xffffffffu;
+            const u32 e = jj < spec->n ? ((g_cu32*)spec->pos)[jj] + ((g_cu32*)spec->len)[jj] : 0xffffffffu;
             const unsigned long long lt = __ballot(e < E), eq = __ballot(e == E);
             if (eq) { found = (int)(spec->j + (u32)__builtin_ctzll(eq)); break; }
             const u32 adv = (u32)__builtin_popcountll(lt);
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
   const u32 mask = (1u << C.checkbits) - 1u;
   const u32 hi = J.x1 < C.upd_limit ? J.x1 : C.upd_limit;
   for (u32 q = J.x0 + blockIdx.x * 256u + threadIdx.x; q < hi; q += gridDim.x * 256u) {
-    const u64 qb = load8(C.in + q);
+    const u64 qb = load8((g_cu8*)C.in + q);
     const u32 h = (C.minMatch <= 8 && q >= C.minMatch) ? hash_fast(C, qb) : hash_at(C, q);
     const u32 ih = ((q * 1234547u) >> 19) & C.bucket;
     const u32 val = (q << C.checkbits) | ((u32)((qb >> 24) & 255u) & mask);
