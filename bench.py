@@ -61,6 +61,39 @@ def _exchange(sends, recvs, device):
     return {src: t.to(device) for src, t in got.items()}
 
 
+class CollectiveOrder:
+    """With several steps in flight on several threads, every rank must still issue its collectives in ONE order.
+    A step has three collective sections (0: fragment tables, 1: seam fragments, 2: compressed streams); the order is
+    the software-pipeline order  (k,0) (k,1) (k-depth+1, 2)  for k = 0, 1, ...: a fixed function of (steps, depth),
+    hence identical on every rank, and one that lets step k exchange its tables before step k-1 has finished
+    compressing.  A section holds the turn until its transfers have completed."""
+
+    def __init__(self, steps, depth):
+        import threading
+        self.seq = []
+        for k in range(steps + depth):
+            for st, sec in ((k, 0), (k, 1), (k - (depth - 1), 2)):
+                if 0 <= st < steps:
+                    self.seq.append((st, sec))
+        self.head = 0
+        self.cv = threading.Condition()
+
+    def enter(self, step, sec):
+        with self.cv:
+            while self.seq[self.head] != (step, sec):
+                self.cv.wait()
+
+    def leave(self):
+        with self.cv:
+            self.head += 1
+            self.cv.notify_all()
+
+
+class _NoOrder:          # single-threaded use (sizing steps, one rank)
+    def enter(self, step, sec): pass
+    def leave(self): pass
+
+
 class Pipeline:
     def __init__(self, eng, device, corpus, copies, rank, world, share=None):
         from zpaqfranz_amd import engine as E
@@ -95,23 +128,33 @@ class Pipeline:
         self.tstream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize()
 
-    def step(self):
-        with torch.cuda.stream(self.tstream):
-            return self._step()
+    def step(self, order=None, idx=0):
+        return self.phase_b(self.phase_a(), order or _NoOrder(), idx)
 
-    def _step(self):
+    def phase_a(self):
+        """Local half of a step: fragment + SHA-1 of every fragment.  No collective, so a helper thread may run it
+        for step i+1 while the main thread is in phase_b of step i (the multi-rank pipeline)."""
+        eng = self.eng
+        with torch.cuda.stream(self.tstream):
+            nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
+                                  self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
+            eng.sha1_extents_dev(self.data.data_ptr(), self.frag_off.data_ptr(), self.frag_len.data_ptr(), nf,
+                                 self.digests.data_ptr())
+            eng.sync()
+        return nf
+
+    def phase_b(self, nf, order, idx):
+        with torch.cuda.stream(self.tstream):
+            return self._rest(nf, order, idx)
+
+    def _rest(self, nf, order, idx):
         eng, E, dev = self.eng, self.E, self.dev
         tsync = self.tstream.synchronize   # waits for THIS pipeline's torch work only (another step may be in flight)
-        # 1. fragment + 2. SHA-1 of every fragment
-        nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
-                              self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
-        eng.sha1_extents_dev(self.data.data_ptr(), self.frag_off.data_ptr(), self.frag_len.data_ptr(), nf,
-                             self.digests.data_ptr())
-        eng.sync()
         dig, flen = self.digests[: nf * 20], self.frag_len[:nf]
         my_lo = 0
         if self.world > 1:
             # exchange: fragment tables (20-byte id + length) of every rank, order-preserving
+            order.enter(idx, 0)
             cnt = torch.tensor([nf], dtype=torch.int64, device=dev)
             cnts = [int(c.item()) for c in _all_gather(cnt)]
             mx = max(cnts)
@@ -123,6 +166,7 @@ class Pipeline:
             my_lo = sum(cnts[: self.rank])
             ntot = sum(cnts)
             tsync()
+            order.leave()
         else:
             cnts, ntot = [nf], nf
         # 3. dedup (global first occurrence)
@@ -159,7 +203,10 @@ class Pipeline:
             for p_, tr in trailers:
                 blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
         if self.world > 1:
+            order.enter(idx, 1)
             self._exchange_seams(P, lens, my_lo, nf, layout, blocks_buf)
+            tsync()
+            order.leave()
         eng.sync(); tsync()
         # 5. compressBlock on every owned block ("14": LZ77 x4,1,5,0,3,24 + framing + SHA-1)
         nb = len(mine)
@@ -197,6 +244,7 @@ class Pipeline:
             self.verify_sample_all = torch.cat(pieces)
         if self.world > 1:
             # the archive is stitched on rank 0 in block order: gather the compressed streams
+            order.enter(idx, 2)
             t = torch.tensor([out_bytes], dtype=torch.int64, device=dev)
             ts = _all_gather(t)
             mx = max(int(x.item()) for x in ts)
@@ -210,6 +258,7 @@ class Pipeline:
             out_bytes = sum(int(x.item()) for x in ts)
             self.gathered = [g[: int(x.item())] for g, x in zip(gathered, ts)]   # rank r's framed blocks, block order
             tsync()
+            order.leave()
         self.stats = dict(fragments=int(ntot), unique_fragments=int(len(uniq_idx)), blocks=int(nblk),
                           unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
         return out_bytes
@@ -284,7 +333,9 @@ def main():
     from zpaqfranz_amd import Engine
     eng = Engine(local)
     corpus = datagen.silesia_like(seed=rank, scale=a.scale)
-    depth = max(1, a.pipeline if world == 1 else 1)       # collectives keep the multi-rank path one step deep
+    # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
+    # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
+    depth = max(1, a.pipeline)
     pipes = [Pipeline(eng, dev, corpus, a.copies, rank, world)]
     engines = [eng]
     for _ in range(1, depth):
@@ -309,17 +360,27 @@ def main():
         import threading
         nxt, lock, outs, errs = [0], threading.Lock(), [0] * n, []
 
+        order = CollectiveOrder(n, depth) if world > 1 else _NoOrder()
+
         def worker(p_, delay):
             try:
+                torch.cuda.set_device(local)     # the current device is per host thread
                 time.sleep(delay)      # stagger: one step's chip-wide kernels against the other's latency-bound tail
                 while True:
                     with lock:
                         i = nxt[0]; nxt[0] += 1
                     if i >= n:
                         return
-                    outs[i] = p_.step()
+                    outs[i] = p_.step(order, i)
+                    if i == n - 1:
+                        last_pipe[0] = p_
             except Exception as ex:       # surface worker failures in the main thread
                 errs.append(ex)
+                if world > 1:              # a rank that stops would leave the others waiting in a collective
+                    import traceback
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    os._exit(3)
         if depth == 1:
             worker(pipes[0], 0.0)
         else:
@@ -331,6 +392,7 @@ def main():
         return outs[-1] if n else 0
 
     stagger = [0.0]
+    last_pipe = [pipes[0]]     # the context that ran the last step (its results are the ones dumped / verified)
     if depth > 1:            # one untimed serial step per context sizes its scratch; a second, warm one gives the stagger
         for p_ in pipes:
             p_.step()
@@ -343,6 +405,7 @@ def main():
     out_bytes = run_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
+    pipe = last_pipe[0]
     kern = {}
     for e_ in engines:
         for k_, (c_, m_) in e_.profile_report().items():

@@ -585,12 +585,14 @@ def test_journaling_archive_add_and_extract(eng):
 # process produces for the concatenated inputs: table all-gather, global dedup, ownership, seam exchange.
 # ---------------------------------------------------------------------------------------------------
 def test_two_rank_add_is_bit_identical_to_serial(tmp_path):
+    # (two contexts per rank: phase_a of step i+1 runs on a helper thread beside phase_b of step i, every collective is
+    # issued by the main thread; the archive dumped is the one of the last step, which ran on the second context)
     import subprocess, sys
     from zpaqfranz_amd import sharding
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "two_rank.bin")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--copies", "2",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--copies", "2",
            "--scale", "0.05", "--dist-backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-verify", "--dump-archive", out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]

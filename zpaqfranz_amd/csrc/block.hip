@@ -134,6 +134,7 @@ extern "C" size_t zpq_block_bound(size_t n, const char* filename, const char* co
 }
 
 extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
   std::vector<Config> cfg(njobs);
@@ -303,6 +304,7 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
 }
 
 extern "C" int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   // stage host inputs into one device arena, run the device path, copy framed blocks back
   size_t in_total = 0, out_total = 0;
@@ -334,6 +336,7 @@ extern "C" int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njo
 
 // ---- decode side ----------------------------------------------------------------------------------------
 extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
   // kind: 0 stored+PASS, 2 stored + the known LZ77-L1 PCOMP (native decoder), 3 generic (context-model

@@ -939,6 +939,7 @@ const Tables* device_tables(zpq_ctx* ctx) {
 }
 
 int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
   const Tables* dT = device_tables(ctx);
@@ -1119,6 +1120,7 @@ int zpq_cm_decode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs) { return run
 
 int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm, const uint8_t* d_in,
                       uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (ph > 24 || pm > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "PCOMP memory 2^%u/2^%u too large", ph, pm);
   hipStream_t st = ctx->stream;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

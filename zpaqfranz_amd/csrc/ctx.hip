@@ -14,6 +14,7 @@ int zpq_fail(zpq_ctx* ctx, int status, const char* fmt, ...) {
 }
 
 void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (bytes <= ctx->scratch_cap[slot] && ctx->scratch[slot]) return ctx->scratch[slot];
   if (ctx->scratch[slot]) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipFree(ctx->scratch[slot]); }
   size_t cap = bytes + bytes / 4 + 4096;
@@ -25,6 +26,7 @@ void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes) {
 }
 
 void* zpq_pinned(zpq_ctx* ctx, size_t bytes) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (bytes <= ctx->pinned_cap && ctx->pinned) return ctx->pinned;
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   size_t cap = bytes + bytes / 4 + 4096;
@@ -96,6 +98,7 @@ const char* zpq_strerror(int status) {
 const char* zpq_last_error(const zpq_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
 int zpq_sync(zpq_ctx* ctx) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   return ZPQ_OK;
@@ -153,16 +156,19 @@ int zpq_dev_free(zpq_ctx* ctx, void* dptr) {
   return ZPQ_OK;
 }
 int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   ZPQ_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZPQ_OK;
 }
 int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   ZPQ_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZPQ_OK;
 }
 int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   ZPQ_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
   return ZPQ_OK;
 }

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void dedup_lookup_kernel(const u8* __restrict_
 }  // namespace
 
 extern "C" int zpq_dedup_dev(zpq_ctx* ctx, const uint8_t* d_digests, size_t n, uint32_t* d_first) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   if (n > 0x7fffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many fragments");
   u32 size = 1024;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src_
 
 extern "C" int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uint64_t* d_src_off, const uint32_t* d_len,
                               const uint64_t* d_dst_off, size_t n, uint8_t* d_dst_base) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   // fragments are at most 8128<<fragment bytes; 16 KiB pieces keep the grid balanced
   const u32 pieces = 64;  // covers extents up to 1 MiB; larger extents are rejected by the caller contract

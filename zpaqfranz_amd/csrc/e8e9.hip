@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void e8e9_forward_kernel(u8* __restrict__ buf,
 }  // namespace
 
 extern "C" int zpq_e8e9_dev(zpq_ctx* ctx, uint8_t* d_buf, size_t n) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (!ctx) return ZPQ_ERR_ARG;
   if (n < 5) return ZPQ_OK;
   if (n > 0xffffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "e8e9: offsets are 32-bit in the reference (n <= 2^32-1)");

@@ -530,6 +530,7 @@ size_t zpq_fragment_capacity(const uint64_t* file_off, size_t nfiles, const zpq_
 int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
                      const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
                      size_t frag_cap, size_t* nfrags) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (!ctx || !file_off || !p || !nfrags) return ZPQ_ERR_ARG;
   *nfrags = 0;
   if (nfiles == 0) return ZPQ_OK;

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
 }  // namespace
 
 extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t njobs) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
   u8* d_meta = (u8*)zpq_scratch(ctx, 2, njobs * (sizeof(LzDecDev) + 8) + 64);

@@ -925,6 +925,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
 }
 
 extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   for (size_t i = 0; i < njobs; ++i) {
     int rc = check_args(ctx, jobs[i].args, jobs[i].n);

@@ -230,6 +230,9 @@ __device__ __forceinline__ void sha1_rounds_lane(const u32 (&w)[80], int blk, Sh
 
 __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                         const u32* __restrict__ len, u8* __restrict__ digests) {
+  // a chain is one dependent instruction stream: wherever it lands it must win issue arbitration against the
+  // throughput kernels of other steps sharing the SIMD
+  __builtin_amdgcn_s_setprio(3);
   const u32 idx = blockIdx.x;
   const int lane = lane_id();
   const u8* p = base + off[idx];
@@ -358,6 +361,7 @@ const u32* extent_order(zpq_ctx* ctx, hipStream_t s, const L* d_len, size_t n, i
 
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   // Each chain wants a SIMD to itself (it is bound by dependent-issue latency; a co-resident wave of a
   // concurrent kernel would stretch it, or be stretched by it).  Asking for most of a CU's LDS keeps
@@ -370,7 +374,8 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
   }
   {
     ZpqProfScope prof_scope_(ctx, "sha1_chain_kernel", s);
-    hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), n <= 64 ? hog : 0, s, d_base, d_off, d_len, d_digests);
+    const bool reserve = n <= 64 && getenv("ZPQ_CHAIN_NO_HOG") == nullptr;
+    hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);
   }
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
@@ -378,6 +383,7 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
 
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                         u8* d_digests, const char* prof_name) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
   // one counter per stream so that the two streams never share it
@@ -401,6 +407,7 @@ int zpq_sha1_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_
 
 int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off, const uint64_t* d_len, size_t n,
                            uint8_t* d_digests) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + 32;
@@ -416,6 +423,7 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
 
 // Host convenience wrappers: pack the buffers into one staging area, run the device path.
 static int many(zpq_ctx* ctx, const uint8_t* const* bufs, const size_t* lens, size_t n, uint8_t* digests, int dsz) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   size_t total = 0;
   for (size_t i = 0; i < n; ++i) total += lens[i];
