@@ -22,7 +22,58 @@ struct FileWriter : libzpaq::Writer {
   void write(const char* buf, int n) { fwrite(buf, 1, n, f); }
 };
 
+struct FileReader : libzpaq::Reader {
+  FILE* f;
+  explicit FileReader(FILE* g) : f(g) {}
+  int get() { return getc(f); }
+  int read(char* buf, int n) { return (int)fread(buf, 1, n, f); }
+};
+
+// The extract side exactly as decompressThread drives it (ZSFX/zsfx.cpp:1783-1834): one Decompresser per block,
+// findBlock / findFilename / readComment / decompress(1<<14) ... / readSegmentEnd, SHA-1 of the output through
+// libzpaq::SHA1.  Blocks whose declared size exceeds max_usize are skipped with readSegmentEnd alone.
+static int extract_mode(const char* path, size_t max_usize) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return 3;
+  FileReader in(f);
+  try {
+    for (;;) {
+      libzpaq::Decompresser d;
+      d.setInput(&in);
+      double mem = 0;
+      if (!d.findBlock(&mem)) break;
+      libzpaq::StringBuffer name, comment, out;
+      while (d.findFilename(&name)) {
+        d.readComment(&comment);
+        const size_t declared = strtoull(std::string(comment.c_str(), comment.size()).c_str(), 0, 10);
+        libzpaq::SHA1 sha;
+        char rec[21];
+        bool skipped = declared > max_usize;
+        if (!skipped) {
+          d.setOutput(&out);
+          d.setSHA1(&sha);
+          while (d.decompress(1 << 14)) {}
+        }
+        d.readSegmentEnd(rec);
+        printf("%s|%zu|%s|", std::string(name.c_str(), name.size()).c_str(), out.size(), skipped ? "skipped" : "decoded");
+        const char* h = sha.result();
+        for (int i = 0; i < 20; ++i) printf("%02x", skipped ? 0 : (unsigned char)h[i]);
+        printf("|%d|", rec[0]);
+        for (int i = 1; i <= 20; ++i) printf("%02x", (unsigned char)rec[i]);
+        printf("|%.0f\n", mem);
+      }
+    }
+  } catch (std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    fclose(f);
+    return 5;
+  }
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::string(argv[1]) == "--extract") return extract_mode(argv[2], strtoull(argv[3], 0, 10));
   if (argc < 6) return 2;
   std::vector<char> data;
   {

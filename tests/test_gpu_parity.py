@@ -430,6 +430,32 @@ def test_libzpaq_shim_multithreaded_cpp_caller(tmp_path):
         assert orc.ref_decompress(want, len(data) + 64) == data
 
 
+def test_libzpaq_shim_decompresser_class_reads_fixture_archives(tmp_path):
+    """libzpaq::Decompresser of the shim, driven like decompressThread (ZSFX/zsfx.cpp:1783-1834), over the reference's
+    own archives: names, sizes, output SHA-1 and the stored SHA-1 records must agree; the 9.4 MB context-mixing d block
+    is skipped with readSegmentEnd alone (the skip path), zsfx32.zpaq (23 components) is decoded."""
+    import subprocess
+    from zpaqfranz_amd import build
+    build.build(verbose=False)
+    drv = build.build_shim_driver(str(tmp_path / "shim_driver"))
+    blocks = json.load(open(os.path.join(G, "blocks.json")))
+    r = subprocess.run([drv, "--extract", os.path.join(G, "sha256.zpaq"), "100000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split("|") for l in r.stdout.strip().splitlines()]
+    assert len(lines) == len(blocks)
+    for l, b in zip(lines, blocks):
+        assert l[0] == b["filename"] and l[4] == "1" and l[5] == b["sha1"]
+        if b["usize"] > 100000:
+            assert l[2] == "skipped"
+        else:
+            assert l[2] == "decoded" and int(l[1]) == b["usize"] and l[3] == b["sha1"]
+    r = subprocess.run([drv, "--extract", os.path.join(G, "zsfx32.zpaq"), "1000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    (l,) = [x.split("|") for x in r.stdout.strip().splitlines()]
+    plain = lzma.decompress(open(os.path.join(G, "zsfx32_plain.xz"), "rb").read())
+    assert l[0] == "" and int(l[1]) == len(plain) and l[3] == orc.sha1(plain).hex() == l[5] and float(l[6]) > 5e7
+
+
 def test_fragmenter_fragments_longer_than_a_segment(eng):
     """Fragments that swallow whole 256 KiB speculation segments (no cut inside a segment): incompressible
     data with max-size fragments, and a run whose period defeats the rolling hash."""

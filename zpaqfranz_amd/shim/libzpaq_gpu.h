@@ -6,12 +6,13 @@
 //   SHA1 / SHA256    ZSFX/libzpaq.h:934-979 (put/write/size/usize/result; result() resets)
 //   StringBuffer     ZSFX/libzpaq.h:1377-1494
 //   compressBlock()  ZSFX/libzpaq.h:1505, compress() :1501, decompress() :1268
-// so that a Jidac-style caller (one compressBlock per block per worker thread,
-// ZSFX/zsfx.cpp:1783-1801 on the extract side) links against this header unchanged.
+//   Decompresser     ZSFX/libzpaq.h:1243-1264
+// so that a Jidac-style caller (one compressBlock per block per worker thread; one Decompresser per block on the
+// extract side, ZSFX/zsfx.cpp:1783-1801) links against this header unchanged.
 //
 // What runs where: the byte work (LZ77 level 1, stored framing, block SHA-1, LZ77 inverse) runs in
 // HIP kernels behind the C ABI of include/zpaqhip.h.  Method strings outside the family the engine
-// implements (levels 2..5, E8E9, context-model components) end in libzpaq::error("...") -- there is
+// implements (byte-aligned LZ77, BWT and E8E9 front ends) end in libzpaq::error("...") -- there is
 // no CPU fallback compiled into this library; the host keeps its CPU libzpaq for those if it wants.
 //
 // Batching: compressBlock() blocks the calling thread like the reference's does.  Calls made
@@ -110,6 +111,34 @@ void compress(Reader* in, Writer* out, const char* method, const char* filename 
 
 // Decompress every block of in to out (ZSFX/libzpaq.h:1268); stored SHA-1s are verified.
 void decompress(Reader* in, Writer* out);
+
+// Block-at-a-time reader with the reference's interface and call sequence (ZSFX/libzpaq.h:1243-1264; used as in
+// ZSFX/zsfx.cpp:1783-1801: setInput, setOutput, findBlock, {findFilename, readComment, decompress(n)*, readSegmentEnd}*).
+// The segment is decoded by the engine on the first decompress() call and then handed out n bytes at a time.
+// Blocks with more than one segment (streaming archives that continue a model across files) are refused through
+// error(): the journaling format zpaqfranz writes has one segment per block.
+class Decompresser {
+ public:
+  Decompresser();
+  ~Decompresser();
+  void setInput(Reader* in) { in_ = in; }
+  bool findBlock(double* memptr = 0);       // false at end of input
+  void hcomp(Writer* out2);                 // the block header (hsize .. HCOMP END), as stored
+  bool findFilename(Writer* filename = 0);  // false at the end of the block
+  void readComment(Writer* comment = 0);
+  void setOutput(Writer* out) { out_ = out; }
+  void setSHA1(SHA1* sha1ptr) { sha_ = sha1ptr; }
+  bool decompress(int n = -1);              // n bytes (-1 = all); false once the segment is exhausted
+  bool pcomp(Writer* out2);                 // not retained by this implementation: returns false
+  void readSegmentEnd(char* sha1string = 0);// [0] = 1 if a SHA-1 follows in [1..20], else 0
+  void stat(int) {}
+  int buffered() { return 0; }
+ private:
+  struct Impl;
+  Impl* d_;
+  Reader* in_; Writer* out_; SHA1* sha_;
+  Decompresser(const Decompresser&); void operator=(const Decompresser&);
+};
 
 // Engine plumbing (not in the reference): which GPU this process uses; call before first use.
 void setDevice(int ordinal);
