@@ -78,10 +78,13 @@ class CollectiveOrder:
         self.head = 0
         self.cv = threading.Condition()
 
-    def enter(self, step, sec):
+    def enter(self, step, sec, timeout=600.0):
         with self.cv:
+            t0 = time.monotonic()
             while self.seq[self.head] != (step, sec):
-                self.cv.wait()
+                self.cv.wait(5.0)
+                if time.monotonic() - t0 > timeout:       # fail loudly rather than hang the job
+                    raise RuntimeError("collective order stalled at %r waiting for %r" % (self.seq[self.head], (step, sec)))
 
     def leave(self):
         with self.cv:
