@@ -230,9 +230,6 @@ __device__ __forceinline__ void sha1_rounds_lane(const u32 (&w)[80], int blk, Sh
 
 __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                         const u32* __restrict__ len, u8* __restrict__ digests) {
-  // a chain is one dependent instruction stream: wherever it lands it must win issue arbitration against the
-  // throughput kernels of other steps sharing the SIMD
-  __builtin_amdgcn_s_setprio(3);
   const u32 idx = blockIdx.x;
   const int lane = lane_id();
   const u8* p = base + off[idx];
