@@ -1,0 +1,39 @@
+"""The start-independent fragmenter model (tools/proto/frag_independent.c) must give exactly the
+serial loop's cuts: global (never reset) hash triggers + per-fragment disturbance windows.  CPU only; this is the
+design check for the crossing-free GPU pass, not product code."""
+import os
+import subprocess
+
+import pytest
+
+import datagen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def proto(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("proto") / "frag_proto")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "proto", "frag_independent.c")])
+    return exe
+
+
+CASES = {
+    "text": lambda: datagen.text_like(3 << 20, 1),
+    "binary": lambda: datagen.binary_like(3 << 20, 2),
+    "mixed": lambda: datagen.mixed(4 << 20, 3),
+    "random": lambda: datagen.random_bytes(2 << 20, 4),
+    "zeros": lambda: bytes(3 << 20),
+    "period": lambda: bytes(range(256)) * 6000,
+    "runs": lambda: b"".join(bytes([i % 256]) * 70000 + datagen.text_like(50000, i) for i in range(12)),
+    "tiny": lambda: b"abc",
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("params", [(), ("512", "65024", "19")])
+def test_model_reproduces_the_serial_cuts(proto, tmp_path, name, params):
+    f = tmp_path / "in.bin"
+    f.write_bytes(CASES[name]())
+    r = subprocess.run([proto, str(f), *params], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
