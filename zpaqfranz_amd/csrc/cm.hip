@@ -9,10 +9,10 @@
 // at :1733 and :1739; the bit-history state table from the ZPAQ specification's num_states/next_state
 // rules); tests compare every entry with the reference's literal tables.
 //
-// Round-1 shape: one block = one serial chain of bit decisions; this first version walks it with ONE
-// lane per block (throughput comes from blocks in flight, as on the CPU it comes from threads), all
-// state in HBM except the per-bit scalars.  It is here for coverage and parity; mapping components to
-// lanes and the hot tables to LDS is the planned optimisation.
+// One block = one serial chain of bit decisions.  cm_wave_kernel gives a block a wave and every component a
+// lane (state in registers, tables in LDS, one load round per bit); cm_code_kernel is the plain one-lane
+// walk, kept for models with more than 64 components or more mixers/SSE stages than the wave kernel has
+// register slots for.  Measured split and next steps: DESIGN.md section 7-2.
 #include <math.h>
 #include <stdlib.h>
 
