@@ -95,6 +95,14 @@ def test_method_expansion_table(cfg):
     assert cfg.expand_method("x3,0c0,0,255", b"") == "x3,0c0,0,255"       # explicit methods pass through
 
 
+def test_level5_without_data_is_an_error_not_a_crash(cfg):
+    import ctypes as C
+    L = cfg.load()
+    out = C.create_string_buffer(256)
+    assert L.zpq_expand_method(None, b"5", None, 1000, out, 256) != 0
+    assert L.zpq_expand_method(None, b"5", None, 0, out, 256) == 0 and out.value.startswith(b"x0,0w1i1")
+
+
 def test_unpinned_preprocessors_are_refused(cfg):
     for m in ("x4,2,4,0,3,24", "x4,3ci1", "x4,4ci1", "x4,6,12,0,7,25,1c0,0,511i2", "q1"):
         with pytest.raises(cfg.ConfigRefused):

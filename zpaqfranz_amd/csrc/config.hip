@@ -506,6 +506,7 @@ std::string expand_method(const std::string& method, const u8* data, u32 n) {
       m += "m";
     } else m += "," + itos(3 + doe8) + "ci1";
   } else {
+    if (n && !data) throw ConfigError("levels 5..9 look at the data to choose periodic models: data pointer missing");
     m += "," + itos(doe8);
     if (type & 1) m += "w2c0,1010,255i1"; else m += "w1i1";
     m += "c256ci1,1,1,1,1,1,2a";
