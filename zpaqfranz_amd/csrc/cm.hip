@@ -490,7 +490,17 @@ __device__ u32 cm_find_g(g_u8* ht, u32 ht_size, int sizebits, u32 cxt) {
 // chosen 16-byte row then lives in registers.  After the bit is known nothing is loaded: every new
 // value is computed from registers and stored without waiting.
 constexpr int kMaxMix = 4, kMaxSse = 2;
-__device__ unsigned long long g_cm_prof[8];   // ZPQ_CM_STATS=1: cycles in find / addresses+loads / leaves / dependents / update / vm / total / bytes
+// Cycle-counter statistics per phase (find / addresses+loads / leaves / dependents / update / vm / total / bytes):
+// compiled in with -DZPQ_CM_PROFILE (ZPQ_EXTRA_FLAGS), printed when ZPQ_CM_STATS is set.  Off by default: every
+// s_memtime is a scalar memory operation the wave has to wait for.
+__device__ unsigned long long g_cm_prof[8];
+#ifdef ZPQ_CM_PROFILE
+#define CM_TICK(var) unsigned long long var = __builtin_readcyclecounter()
+#define CM_TOCK(k, var) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[k] += t_ - var; var = t_; }
+#else
+#define CM_TICK(var)
+#define CM_TOCK(k, var)
+#endif
 typedef __attribute__((address_space(1))) u64_u g_u64_u;
 typedef __attribute__((address_space(1))) u32x4_u g_u32x4_u;
 
@@ -567,9 +577,9 @@ struct WavePred {
   }
 
   __device__ __forceinline__ int predict() {            // predict0, ZSFX/libzpaq.cpp:1846-1943
-    unsigned long long tq = __builtin_readcyclecounter();
+    CM_TICK(tq);
     if (c8 == 1 || (c8 & 0xf0) == 16) find_rows();
-    { const unsigned long long t = __builtin_readcyclecounter(); prof[0] += t - tq; tq = t; }
+    CM_TOCK(0, tq)
     // ---- every address first ---------------------------------------------------------------------
     pa = dummy;
     switch (C.type) {
@@ -620,7 +630,7 @@ struct WavePred {
 #pragma unroll
       for (int s = 0; s < kMaxSse; ++s) se[s] = t1[s];
     }
-    { const unsigned long long t = __builtin_readcyclecounter(); prof[1] += t - tq; tq = t; }
+    CM_TOCK(1, tq)
     // ---- leaves --------------------------------------------------------------------------------------
     switch (C.type) {
       case CM: p = stretch(va >> 17); break;
@@ -635,7 +645,7 @@ struct WavePred {
       case MIX2: va &= 0xffffu; break;    // 2-byte entry (the load started at its address)
       default: break;
     }
-    { const unsigned long long t = __builtin_readcyclecounter(); prof[2] += t - tq; tq = t; }
+    CM_TOCK(2, tq)
     // ---- dependent components, in index order (registers only) ---------------------------------------
     int kmix = 0, ksse = 0;
     for (unsigned long long m = dep; m; m &= m - 1) {
@@ -681,7 +691,7 @@ struct WavePred {
         }
       }
     }
-    { const unsigned long long t = __builtin_readcyclecounter(); prof[3] += t - tq; }
+    CM_TOCK(3, tq)
     return squash(rl(p, (int)n_last));
   }
 
@@ -693,7 +703,7 @@ struct WavePred {
 
   __device__ __forceinline__ void update(int y, Vm& z) {   // update0, ZSFX/libzpaq.cpp:1946-2058 -- stores only
     const __attribute__((address_space(3))) u8* ns = T->ns;
-    unsigned long long tq = __builtin_readcyclecounter();
+    CM_TICK(tq);
     int kmix = 0;
     for (unsigned long long m = dep; m; m &= m - 1) {
       const int i = __builtin_ctzll(m);
@@ -754,7 +764,7 @@ struct WavePred {
       case SSE: cm[C.cxt & C.cm_mask] = trained(va, y, C.limit); break;
       default: break;
     }
-    { const unsigned long long t = __builtin_readcyclecounter(); prof[4] += t - tq; tq = t; }
+    CM_TOCK(4, tq)
     c8 += c8 + (u32)y;
     if (c8 >= 256) {
       if (lane == 0) vm_run(z, c8 - 256);
@@ -764,7 +774,7 @@ struct WavePred {
       hmap4 = 1;
       c8 = 1;
       h = ((volatile u32*)z.H)[(u32)lane & z.hmask];
-      prof[5] += __builtin_readcyclecounter() - tq;
+      CM_TOCK(5, tq)
     } else if (c8 >= 16 && c8 < 32) hmap4 = (hmap4 & 0xf) << 5 | (u32)y << 4 | 1;
     else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (u32)y) & 0xf);
   }
@@ -784,7 +794,7 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
   for (int k = 0; k < kMaxSse; ++k) pr.se[k] = 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) pr.prof[k] = 0;
-  const unsigned long long tk_ = __builtin_readcyclecounter();
+  CM_TICK(tk_);
   if ((u32)lane < J.n) { pr.C = J.comp[lane]; pr.p = J.p[lane]; }
   else { memset(&pr.C, 0, sizeof pr.C); pr.p = 0; }
   pr.cm = (g_u32*)pr.C.cm; pr.ht = (g_u8*)pr.C.ht; pr.a16 = (g_u16*)pr.C.a16;
@@ -861,10 +871,12 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
   if (pr.vmerr) status = ZPQ_ERR_FORMAT;
   if (lane == 0) {
     J.result[0] = op; J.result[1] = (u32)status;
+#ifdef ZPQ_CM_PROFILE
 #pragma unroll
     for (int k = 0; k < 6; ++k) atomicAdd(&g_cm_prof[k], pr.prof[k]);
     atomicAdd(&g_cm_prof[6], __builtin_readcyclecounter() - tk_);
     atomicAdd(&g_cm_prof[7], (unsigned long long)(encode ? J.in_len : op));
+#endif
   }
 }
 
