@@ -37,3 +37,20 @@ def test_model_reproduces_the_serial_cuts(proto, tmp_path, name, params):
     f.write_bytes(CASES[name]())
     r = subprocess.run([proto, str(f), *params], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def proto_pages(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("proto2") / "frag_pages")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "proto", "frag_pages.c")])
+    return exe
+
+
+@pytest.mark.parametrize("name", ["text", "binary", "mixed", "random", "tiny"])
+@pytest.mark.parametrize("seg", ["65536", "262144", "344064"])
+def test_page_model_reproduces_the_serial_cuts(proto_pages, tmp_path, name, seg):
+    """Stage 2: page summaries + equal-work lanes + page-by-page chain (tools/proto/frag_pages.c)."""
+    f = tmp_path / "in.bin"
+    f.write_bytes(CASES[name]())
+    r = subprocess.run([proto_pages, str(f), seg], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
