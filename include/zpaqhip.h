@@ -108,6 +108,14 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
                      const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len,
                      uint32_t* d_frag_file, size_t frag_cap, size_t* nfrags);
 
+/* ---- file-level checksums (section 8f-2) ------------------------------------------------------ */
+/* What zpaqfranz stores per file in the i blocks and re-checks on extract / test (README.md:95-105; attribute
+ * layout: SURVEY.md Appendix B.4): CRC-32 (zlib polynomial), XXH64 (seed 0) and, optionally, BLAKE3 (32 bytes).
+ * Files are the extents [file_off[f], file_off[f+1]) of one device buffer (file_off: HOST array, nfiles+1
+ * entries, as for zpq_fragment_dev).  Results go to HOST arrays; any of them may be NULL to skip that hash. */
+int zpq_file_checksums_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                           uint32_t* crc32, uint64_t* xxh64, uint8_t* blake3 /* 32*nfiles */);
+
 /* ---- dedup index (row a3) ------------------------------------------------------------------ */
 /* first[i] = smallest j <= i with digest[j] == digest[i] (20-byte SHA-1 keys): fragment i is new
  * iff first[i] == i.  Deterministic regardless of scheduling. */
@@ -183,6 +191,18 @@ typedef struct zpq_unblock_job {
   uint8_t sha1[20];       /* result: SHA-1 of the decoded bytes */
 } zpq_unblock_job;
 int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
+/* The same with framed blocks and outputs resident in HBM (in/out are DEVICE pointers; every `in` readable for
+ * 64 bytes past n): the extract-side counterpart of zpq_compress_blocks_dev.  The framing is walked on the
+ * device, all blocks of the call are decoded by one launch each of the gather / LZ77 / checksum kernels, and
+ * the stored SHA-1 is compared on the device; only the per-block records cross PCIe.  This is what a
+ * Jidac::extract over an archive staged in HBM calls once per batch of d blocks (decompressThread,
+ * ZSFX/zsfx.cpp:1731-1834). */
+int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
+/* Compares two device arrays of n digests of digest_size bytes each (fragment SHA-1s of an extracted block
+ * against the h table, ZSFX/zsfx.cpp:1811-1834; file checksums against the originals): *mismatches = number
+ * of differing entries, *first_mismatch = smallest differing index. */
+int zpq_digest_compare_dev(zpq_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, size_t n, uint32_t digest_size,
+                           uint64_t* mismatches, uint64_t* first_mismatch);
 
 /* ---- context-mixing blocks, n > 0 components (rows a11-a16) ---------------------------------- */
 /* header = the block header exactly as stored in the archive, starting at hsize[2]

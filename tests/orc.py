@@ -11,8 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def _build():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    src = os.path.join(ORACLE_DIR, "zpaq_oracle.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("zpaq_oracle.cpp", "checksum_oracle.cpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "liboracle.so"])
     return so
 
@@ -36,6 +36,25 @@ def sha1(b):
 def sha256(b):
     out = (C.c_ubyte * 32)()
     _L.orc_sha256(_buf(b), C.c_long(len(b)), out)
+    return bytes(out)
+
+
+_L.orc_crc32.restype = C.c_uint32
+_L.orc_xxh64.restype = C.c_uint64
+_L.orc_xxh64.argtypes = [C.c_void_p, C.c_long, C.c_uint64]
+
+
+def crc32(b):
+    return int(_L.orc_crc32(_buf(b), C.c_long(len(b))))
+
+
+def xxh64(b, seed=0):
+    return int(_L.orc_xxh64(C.cast(_buf(b), C.c_void_p), len(b), seed))
+
+
+def blake3(b):
+    out = (C.c_ubyte * 32)()
+    _L.orc_blake3(_buf(b), C.c_long(len(b)), out)
     return bytes(out)
 
 

@@ -19,7 +19,8 @@ const u8 kTag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2,
 // LZ77 level-1 post-processor program for rb = 0 without E8E9: the 302 bytes every "-m1" block of
 // up to 16 MiB carries (golden: i-blocks of the reference's AUTOTEST/sha256.zpaq; SURVEY.md
 // Appendix D).  Stored after the 2-byte little-endian length 0x012e.
-const u8 kPcompLz1[302] = {
+}  // namespace
+const u8 zpq_pcomp_lz1[302] = {
     0xef, 0xff, 0x2f, 0x0d, 0x04, 0x0c, 0x14, 0x1c, 0x37, 0x01, 0x37, 0x02, 0x37, 0x03, 0x37, 0x04, 0x38, 0xcb, 0x82,
     0x50, 0x47, 0x08, 0x83, 0x58, 0x07, 0x01, 0xdf, 0x00, 0x2f, 0x33, 0x47, 0x01, 0x37, 0x02, 0x42, 0xaf, 0x03, 0xef,
     0x00, 0x2f, 0x1e, 0x02, 0xcf, 0x03, 0x37, 0x03, 0x42, 0xd7, 0x02, 0x50, 0x0f, 0x03, 0xaf, 0x07, 0x81, 0x37, 0x03,
@@ -36,6 +37,8 @@ const u8 kPcompLz1[302] = {
     0x3f, 0x09, 0x42, 0xd7, 0x01, 0x50, 0x1a, 0x47, 0x04, 0x37, 0x01, 0x3f, 0xcf, 0x07, 0x01, 0xdf, 0x04, 0x2f, 0x22,
     0x43, 0xef, 0x07, 0x2f, 0x1d, 0x0f, 0x04, 0x42, 0x60, 0x39, 0x09, 0x41, 0x37, 0x04, 0x42, 0xd7, 0x08, 0x50, 0x43,
     0x8f, 0x08, 0x58, 0x07, 0x02, 0x02, 0x37, 0x02, 0xdf, 0x00, 0x2f, 0x03, 0x04, 0x37, 0x01, 0x38, 0x00};
+namespace {
+#define kPcompLz1 zpq_pcomp_lz1
 
 enum Kind { KIND_STORE0 = 0, KIND_STOREX = 1, KIND_LZ1 = 2 };
 
@@ -200,6 +203,10 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   FrameDev* d_frames = (FrameDev*)(d_dig + ((njobs * 20 + 15) & ~(size_t)15));
   u8* d_prefix = (u8*)(d_frames + njobs);
   if (!sha_job.empty()) {
+    // everything the caller enqueued on the context stream (gathers, memsets that produce the block inputs)
+    // happens before the checksum chains read them on the second stream
+    ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
+    ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_off, sha_off.data(), sha_off.size() * 8, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sha_len, sha_len.data(), sha_len.size() * 4, hipMemcpyHostToDevice, ctx->stream2));
     ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream2));
@@ -335,7 +342,9 @@ extern "C" int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njo
 }
 
 // ---- decode side ----------------------------------------------------------------------------------------
-extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify) {
+// Host-parsed path: jobs[].in are host pointers.  unblock.hip routes here the blocks its device-side parser does
+// not take (context-model coded data, PCOMP programs other than the level-1 LZ77 one, odd framing).
+int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify, bool out_dev) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
   hipStream_t st = ctx->stream;
@@ -516,13 +525,13 @@ extern "C" int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t
     ZPQ_HIP(ctx, hipMemcpyAsync(d_so, so.data(), so.size() * 8, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sl, sl.data(), sl.size() * 4, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
-    int rc = zpq_sha1_extents_on(ctx, st, (const u8*)0, d_so, d_sl, sj.size(), d_dg);
+    int rc = zpq_sha1_chains_on(ctx, st, (const u8*)0, d_so, d_sl, sj.size(), d_dg);   // one wave per block checksum
     if (rc) return rc;
     std::vector<u8> dg(sj.size() * 20);
     ZPQ_HIP(ctx, hipMemcpyAsync(dg.data(), d_dg, dg.size(), hipMemcpyDeviceToHost, st));
     for (size_t k = 0; k < sj.size(); ++k) {
       zpq_unblock_job& j = jobs[sj[k]];
-      if (j.out_len) ZPQ_HIP(ctx, hipMemcpyAsync(j.out, outp[sj[k]], j.out_len, hipMemcpyDeviceToHost, st));
+      if (j.out_len) ZPQ_HIP(ctx, hipMemcpyAsync(j.out, outp[sj[k]], j.out_len, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     }
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
     for (size_t k = 0; k < sj.size(); ++k) {

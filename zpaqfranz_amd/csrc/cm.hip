@@ -936,6 +936,7 @@ int parse_header(zpq_ctx* ctx, const u8* h, u32 len, ParsedHeader& P) {
     P.comps.push_back(std::vector<u8>(h + p, h + p + kCompSize[t]));
     p += kCompSize[t];
   }
+  if (p + 1 >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP fills the header: no COMP END / HCOMP END");
   if (h[p++] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing COMP END");
   if (hsize + 2 < p + 1 || h[hsize + 1] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing HCOMP END");
   P.hcomp.assign(h + p, h + hsize + 1);

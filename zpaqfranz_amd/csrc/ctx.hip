@@ -52,13 +52,14 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
   zpq_ctx* c = new zpq_ctx();
   c->device = device_ordinal;
   c->cu_count = prop.multiProcessorCount;
-  for (int i = 0; i < 12; ++i) c->scratch[i] = nullptr, c->scratch_cap[i] = 0;
+  for (int i = 0; i < ZPQ_SCRATCH_SLOTS; ++i) c->scratch[i] = nullptr, c->scratch_cap[i] = 0;
   c->pinned = nullptr;
   c->pinned_cap = 0;
   c->profiling = false;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ZPQ_ERR_HIP;
   }
@@ -71,10 +72,11 @@ void zpq_destroy(zpq_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < ZPQ_SCRATCH_SLOTS; ++i)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipEventDestroy(ctx->ev);
+  (void)hipEventDestroy(ctx->ev2);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
   delete ctx;

@@ -73,25 +73,28 @@ extern "C" int zpq_dedup_dev(zpq_ctx* ctx, const uint8_t* d_digests, size_t n, u
 
 // ---- extent gather: the data movement of the block packer (row a4) ------------------------------------
 namespace {
-// One workgroup per (extent, 16 KiB piece); 16-byte vector copies when source and destination are
-// mutually aligned, bytes otherwise.  HBM-bound copy: traffic = 2 x bytes moved.
+// One workgroup per (extent, piece slot): slot p copies the 16 KiB pieces p, p+P, p+2P, ... of its extent, so
+// extents of any length are covered; the grid is persistent over the (extent, slot) items.  16-byte vector copies when source and destination are mutually aligned, bytes
+// otherwise.  HBM-bound copy: traffic = 2 x bytes moved.
 __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src_base, const u64* __restrict__ src_off,
                                                      const u32* __restrict__ len, const u64* __restrict__ dst_off,
-                                                     u8* __restrict__ dst_base, u32 pieces_per_extent) {
-  const u32 e = blockIdx.x / pieces_per_extent, piece = blockIdx.x % pieces_per_extent;
+                                                     u8* __restrict__ dst_base, u32 pieces_per_extent, u64 items) {
+ for (u64 w = blockIdx.x; w < items; w += gridDim.x) {
+  const u32 e = (u32)(w / pieces_per_extent), piece = (u32)(w % pieces_per_extent);
   const u32 n = len[e];
-  const u64 lo = (u64)piece * 16384u;
-  if (lo >= n) return;
-  const u32 cnt = n - lo < 16384u ? (u32)(n - lo) : 16384u;
-  const u8* s = src_base + src_off[e] + lo;
-  u8* d = dst_base + dst_off[e] + lo;
-  u32 head = (u32)((16 - ((uintptr_t)d & 15)) & 15);
-  if (head > cnt) head = cnt;
-  for (u32 i = threadIdx.x; i < head; i += 256) d[i] = s[i];
-  const u32 body = (cnt - head) & ~15u;
-  for (u32 i = threadIdx.x * 16; i < body; i += 256 * 16)
-    *(u32x4*)(d + head + i) = *(const u32x4_u*)(s + head + i);
-  for (u32 i = head + body + threadIdx.x; i < cnt; i += 256) d[i] = s[i];
+  for (u64 lo = (u64)piece * 16384u; lo < n; lo += (u64)pieces_per_extent * 16384u) {
+    const u32 cnt = n - lo < 16384u ? (u32)(n - lo) : 16384u;
+    const u8* s = src_base + src_off[e] + lo;
+    u8* d = dst_base + dst_off[e] + lo;
+    u32 head = (u32)((16 - ((uintptr_t)d & 15)) & 15);
+    if (head > cnt) head = cnt;
+    for (u32 i = threadIdx.x; i < head; i += 256) d[i] = s[i];
+    const u32 body = (cnt - head) & ~15u;
+    for (u32 i = threadIdx.x * 16; i < body; i += 256 * 16)
+      *(u32x4*)(d + head + i) = *(const u32x4_u*)(s + head + i);
+    for (u32 i = head + body + threadIdx.x; i < cnt; i += 256) d[i] = s[i];
+  }
+ }
 }
 }  // namespace
 
@@ -99,11 +102,13 @@ extern "C" int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uin
                               const uint64_t* d_dst_off, size_t n, uint8_t* d_dst_base) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
-  // fragments are at most 8128<<fragment bytes; 16 KiB pieces keep the grid balanced
-  const u32 pieces = 64;  // covers extents up to 1 MiB; larger extents are rejected by the caller contract
-  if (n * (size_t)pieces > 0x7fffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents for one gather");
-  ZPQ_LAUNCH(ctx, "gather_kernel", ctx->stream, gather_kernel, dim3((unsigned)(n * pieces)), dim3(256), d_src_base,
-             d_src_off, d_len, d_dst_off, d_dst_base, pieces);
+  // piece slots per extent (longer extents loop inside the kernel); with very many extents (the extract side
+  // scatters every fragment of every file) fewer slots and a persistent grid keep the launch small
+  const u32 pieces = n >= 16384 ? 4 : 64;
+  const u64 items = (u64)n * pieces;
+  const unsigned grid = (unsigned)(items < 65536 ? items : 65536);
+  ZPQ_LAUNCH(ctx, "gather_kernel", ctx->stream, gather_kernel, dim3(grid), dim3(256), d_src_base,
+             d_src_off, d_len, d_dst_off, d_dst_base, pieces, items);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }

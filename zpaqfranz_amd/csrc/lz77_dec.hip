@@ -1,56 +1,96 @@
 // LZ77 level-1 decoder: what the 302-byte level-1 PCOMP program (code format
 // ZSFX/libzpaq.cpp:6211-6222) computes when PostProcessor (ZSFX/libzpaq.cpp:2178-2233) runs it per byte.
-// One wave per block: the bit parser is wave-uniform, copies are spread over the lanes, and the last
-// 64 KiB of output live in an LDS ring so that near matches never wait on HBM stores.
+//
+// One wave per block.  The bit parser is wave-uniform and never waits on memory: the code stream is held
+// in registers as a sliding window (each lane keeps 8 bytes of the current 512-byte chunk and of the next
+// one; 64 bits at any bit position are two v_readlane pairs), the interleaved Elias-gamma lengths are
+// decoded with one count-trailing-zeros and a bit compaction instead of a bit loop.  Copies are spread over
+// the lanes; the last 64 KiB of output live in an LDS ring so that near matches never wait on HBM stores.
+//
+// The stream is untrusted (archives come from anywhere): lengths are capped (<= 24 gamma doublings, far
+// beyond what any encoder emits), capacity is checked in 64 bits, offsets must point into produced output,
+// and far matches longer than their offset are copied in pieces that only read what is already written.
 #include "zpq_internal.h"
 
 namespace {
 
 __device__ __forceinline__ u64 load8(const u8* p) { return *(const u64_u*)p; }
 
-// ---- decoder ---------------------------------------------------------------------------------------
-struct LzDecDev {
-  const u8* in; u32 n; u32 rb;
-  u8* out; u32 out_cap;
-  u32* result;  // [0]=out_len, [1]=status
-};
+typedef zpq_lzdec_dev LzDecDev;
 
 constexpr u32 kRing = 1u << 16;
 
-// One wave per block.  The bit parser is wave-uniform; copies are spread over the lanes.  The last
-// 64 KiB of output live in an LDS ring so that near matches never wait on HBM stores.
+__device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
+  const u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+  return (u64)lo | (u64)hi << 32;
+}
+
+// Interleaved Elias gamma, LSB first: pairs (1, bit) and a closing 0; the value has an implied leading 1 and
+// the first bit read is the most significant.  w = the bits at the code; returns the value, nb = bits used
+// (2k+1); k > 24 (or no terminator in the window) sets nb = 0xffffffff.
+__device__ __forceinline__ u32 gamma_decode(u64 w, u32& nb) {
+  const u64 z = ~w & 0x5555555555555555ull;            // a 0 flag at an even position ends the code
+  const u32 p = z ? (u32)__builtin_ctzll(z) : 64u;
+  if (p > 48) { nb = 0xffffffffu; return 1; }
+  nb = p + 1;
+  const u32 k = p >> 1;
+  u64 x = (w >> 1) & 0x5555555555555555ull & ((1ull << p) - 1);   // data bits, now at even positions
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+  x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+  x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+  x = (x | (x >> 16)) & 0xffffffffull;
+  const u32 y = (u32)x;                                 // bit i = i-th data bit read
+  return (1u << k) | (k ? __builtin_bitreverse32(y) >> (32 - k) : 0u);
+}
+
 __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restrict__ jobs) {
   const LzDecDev J = jobs[blockIdx.x];
   __shared__ u8 ring[kRing];
   const u32 lane = (u32)lane_id();
   const u8* in = J.in;
-  const u64 nbits = (u64)J.n * 8;
+  const u32 n = J.n;
+  const u64 nbits = (u64)n * 8;
   u64 bp = 0; u32 op = 0; int status = ZPQ_OK;
-#define PEEK() (load8(in + (bp >> 3)) >> (bp & 7))
+  // code-stream window: chunk c = bytes [512c, 512c+512), 8 per lane; bytes at or past n read as 0
+  auto load_chunk = [&](u32 c) -> u64 { const u64 o = (u64)c * 512 + (u64)lane * 8; return o < n ? load8(in + o) : 0ull; };
+  u32 chunk = 0;
+  u64 cur = load_chunk(0), nxt = load_chunk(1);
+  auto peek = [&](u64 b) -> u64 {                       // 64 bits of the stream from bit b on (b < nbits)
+    const u32 byte = (u32)(b >> 3);
+    const u32 c = __builtin_amdgcn_readfirstlane(byte >> 9);
+    if (c != chunk) {
+      cur = c == chunk + 1 ? nxt : load_chunk(c);
+      nxt = load_chunk(c + 1);
+      chunk = c;
+    }
+    const u32 idx = byte & 511u;
+    const u32 L = __builtin_amdgcn_readfirstlane(idx >> 3);
+    const u32 sh = ((idx & 7u) << 3) | (u32)(b & 7);
+    const u64 lo = readlane64(cur, L);
+    const u64 hi = L == 63 ? readlane64(nxt, 0) : readlane64(cur, L + 1);
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  };
   for (;;) {
     if (bp + 2 > nbits) break;
-    u64 w = PEEK();
+    u64 w = peek(bp);
     const u32 mmv = (u32)(w & 3);
-    u64 used = 2; w >>= 2;
+    u32 used = 2; w >>= 2;
     if (mmv == 0) {                                   // literal run: gamma length then bytes
-      u32 len = 1; bool trunc = false;
-      for (;;) {
-        if (bp + used + 1 > nbits) { trunc = true; break; }
-        const u32 b = (u32)(w & 1); w >>= 1; ++used;
-        if (!b) break;
-        if (bp + used + 1 > nbits) { trunc = true; break; }
-        len = len * 2 + (u32)(w & 1); w >>= 1; ++used;
-      }
-      if (trunc) break;
+      u32 nb;
+      u32 len = gamma_decode(w, nb);
+      if (nb == 0xffffffffu) { if (bp + used + 50 <= nbits) status = ZPQ_ERR_FORMAT; break; }
+      used += nb;
+      if (bp + used > nbits) break;                    // stream ends inside the length code
       bp += used;
       const u64 avail = (nbits - bp) >> 3;
       const bool cutoff = avail < len;
       if (cutoff) len = (u32)avail;                    // stream ends inside the run
-      if (op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
+      if ((u64)op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
+      const u32 byte0 = (u32)(bp >> 3), sh = (u32)(bp & 7);
       for (u32 j = lane; j < len; j += 64) {
-        const u64 b = bp + 8ull * j;
-        const u32 two = (u32)in[b >> 3] | ((u32)in[(b >> 3) + 1] << 8);
-        const u8 c = (u8)(two >> (b & 7));
+        const u32 two = (u32)in[byte0 + j] | ((u32)in[byte0 + j + 1] << 8);
+        const u8 c = (u8)(two >> sh);
         J.out[op + j] = c;
         ring[(op + j) & (kRing - 1)] = c;
       }
@@ -60,25 +100,21 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
     } else {                                          // match
       if (bp + 5 > nbits) break;
       const u32 lo = (mmv - 1) * 8 + (u32)(w & 7); w >>= 3; used += 3;
-      u32 len = 1; bool trunc = false;
-      for (;;) {
-        if (bp + used + 1 > nbits) { trunc = true; break; }
-        const u32 b = (u32)(w & 1); w >>= 1; ++used;
-        if (!b) break;
-        if (bp + used + 1 > nbits) { trunc = true; break; }
-        len = len * 2 + (u32)(w & 1); w >>= 1; ++used;
-      }
-      if (trunc || bp + used + 2 > nbits) break;
-      len = len * 4 + (u32)(w & 3); used += 2;
-      bp += used;                                     // used <= 2+3+2*15+1+2 = 38 bits
+      u32 nb;
+      u32 len = gamma_decode(w, nb);
+      if (nb == 0xffffffffu) { if (bp + used + 50 <= nbits) status = ZPQ_ERR_FORMAT; break; }
+      w >>= nb; used += nb;
+      if (bp + used + 2 > nbits) break;
+      len = len * 4 + (u32)(w & 3); used += 2;         // <= 2^27
+      bp += used;                                      // used <= 2+3+49+2 = 56 bits
       if (bp + J.rb + lo > nbits) break;
-      w = PEEK();
+      w = peek(bp);
       const u32 r = (u32)(w & ((1ull << J.rb) - 1)); w >>= J.rb;
       const u32 qv = (u32)(w & ((1ull << lo) - 1)) | (1u << lo);
       bp += J.rb + lo;
       const u32 off = ((qv << J.rb) | r) - ((1u << J.rb) - 1u);
-      if (off > op) { status = ZPQ_ERR_FORMAT; break; }
-      if (op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
+      if (off == 0 || off > op) { status = ZPQ_ERR_FORMAT; break; }
+      if ((u64)op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
       const u32 src0 = op - off;
       if (off + 64 <= kRing) {                        // source inside the LDS ring
         for (u32 c0 = 0; c0 < len; c0 += 64) {
@@ -90,23 +126,33 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
           if (j < len) { J.out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
           __builtin_amdgcn_wave_barrier();
         }
-      } else {                                        // far match: bytes written >= 64 KiB ago, len < off
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (u32 j = lane; j < len; j += 64) {
-          const u8 c = __builtin_nontemporal_load(J.out + src0 + j);
-          J.out[op + j] = c;
-          ring[(op + j) & (kRing - 1)] = c;
+      } else {                                        // far match: bytes written >= 64 KiB ago
+        // pieces of at most 32 KiB (< off): every piece only reads what earlier pieces have stored
+        for (u32 c0 = 0; c0 < len; c0 += 32768u) {
+          const u32 pl = len - c0 < 32768u ? len - c0 : 32768u;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (u32 j = lane; j < pl; j += 64) {
+            const u8 c = __builtin_nontemporal_load(J.out + src0 + c0 + j);
+            J.out[op + c0 + j] = c;
+            ring[(op + c0 + j) & (kRing - 1)] = c;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
       }
       op += len;
     }
   }
-#undef PEEK
   if (lane == 0) { J.result[0] = op; J.result[1] = (u32)status; }
 }
 
 }  // namespace
+
+// Launch only (no host round trip): results land in d_res[2*i] = out_len, d_res[2*i+1] = status.
+int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs) {
+  ZPQ_LAUNCH(ctx, "lz77_decode_kernel", st, lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), d_jobs);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
 
 extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t njobs) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
@@ -124,8 +170,8 @@ extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, h.data(), njobs * sizeof(LzDecDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  ZPQ_LAUNCH(ctx, "lz77_decode_kernel", st, lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), d_jobs);
-  ZPQ_HIP(ctx, hipGetLastError());
+  int rc = zpq_lz77_decode_launch(ctx, st, d_jobs, njobs);
+  if (rc) return rc;
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));

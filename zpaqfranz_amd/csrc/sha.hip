@@ -384,8 +384,9 @@ int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64
   if (n == 0) return ZPQ_OK;
   if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
   // one counter per stream so that the two streams never share it
-  u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + (s == ctx->stream2 ? 16 : 0);
+  u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+  counter += s == ctx->stream2 ? 16 : 0;
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
   const int grid = persistent_grid(ctx, n, 2);
   const u32* order = extent_order(ctx, s, d_len, n, grid);
@@ -407,8 +408,9 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   if (n > 0xfffffff0u) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many extents");
-  u32* counter = (u32*)zpq_scratch(ctx, 7, 256) + 32;
+  u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+  counter += 32;
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
   const int grid = persistent_grid(ctx, n, 2);
   const u32* order = extent_order(ctx, ctx->stream, d_len, n, grid);

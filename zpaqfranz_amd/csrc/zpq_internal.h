@@ -9,16 +9,21 @@
 
 #include "zpaqhip.h"
 
+// grow-only device scratch arenas; slot numbers are fixed per use (see the zpq_scratch callers):
+// 0-11 compress side / hashing, 12-17 the device-resident decode path (unblock.hip), 18-19 checksums
+#define ZPQ_SCRATCH_SLOTS 24
+
 struct zpq_ctx {
   int device;
   hipStream_t stream;
   hipStream_t stream2;      // second stream: block SHA-1 chains overlap the LZ77 parse
   hipEvent_t ev;
+  hipEvent_t ev2;           // main stream -> second stream ordering (work the caller enqueued before a call)
   int cu_count;
   std::string err;
   // grow-only device scratch arena (avoids hipMalloc in the steady state)
-  void* scratch[12];
-  size_t scratch_cap[12];
+  void* scratch[ZPQ_SCRATCH_SLOTS];
+  size_t scratch_cap[ZPQ_SCRATCH_SLOTS];
   void* pinned;             // pinned host staging
   size_t pinned_cap;
   // optional per-kernel event timing
@@ -62,6 +67,7 @@ typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int32_t i32;
 
 // unaligned vector loads: gfx950 runs with unaligned access mode on, hipcc emits a single
 // global_load_dwordx4 / dwordx2 for these.
@@ -74,6 +80,20 @@ static __device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(
 static __device__ __forceinline__ u32 rotl32(u32 x, int k) { return __builtin_rotateleft32(x, k); }
 static __device__ __forceinline__ u32 rotr32(u32 x, int k) { return __builtin_rotateright32(x, k); }
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// device-side job record of the LZ77 level-1 decoder (lz77_dec.hip); result[0] = out_len, result[1] = status
+struct zpq_lzdec_dev {
+  const u8* in; u32 n; u32 rb;
+  u8* out; u32 out_cap;
+  u32* result;
+};
+// launches one wave per record on `st`; no host round trip
+int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs);
+// the 302-byte LZ77 level-1 post-processor program (rb = 0, no E8E9): golden, AUTOTEST/sha256.zpaq i blocks
+extern const u8 zpq_pcomp_lz1[302];
+// decode path for blocks that need host parsing (context-model coded data, arbitrary PCOMP programs): jobs[].in are
+// HOST pointers; jobs[].out are device pointers when out_dev, else host pointers (block.hip)
+int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify, bool out_dev);
 
 // internal cross-TU entry points
 // method string -> expanded x/0 method, $1..$9, block header bytes (hsize..HCOMP 0) and PCOMP bytecode
