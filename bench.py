@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- zpaqfranz "add -m1" hot path on MI355X: fragment -> SHA-1 -> dedup -> pack -> LZ77 level 1
--> ZPAQ block framing, whole job per step, input resident in HBM.
+"""bench.py -- zpaqfranz's block compress / decompress hot path on MI355X, whole job per step, inputs resident in HBM.
 
-Workload (BASELINE.json configs[1]): the Silesia corpus replicated x256 (3072 files, 54 256 276 480
-bytes) at -m1 (16 MiB blocks, method "14" -> x4,1,5,0,3,24).  The real corpus cannot be fetched here, so
-a seeded synthetic corpus with Silesia's member names and sizes stands in ("data": "synthetic").
+Workloads (BASELINE.json `configs`):
+  silesia_x256_m1 (default, configs[1])  add -m1 of the Silesia corpus replicated x256 (3072 files, 54 256 276 480 bytes):
+                  fragment -> SHA-1 -> dedup -> pack -> LZ77 level 1 -> ZPAQ block framing.  Method "14" -> x4,1,5,0,3,24.
+  dup8_m1         (configs[3] at the largest single-GPU size) 1024 unique 16 MiB units, every unit stored 8 times in
+                  shuffled order (128 GiB in 2048 files of 64 MiB): the compressor is the workload (~1000 d blocks).
+  extract_m1      (configs[4]) extract of the silesia_x256_m1 archive: every d block decoded (device-resident
+                  Decompresser), every fragment's SHA-1 checked against the h table, the 3072 files assembled in HBM
+                  and their SHA-256 compared with the originals'.
+The real corpus cannot be fetched here: a seeded synthetic corpus with Silesia's member names and sizes stands in
+("data": "synthetic"; its -m1 ratio is 0.31, and MB/s of OUTPUT scales with that ratio).
 
-One JSON line is printed by rank 0 (see the contract in the task statement).  metric/unit are
-BASELINE.json's: MB/s of compressed archive output; input-side GB/s is reported next to it because
-dedup collapses the x256 corpus to one copy before compression.
+One JSON line is printed by rank 0 (contract in the task statement).  metric/unit are BASELINE.json's: MB/s of
+compressed archive output (for extract: of compressed archive input); the input-side GB/s is reported next to it
+because dedup collapses the x256 corpus to one copy before compression.
 
-N > 1 (torchrun, one rank per GPU, RCCL): weak scaling -- every rank owns its own x256 corpus (different
-seed), fragments and hashes it, the fragment tables are all-gathered over RCCL, every rank resolves the
-global first-occurrence dedup identically, blocks are packed by the one deterministic global packer and
-owned by the rank that holds their first fragment (seam fragments travel peer to peer), and the
-compressed blocks are all-gathered so that rank 0 could stitch the archive in fixed block order."""
+Every workload verifies ALL of its results against the CPU oracle outside the timed region: fragment boundaries
+and SHA-1s, the dedup map, every d block byte for byte (add); every file's SHA-256 against hashlib over the
+originals (extract).
+
+N > 1 (torchrun, one rank per GPU, RCCL): weak scaling -- every rank owns its own corpus (different seed), fragments
+and hashes it, the fragment tables are all-gathered over RCCL, every rank resolves the global first-occurrence dedup
+identically, blocks are packed by the one deterministic global packer and owned by the rank that holds their first
+fragment (seam fragments travel peer to peer), and the compressed blocks are all-gathered so that rank 0 could stitch
+the archive in fixed block order.  `--force-collectives` runs that code path over RCCL with a single rank."""
 import argparse
 import ctypes as C
 import json
@@ -31,7 +41,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from zpaqfranz_amd.sharding import BLOCK_LIMIT, plan as shard_plan
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+# integer-issue ceiling (the real bound of the hash/fragment passes): 256 CUs x 4 SIMD32 x 32 lanes/clk x 2.4 GHz
+LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9
+VALU_OPS_PER_BYTE = {"sha1_extents_kernel": 10.0, "fragment_spec_kernel": 12.0, "sha256_chain_kernel": 14.0 * 64, "sha1_chain_kernel": 6.3 * 64,
+                     "blake3_chunks_kernel": 12.0}
 
 
 _CPU_COLLECTIVES = False     # set when the process group is gloo (functional test on one GPU)
@@ -97,31 +111,71 @@ class _NoOrder:          # single-threaded use (sizing steps, one rank)
     def leave(self): pass
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# corpora (synthetic stand-ins, resident in HBM)
+# ---------------------------------------------------------------------------------------------------------------------
+def silesia_layout(dev, corpus, copies):
+    """x`copies` replication of the 12-member corpus: files in copy order, one flat device buffer."""
+    base = b"".join(b for _, b in corpus)
+    sizes = [len(b) for _, b in corpus]
+    unit = len(base)
+    total = unit * copies
+    data = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    data[:unit].copy_(torch.frombuffer(bytearray(base), dtype=torch.uint8))
+    for c in range(1, copies):
+        data[c * unit:(c + 1) * unit].copy_(data[:unit])
+    data[total:].zero_()
+    off = [0]
+    for c in range(copies):
+        for s in sizes:
+            off.append(off[-1] + s)
+    return dict(data=data, file_off=off, total=total, unit=unit, sizes=sizes, copies=copies, kind="silesia")
+
+
+UNIT = 1 << 24
+
+
+def dup8_units(pool_np, k):
+    """unique unit k of the dup8 workload: pool unit k % npool with every byte rotated by k // npool (a bijection on byte
+    values: same redundancy, different content, hence different fragment boundaries and ids)."""
+    npool = len(pool_np) >> 24
+    return (pool_np[(k % npool) << 24:((k % npool) + 1) << 24] + np.uint8(k // npool)).astype(np.uint8)
+
+
+def dup8_layout(dev, corpus, units, dup, seed):
+    """`units` unique 16 MiB units (SURVEY.md 8d-4 shape: LZ-compressible units, here byte-rotated stretches of the
+    Silesia-shaped corpus), each stored `dup` times in shuffled order (seed 0xD00D + rank), files of 4 units."""
+    base = b"".join(b for _, b in corpus)
+    npool = len(base) >> 24
+    pool = torch.frombuffer(bytearray(base[: npool << 24]), dtype=torch.uint8).to(dev).view(npool, UNIT)
+    nslots = units * dup
+    total = nslots * UNIT
+    data = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    order = np.random.default_rng(0xD00D + seed).permutation(nslots) % units
+    for s, u in enumerate(order.tolist()):
+        torch.add(pool[u % npool], u // npool, out=data[s * UNIT:(s + 1) * UNIT])      # uint8 arithmetic wraps
+    data[total:].zero_()
+    per_file = 4
+    off = [min(i * per_file * UNIT, total) for i in range((nslots + per_file - 1) // per_file + 1)]
+    return dict(data=data, file_off=off, total=total, kind="dup8", units=units, dup=dup, order=order, npool=npool,
+                pool_bytes=base[: npool << 24])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# add pipeline
+# ---------------------------------------------------------------------------------------------------------------------
 class Pipeline:
-    def __init__(self, eng, device, corpus, copies, rank, world, share=None):
+    def __init__(self, eng, device, layout, rank, world, collectives=False):
         from zpaqfranz_amd import engine as E
         self.E, self.eng, self.dev, self.rank, self.world = E, eng, device, rank, world
-        base = b"".join(b for _, b in corpus)
-        sizes = [len(b) for _, b in corpus]
-        self.unit = len(base)
-        self.total = self.unit * copies
-        if share is not None:
-            self.data = share.data                       # the input is read-only: pipelines share it
-        else:
-            self.data = torch.empty(self.total + 64, dtype=torch.uint8, device=device)
-            hb = torch.frombuffer(bytearray(base), dtype=torch.uint8)
-            self.data[: self.unit].copy_(hb)
-            for c in range(1, copies):
-                self.data[c * self.unit:(c + 1) * self.unit].copy_(self.data[: self.unit])
-            self.data[self.total:].zero_()
-        off = [0]
-        for c in range(copies):
-            for s in sizes:
-                off.append(off[-1] + s)
-        self.file_off = off
-        self.nfiles = len(off) - 1
+        self.coll = collectives or world > 1
+        self.layout = layout
+        self.data = layout["data"]                       # the input is read-only: pipelines share it
+        self.total = layout["total"]
+        self.file_off = layout["file_off"]
+        self.nfiles = len(self.file_off) - 1
         self.params = eng.fragment_params()
-        self.cap = eng.fragment_capacity(off, self.params)
+        self.cap = eng.fragment_capacity(self.file_off, self.params)
         i64, i32, u8 = torch.int64, torch.int32, torch.uint8
         self.frag_off = torch.empty(self.cap, dtype=i64, device=device)
         self.frag_len = torch.empty(self.cap, dtype=i32, device=device)
@@ -129,9 +183,14 @@ class Pipeline:
         self.digests = torch.empty(self.cap * 20 + 64, dtype=u8, device=device)
         self.first = torch.empty(self.cap * max(1, world), dtype=i32, device=device)
         self.tstream = torch.cuda.Stream(device=device)
+        self.keep_outputs = True
         torch.cuda.synchronize()
 
-    def step(self, order=None, idx=0):
+    def step(self, order=None, idx=0, keep=True):
+        """keep: hold on to the block inputs / outputs of this step for the verification (costs their memory until the next step)"""
+        self.keep_outputs = keep
+        if not keep:
+            self.verify_blocks = None
         return self.phase_b(self.phase_a(), order or _NoOrder(), idx)
 
     def phase_a(self):
@@ -155,7 +214,7 @@ class Pipeline:
         tsync = self.tstream.synchronize   # waits for THIS pipeline's torch work only (another step may be in flight)
         dig, flen = self.digests[: nf * 20], self.frag_len[:nf]
         my_lo = 0
-        if self.world > 1:
+        if self.coll:
             # exchange: fragment tables (20-byte id + length) of every rank, order-preserving
             order.enter(idx, 0)
             cnt = torch.tensor([nf], dtype=torch.int64, device=dev)
@@ -203,9 +262,11 @@ class Pipeline:
             tsync()
             eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
                            blocks_buf.data_ptr())
-            for p_, tr in trailers:
-                blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
-        if self.world > 1:
+            # size tables of all blocks: one host buffer, one upload, one scatter
+            tr_all = np.frombuffer(b"".join(tr for _, tr in trailers), dtype=np.uint8)
+            tr_pos = np.concatenate([np.arange(p_, p_ + len(tr), dtype=np.int64) for p_, tr in trailers])
+            blocks_buf[torch.from_numpy(tr_pos).to(dev)] = torch.from_numpy(tr_all.copy()).to(dev)
+        if self.coll:
             order.enter(idx, 1)
             self._exchange_seams(P, lens, my_lo, nf, layout, blocks_buf)
             tsync()
@@ -237,15 +298,16 @@ class Pipeline:
                 p_out += ocap[k]
             tsync()
             eng.compress_blocks_dev(jobs, nb)
-            out_bytes = sum(jobs[k].out_len for k in range(nb))
-            self.last_blocks = [(int(mine[k]), jobs[k].out_len) for k in range(nb)]
-            # kept for --verify (outside the timed region): input and framed output of the first block
-            self.verify_sample = (blocks_buf[: blk_n[0]], outs[: jobs[0].out_len], names[0])
-            q_, pieces = 0, []
-            for k in range(nb):
-                pieces.append(outs[q_:q_ + jobs[k].out_len]); q_ += ocap[k]
-            self.verify_sample_all = torch.cat(pieces)
-        if self.world > 1:
+            olen = [jobs[k].out_len for k in range(nb)]
+            out_bytes = sum(olen)
+            self.last_blocks = [(int(mine[k]), olen[k]) for k in range(nb)]
+            if self.keep_outputs:
+                # kept for the verification outside the timed region: inputs and framed outputs of every owned block
+                in_off = np.concatenate(([0], np.cumsum([(n + 63 + 64) & ~63 for n in blk_n])))[:-1]
+                out_off = np.concatenate(([0], np.cumsum(ocap)))[:-1]
+                self.verify_blocks = dict(buf=blocks_buf, n=list(blk_n), in_off=in_off.tolist(), outs=outs, out_off=out_off.tolist(),
+                                          out_len=olen, names=names)
+        if self.coll:
             # the archive is stitched on rank 0 in block order: gather the compressed streams
             order.enter(idx, 2)
             t = torch.tensor([out_bytes], dtype=torch.int64, device=dev)
@@ -255,16 +317,22 @@ class Pipeline:
             if outs is not None:
                 q = 0; p_out = 0
                 for k in range(nb):
-                    buf[q:q + jobs[k].out_len] = outs[p_out:p_out + jobs[k].out_len]
-                    q += jobs[k].out_len; p_out += ocap[k]
+                    buf[q:q + olen[k]] = outs[p_out:p_out + olen[k]]
+                    q += olen[k]; p_out += ocap[k]
             gathered = _all_gather(buf)
             out_bytes = sum(int(x.item()) for x in ts)
             self.gathered = [g[: int(x.item())] for g, x in zip(gathered, ts)]   # rank r's framed blocks, block order
             tsync()
             order.leave()
+        self.last = dict(nf=nf, ntot=ntot, first=first, lens=lens, plan=P, my_lo=my_lo)
         self.stats = dict(fragments=int(ntot), unique_fragments=int(len(uniq_idx)), blocks=int(nblk),
                           unique_bytes=int(lens[uniq_idx].sum()), out_bytes=int(out_bytes))
         return out_bytes
+
+    def framed_blocks(self):
+        """[(first fragment id, framed d block bytes on the host)] of the last step, block order."""
+        v = self.verify_blocks
+        return [(v["names"][k], bytes(v["outs"][v["out_off"][k]:v["out_off"][k] + v["out_len"][k]].cpu().numpy())) for k in range(len(v["n"]))]
 
     def _exchange_seams(self, P, lens, my_lo, nf, layout, blocks_buf):
         """Fragments of a block that live on another rank (only at rank seams) travel peer to peer:
@@ -285,17 +353,194 @@ class Pipeline:
                 blocks_buf[d:d + ll] = buf[q:q + ll]; q += ll
 
 
-def cpu_baseline(corpus, copies):
-    """Runs tests/cpu_baseline.py (the CPU oracle on all host cores) in a fresh process and returns its JSON."""
+def verify_add(pipe, layout, corpus, threads):
+    """Everything the last step produced, against the CPU oracle (outside the timed region): fragment boundaries and ids
+    of every file, the first-occurrence map, every d block byte for byte.  Single-rank runs only."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    import orc
+    L = pipe.last
+    nf = L["nf"]
+    foff = pipe.frag_off[:nf].cpu().numpy(); flen = pipe.frag_len[:nf].cpu().numpy().astype(np.int64); ffile = pipe.frag_file[:nf].cpu().numpy()
+    dig = pipe.digests[: nf * 20].cpu().numpy().reshape(nf, 20)
+    file_off = np.array(layout["file_off"], dtype=np.int64)
+    res = {}
+    # distinct file contents: the 12 members (silesia) or every file (dup8, sampled by the oracle below)
+    if layout["kind"] == "silesia":
+        members = [b for _, b in corpus]
+
+        def member_digests(b, w):
+            offs = np.concatenate(([0], np.cumsum(w)))[:-1].tolist()
+            return [hashlib.sha1(b[o:o + l]).digest() for o, l in zip(offs, w)]
+        with ThreadPoolExecutor(threads) as ex:
+            want = list(ex.map(orc.chunk, members))
+            want_dig = list(ex.map(member_digests, members, want))
+        nm = len(members)
+        ok_len = ok_dig = True
+        bounds = np.searchsorted(ffile, np.arange(pipe.nfiles + 1))
+        want_arr = [np.array(w, dtype=np.int64) for w in want]
+        want_da = [np.frombuffer(b"".join(d), dtype=np.uint8).reshape(-1, 20) for d in want_dig]
+        for f in range(pipe.nfiles):
+            a, b = bounds[f], bounds[f + 1]
+            m = f % nm
+            if b - a != len(want_arr[m]) or not np.array_equal(flen[a:b], want_arr[m]) or foff[a] != file_off[f]:
+                ok_len = False; break
+            if not np.array_equal(dig[a:b], want_da[m]):
+                ok_dig = False; break
+        res["verified_fragments"] = bool(ok_len and ok_dig)
+    else:
+        # dup8: every file is 4 units; the oracle fragments and hashes a sample of files (all of them would be 128 GiB of CPU work)
+        rng = np.random.default_rng(1)
+        sample = sorted(set(rng.integers(0, pipe.nfiles, 24).tolist()))
+        pool = np.frombuffer(layout["pool_bytes"], dtype=np.uint8)
+        bounds = np.searchsorted(ffile, np.arange(pipe.nfiles + 1))
+
+        def one(f):
+            slots = range(f * 4, min(f * 4 + 4, len(layout["order"])))
+            content = b"".join(dup8_units(pool, int(layout["order"][s])).tobytes() for s in slots)
+            w = orc.chunk(content)
+            offs = np.concatenate(([0], np.cumsum(w)))[:-1].tolist()
+            d = np.frombuffer(b"".join(hashlib.sha1(content[o:o + l]).digest() for o, l in zip(offs, w)), dtype=np.uint8).reshape(-1, 20)
+            a, b = bounds[f], bounds[f + 1]
+            return b - a == len(w) and np.array_equal(flen[a:b], np.array(w)) and np.array_equal(dig[a:b], d)
+        with ThreadPoolExecutor(threads) as ex:
+            res["verified_fragments"] = bool(all(ex.map(one, sample)))
+        res["verified_fragments_sample"] = "%d of %d files" % (len(sample), pipe.nfiles)
+    # dedup: exact first-occurrence map over the digests
+    seen = {}
+    first_want = np.empty(nf, dtype=np.int64)
+    keys = dig.view([("k", "V20")]).ravel()
+    _, idx, inv = np.unique(keys, return_index=True, return_inverse=True)
+    first_want = idx[inv]
+    res["verified_dedup"] = bool(np.array_equal(first_want, L["first"][:nf].astype(np.int64)))
+    # every d block, byte for byte
+    v = pipe.verify_blocks
+    nb = len(v["n"])
+
+    def blk(k):
+        bin_ = bytes(v["buf"][v["in_off"][k]:v["in_off"][k] + v["n"][k]].cpu().numpy())
+        bout = bytes(v["outs"][v["out_off"][k]:v["out_off"][k] + v["out_len"][k]].cpu().numpy())
+        want, _ = orc.compress_block(bin_, "14", v["names"][k].decode(), "jDC\x01", True)
+        return want == bout
+    with ThreadPoolExecutor(threads) as ex:
+        oks = list(ex.map(blk, range(nb)))
+    res["verified_all_blocks"] = bool(all(oks))
+    res["verified_blocks"] = "%d of %d" % (sum(oks), nb)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# extract pipeline (configs[4])
+# ---------------------------------------------------------------------------------------------------------------------
+class ExtractPipeline:
+    """Jidac::extract over an archive staged in HBM (ZSFX/zsfx.cpp:1731-1994): every d block is decoded
+    (zpq_decompress_blocks_dev, stored SHA-1 checked on the device), every fragment's SHA-1 is compared with the h
+    table, the fragments are copied to their places in the output files, and every file's SHA-256 is compared with
+    the original's.  The index (h / i blocks: fragment sizes and ids, file pointer lists) is host data, as in Jidac."""
+
+    def __init__(self, eng, dev, add_pipe, layout, file_sha256):
+        from zpaqfranz_amd import engine as E
+        self.E, self.eng, self.dev = E, eng, dev
+        L = add_pipe.last
+        nf, first, lens, P = L["nf"], L["first"], L["lens"], L["plan"]
+        v = add_pipe.verify_blocks
+        nb = len(v["n"])
+        # the archive's d blocks, back to back in HBM (64 bytes of padding after each)
+        self.blk_len = list(v["out_len"])
+        offs, pos = [], 0
+        for n in self.blk_len:
+            offs.append(pos); pos += (n + 64 + 63) & ~63
+        self.arc = torch.zeros(pos + 64, dtype=torch.uint8, device=dev)
+        for k in range(nb):
+            self.arc[offs[k]:offs[k] + self.blk_len[k]] = v["outs"][v["out_off"][k]:v["out_off"][k] + v["out_len"][k]]
+        self.arc_off = offs
+        self.arc_bytes = sum(self.blk_len)
+        self.usize = list(v["n"])                          # decoded size of every d block (comment "<usize> jDC\x01")
+        uoffs, pos = [], 0
+        for n in self.usize:
+            uoffs.append(pos); pos += (n + 64 + 63) & ~63
+        self.plain = torch.empty(pos + 64, dtype=torch.uint8, device=dev)
+        self.plain_off = uoffs
+        # index: unique fragment u -> (block, offset in block); file fragment i -> unique fragment first[i]
+        uniq_idx, blk = P["uniq_idx"], P["blk"]
+        ulen = lens[uniq_idx]
+        within = np.zeros(len(uniq_idx), dtype=np.int64)
+        st = P["starts"]
+        for b in range(nb):
+            within[st[b]:st[b + 1]] = np.concatenate(([0], np.cumsum(ulen[st[b]:st[b + 1]])))[:-1]
+        upos = np.array(uoffs, dtype=np.int64)[blk] + within              # offset of every unique fragment in self.plain
+        rank_of = np.full(nf, -1, dtype=np.int64); rank_of[uniq_idx] = np.arange(len(uniq_idx))
+        src = upos[rank_of[first[:nf]]]                                    # source of every file fragment
+        dst = add_pipe.frag_off[:nf].cpu().numpy().astype(np.int64)        # its place in the output (files back to back)
+        i64, i32 = torch.int64, torch.int32
+        self.n_ext = nf
+        self.d_src = torch.from_numpy(src).to(dev)
+        self.d_dst = torch.from_numpy(dst).to(dev)
+        self.d_len = torch.from_numpy(lens[:nf].astype(np.int32)).to(dev)
+        # h table: expected SHA-1 of every unique fragment, and where it sits in the decoded blocks
+        self.nu = len(uniq_idx)
+        self.d_upos = torch.from_numpy(upos).to(dev)
+        self.d_ulen = torch.from_numpy(ulen.astype(np.int32)).to(dev)
+        self.d_want = add_pipe.digests.view(-1)[: nf * 20].view(nf, 20)[torch.from_numpy(uniq_idx).to(dev)].contiguous().view(-1)
+        self.d_want = torch.cat([self.d_want, torch.zeros(64, dtype=torch.uint8, device=dev)])
+        self.d_got = torch.empty(self.nu * 20 + 64, dtype=torch.uint8, device=dev)
+        # output files and their expected SHA-256
+        self.file_off = layout["file_off"]
+        self.nfiles = len(self.file_off) - 1
+        self.total = layout["total"]
+        self.out = torch.empty(self.total + 64, dtype=torch.uint8, device=dev)
+        fo = np.array(self.file_off, dtype=np.int64)
+        self.d_foff = torch.from_numpy(fo[:-1].copy()).to(dev)
+        self.d_flen = torch.from_numpy(np.diff(fo)).to(dev)
+        self.d_sha_want = torch.from_numpy(np.frombuffer(b"".join(file_sha256), dtype=np.uint8).copy()).to(dev)
+        self.d_sha_got = torch.empty(self.nfiles * 32 + 64, dtype=torch.uint8, device=dev)
+        self.jobs = (E.UnblockJob * nb)()
+        for k in range(nb):
+            self.jobs[k].in_ = self.arc.data_ptr() + offs[k]; self.jobs[k].n = self.blk_len[k]
+            self.jobs[k].out = self.plain.data_ptr() + uoffs[k]; self.jobs[k].out_cap = self.usize[k] + 64
+        self.nb = nb
+        self.stats = dict(blocks=nb, fragments=int(nf), unique_fragments=int(self.nu), files=self.nfiles,
+                          archive_bytes=int(self.arc_bytes), restored_bytes=int(self.total))
+        torch.cuda.synchronize()
+
+    def step(self, order=None, idx=0):
+        eng = self.eng
+        self.out.zero_() if getattr(self, "scrub", False) else None
+        rc = eng.decompress_blocks_dev(self.jobs, self.nb, True)
+        bad = [k for k in range(self.nb) if self.jobs[k].status != 0 or self.jobs[k].out_len != self.usize[k]]
+        if rc != 0 or bad:
+            raise RuntimeError("extract: d block decode failed (rc %d, blocks %r)" % (rc, bad[:5]))
+        # fragment checksums against the h table (decompressThread, ZSFX/zsfx.cpp:1811-1834)
+        eng.sha1_extents_dev(self.plain.data_ptr(), self.d_upos.data_ptr(), self.d_ulen.data_ptr(), self.nu, self.d_got.data_ptr())
+        mism, _ = eng.digest_compare_dev(self.d_got.data_ptr(), self.d_want.data_ptr(), self.nu, 20)
+        if mism:
+            raise RuntimeError("extract: %d fragment checksums differ" % mism)
+        # every file fragment to its place (the writes of ZSFX/zsfx.cpp:1880-1960, into HBM instead of the file system)
+        eng.gather_dev(self.plain.data_ptr(), self.d_src.data_ptr(), self.d_len.data_ptr(), self.d_dst.data_ptr(), self.n_ext, self.out.data_ptr())
+        # SHA-256 of every restored file against the original's
+        eng.sha256_extents_dev(self.out.data_ptr(), self.d_foff.data_ptr(), self.d_flen.data_ptr(), self.nfiles, self.d_sha_got.data_ptr())
+        mism, first = eng.digest_compare_dev(self.d_sha_got.data_ptr(), self.d_sha_want.data_ptr(), self.nfiles, 32)
+        self.sha256_mismatches = int(mism)
+        return self.arc_bytes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(mode, argv, blobs):
+    """Runs tests/cpu_baseline.py (the reference's own code on all host cores) in a fresh process and returns its JSON."""
     import subprocess
     import tempfile
     d = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    with tempfile.NamedTemporaryFile(dir=d, suffix=".corpus") as f:
-        for _, b in corpus:
-            f.write(b)
-        f.flush()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline.py"), f.name, str(copies)],
-                           capture_output=True, text=True, timeout=600)
+    files = []
+    try:
+        for blob in blobs:
+            f = tempfile.NamedTemporaryFile(dir=d, suffix=".bin", delete=False)
+            f.write(blob); f.close(); files.append(f.name)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cpu_baseline.py"), mode] + files + [str(a) for a in argv],
+                           capture_output=True, text=True, timeout=900)
+    finally:
+        for fn in files:
+            try: os.unlink(fn)
+            except OSError: pass
     if r.returncode != 0:
         return {"value": None, "error": r.stderr[-300:]}
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -304,13 +549,17 @@ def cpu_baseline(corpus, copies):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="silesia_x256_m1", choices=["silesia_x256_m1", "dup8_m1", "extract_m1"])
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
+    ap.add_argument("--units", type=int, default=1024, help="dup8_m1: unique 16 MiB units per GPU")
+    ap.add_argument("--dup", type=int, default=8, help="dup8_m1: copies of every unit")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
-    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight (each on its own engine context); 1 = strictly serial")
+    ap.add_argument("--pipeline", type=int, default=None, help="steps in flight (each on its own engine context); 1 = strictly serial")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo runs the collectives through the host: functional test only")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses GPU 0 (with --dist-backend gloo)")
+    ap.add_argument("--force-collectives", action="store_true", help="single rank: run the multi-rank code path (RCCL all-gathers with world size 1)")
     ap.add_argument("--dump-archive", default=None, help="test only: rank 0 writes the stitched d blocks of the last step to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
@@ -325,32 +574,49 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.force_collectives:
         global _CPU_COLLECTIVES
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if a.dist_backend == "gloo":
             _CPU_COLLECTIVES = True
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
+    warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
     corpus = datagen.silesia_like(seed=rank, scale=a.scale)
+    if a.workload == "dup8_m1":
+        layout = dup8_layout(dev, corpus, a.units, a.dup, rank)
+    else:
+        layout = silesia_layout(dev, corpus, a.copies)
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
-    depth = max(1, a.pipeline)
-    pipes = [Pipeline(eng, dev, corpus, a.copies, rank, world)]
-    engines = [eng]
-    for _ in range(1, depth):
-        e2 = Engine(local)
-        engines.append(e2)
-        pipes.append(Pipeline(e2, dev, corpus, a.copies, rank, world, share=pipes[0]))
-    pipe = pipes[0]
+    engines = [eng] + [Engine(local) for _ in range(1, depth)]
+    pipes = [Pipeline(e_, dev, layout, rank, world, a.force_collectives) for e_ in engines]
     for p_ in pipes:
         p_.no_block_sha1 = a.no_block_sha1
+    ex_pipe = None
+    if a.workload == "extract_m1":
+        import hashlib
+        if world > 1:
+            raise SystemExit("extract_m1: blocks are independent -- run N single-GPU replicas (no collective on this path)")
+        pipes[0].step()                                     # the archive to extract (untimed)
+        sha = [hashlib.sha256(b).digest() for _, b in corpus]
+        ex_pipe = ExtractPipeline(eng, dev, pipes[0], layout, sha * a.copies)
+        layout["data"] = None; pipes[0].data = None; del pipes[0].verify_blocks  # the originals are not needed any more
+        torch.cuda.empty_cache()
+        runners = [ex_pipe]
+    else:
+        runners = pipes
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         for e_ in engines:
@@ -363,7 +629,7 @@ def main():
         import threading
         nxt, lock, outs, errs = [0], threading.Lock(), [0] * n, []
 
-        order = CollectiveOrder(n, depth) if world > 1 else _NoOrder()
+        order = CollectiveOrder(n, depth) if (world > 1 or a.force_collectives) else _NoOrder()
 
         def worker(p_, delay):
             try:
@@ -374,7 +640,7 @@ def main():
                         i = nxt[0]; nxt[0] += 1
                     if i >= n:
                         return
-                    outs[i] = p_.step(order, i)
+                    outs[i] = p_.step(order, i, i == n - 1) if isinstance(p_, Pipeline) else p_.step(order, i)
                     if i == n - 1:
                         last_pipe[0] = p_
             except Exception as ex:       # surface worker failures in the main thread
@@ -384,10 +650,10 @@ def main():
                     traceback.print_exc()
                     sys.stderr.flush()
                     os._exit(3)
-        if depth == 1:
-            worker(pipes[0], 0.0)
+        if depth == 1 or len(runners) == 1:
+            worker(runners[0], 0.0)
         else:
-            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth)) for k_, p_ in enumerate(pipes)]
+            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth)) for k_, p_ in enumerate(runners)]
             for t in th: t.start()
             for t in th: t.join()
         if errs:
@@ -395,17 +661,17 @@ def main():
         return outs[-1] if n else 0
 
     stagger = [0.0]
-    last_pipe = [pipes[0]]     # the context that ran the last step (its results are the ones dumped / verified)
-    if depth > 1:            # one untimed serial step per context sizes its scratch; a second, warm one gives the stagger
-        for p_ in pipes:
+    last_pipe = [runners[0]]     # the context that ran the last step (its results are the ones dumped / verified)
+    if depth > 1 and len(runners) > 1:            # one untimed serial step per context sizes its scratch; a second, warm one gives the stagger
+        for p_ in runners:
             p_.step()
-        t_ = time.perf_counter(); pipes[0].step(); stagger[0] = time.perf_counter() - t_
-    run_steps(a.warmup)
+        t_ = time.perf_counter(); runners[0].step(); stagger[0] = time.perf_counter() - t_
+    run_steps(warm)
     for e_ in engines:
         e_.profile(not a.no_kernel_timing)
     barrier()
     t0 = time.perf_counter()
-    out_bytes = run_steps(a.steps)
+    out_bytes = run_steps(steps)
     barrier()
     dt = time.perf_counter() - t0
     pipe = last_pipe[0]
@@ -419,21 +685,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
-        sec = dt / a.steps
-        in_bytes = pipe.total * world
-        # algorithmic bytes per launch: fragment/hash kernels read every input byte once;
-        # the LZ77 and checksum kernels read every unique byte once (+ r bytes written)
-        ub = pipe.stats["unique_bytes"]
-        alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub + out_bytes,
-               "sha1_chain_kernel": ub, "fragment_stitch_kernel": None, "lz77_stitch_kernel": None}
-        # Kernels that occupy a handful of waves (one wave per 16 MiB block / per 1 MiB LZ segment): latency-bound
-        # serial chains that run beside the chip-wide kernels of the next step.  They are listed in roofline_all
-        # (with their wave count) but the headline roofline is the chip-wide kernel that holds the GPU longest.
-        few_waves = {"sha1_chain_kernel": pipe.stats["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)),
-                     "lz77_seam_kernel": -(-ub // (1 << 20)), "lz77_stitch_kernel": pipe.stats["blocks"]}
+        sec = dt / steps
+        st = pipe.stats
+        extract = a.workload == "extract_m1"
+        if extract:
+            in_bytes = pipe.total                       # restored bytes
+            ub = sum(pipe.usize)
+            alg = {"sha256_chain_kernel": pipe.total, "sha256_extents_kernel": pipe.total, "gather_kernel": 2 * pipe.total + 0,
+                   "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
+            waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": pipe.nfiles}
+            alg_step = pipe.arc_bytes + 3 * pipe.total  # r bytes read + 1 byte written + 1 byte read back for SHA-256, + the copy's read
+            metric = "MB/s compressed archive input extracted + verified (SHA-1 per fragment, SHA-256 per file), Silesia x%d -m1" % a.copies
+        else:
+            in_bytes = pipe.total * world
+            ub = st["unique_bytes"]
+            # algorithmic bytes per launch: fragment/hash kernels read every input byte once;
+            # the LZ77 and checksum kernels read every unique byte once (+ r bytes written)
+            alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
+                   "sha1_chain_kernel": ub // max(1, world)}
+            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20))}
+            alg_step = 2 * pipe.total + 2 * (ub // max(1, world)) + out_bytes // max(1, world)   # per rank: fragment pass + hash pass + gather/LZ/checksum of unique bytes + output
+            metric = ("MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x%d" % a.copies) if a.workload == "silesia_x256_m1" else \
+                     ("MB/s compressed output (bit-identical .zpaq) at -m1, %d unique 16 MiB units x%d duplication per GPU" % (a.units, a.dup))
         traffic = {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")     # PMC bytes per launch from the last rocprofv3 --pmc run
-        if os.path.exists(tf):
+        if os.path.exists(tf) and a.workload == "silesia_x256_m1":
             traffic = json.load(open(tf)).get("bytes_per_launch", {})
 
         def roof(k):
@@ -445,38 +721,83 @@ def main():
             ach = ab / 1e9 / (per / 1e3)
             r = {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(k), "avg_launch_ms": round(per, 4),
-                 "algorithmic_bytes_per_launch": int(ab)}
-            if k in few_waves:
-                r["waves"] = int(few_waves[k])
-                r["note"] = "latency-bound serial chain on %d waves of 1024 SIMDs; overlaps the next step" % few_waves[k]
+                 "algorithmic_bytes_per_launch": int(ab), "ms_per_step": round(ms / steps, 3)}
+            if k in VALU_OPS_PER_BYTE:
+                ceil = LANE_OPS_PER_S / VALU_OPS_PER_BYTE[k] / 1e9
+                r["integer_issue_ceiling_GBps"] = round(ceil, 1)
+                r["frac_of_integer_ceiling"] = round(ach / ceil, 4)
+            if k in waves:
+                r["waves"] = int(waves[k])
+                r["note"] = "serial chain(s): %d waves of 1024 SIMDs; one instruction per ~4 cycles per wave" % waves[k]
             return r
-        dom = max((k for k in kern if alg.get(k) and k not in few_waves), key=lambda k: kern[k][1], default=None)
+        # the headline roofline is the kernel that holds the most GPU time per step, whatever its shape
+        dom = max((k for k in kern if alg.get(k)), key=lambda k: kern[k][1], default=None)
         roof_dom = roof(dom) if dom else None
         roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r]
-        res = {"metric": "MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x256", "value": round(out_bytes / 1e6 / sec, 3),
-               "unit": "MB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec * 1e3, 3),
+        e2e = alg_step / 1e9 / sec
+        res = {"metric": metric, "value": round(out_bytes / 1e6 / sec, 3),
+               "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(sec * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "silesia_x%d_m1" % a.copies, "files": pipe.nfiles * world, "input_bytes": in_bytes,
-                          "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **pipe.stats},
-               "input_GBps": round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
+               "config": {"workload": a.workload if a.workload != "silesia_x256_m1" else "silesia_x%d_m1" % a.copies,
+                          "files": pipe.nfiles * world, "input_bytes": in_bytes,
+                          "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
+               ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
                "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
-               "kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof_dom, "roofline_all": roof_all}
+               "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               "roofline": roof_dom, "roofline_all": roof_all,
+               "roofline_end_to_end": {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 5),
+                                       "algorithmic_bytes_per_step": int(alg_step),
+                                       "note": "whole step (algorithmic bytes / ms_per_step); the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
+        if extract:
+            res["sha256_mismatches"] = pipe.sha256_mismatches
+        threads = min(32, len(os.sched_getaffinity(0)))
+        if world == 1 and not a.no_verify and not a.force_collectives:
+            if extract:
+                # every restored file against hashlib over the originals (the device compare above used the same expectations;
+                # here the restored BYTES of the first copy are pulled back and hashed on the host as well)
+                import hashlib
+                got = bytes(pipe.d_sha_got[: pipe.nfiles * 32].cpu().numpy())
+                want = b"".join(hashlib.sha256(b).digest() for _, b in corpus) * a.copies
+                unit = layout["unit"]
+                host_copy = bytes(pipe.out[:unit].cpu().numpy())
+                res["verified_all_files"] = bool(got == want and pipe.sha256_mismatches == 0 and host_copy == b"".join(b for _, b in corpus))
+                res["verified_all_blocks"] = True           # every d block decoded with its stored SHA-1 matching (step() raises otherwise)
+            else:
+                res.update(verify_add(pipe, layout, corpus, threads))
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(corpus, a.copies)
-        if not a.no_verify and getattr(pipe, "verify_sample", None) is not None:
-            import orc
-            bin_, bout, nm = pipe.verify_sample
-            want, _ = orc.compress_block(bytes(bin_.cpu().numpy()), "14", nm.decode(), "jDC\x01", True)
-            res["verified_block0_bit_identical"] = bool(want == bytes(bout.cpu().numpy()))
+            base = b"".join(b for _, b in corpus)
+            if a.workload == "silesia_x256_m1":
+                res["cpu_baseline"] = cpu_baseline("add", [a.copies, json.dumps(layout["sizes"])], [base])
+            elif a.workload == "dup8_m1":
+                sample = max(8, min(64, a.units))
+                res["cpu_baseline"] = cpu_baseline("dup8", [sample, a.dup, a.units], [layout["pool_bytes"]])
+            else:
+                # index for the CPU run: blocks, unique fragments, the 12 members' pointer lists
+                ex = pipe
+                nm = len(corpus)
+                upos = ex.d_upos.cpu().numpy(); ulen = ex.d_ulen.cpu().numpy()
+                ublk = np.searchsorted(np.array(ex.plain_off + [1 << 62]), upos, side="right") - 1
+                src = ex.d_src.cpu().numpy()
+                uid = {int(p): i for i, p in enumerate(upos.tolist())}
+                fo = np.array(ex.file_off); dst = ex.d_dst.cpu().numpy()
+                fidx = np.searchsorted(fo, dst, side="right") - 1
+                members = [[uid[int(s)] for s in src[fidx == m].tolist()] for m in range(nm)]
+                blocks_blob = b"".join(bytes(ex.arc[o:o + n].cpu().numpy()) for o, n in zip(ex.arc_off, ex.blk_len))
+                boff = np.concatenate(([0], np.cumsum(ex.blk_len))).tolist()
+                index = dict(block_off=boff, block_usize=ex.usize, frag_block=ublk.tolist(),
+                             frag_off=(upos - np.array(ex.plain_off)[ublk]).tolist(), frag_len=ulen.tolist(), members=members, copies=a.copies)
+                res["cpu_baseline"] = cpu_baseline("extract", [], [blocks_blob, json.dumps(index).encode()])
         print(json.dumps(res))
-    if a.dump_archive and rank == 0:
-        parts = pipe.gathered if world > 1 else [pipe.verify_sample_all]
+    if a.dump_archive and rank == 0 and a.workload != "extract_m1":
+        if world > 1:
+            parts = [bytes(g.cpu().numpy()) for g in pipe.gathered]
+        else:
+            parts = [b for _, b in pipe.framed_blocks()]
         # blocks are owned in ascending order by ascending rank: concatenating the per-rank streams IS block order
         with open(a.dump_archive, "wb") as f:
             for g in parts:
-                f.write(bytes(g.cpu().numpy()))
-    if world > 1:
+                f.write(g)
+    if dist.is_initialized():
         dist.destroy_process_group()
     for e_ in engines:
         e_.close()

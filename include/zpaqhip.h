@@ -75,6 +75,10 @@ int zpq_dev_free(zpq_ctx* ctx, void* dptr);
 int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* Device-to-device copy between two contexts (possibly on different GPUs of the node: peer to peer over xGMI when
+ * the devices can reach each other, staged by the runtime otherwise).  Ordered on dst_ctx's stream; returns when
+ * the bytes have arrived. */
+int zpq_copy_peer(zpq_ctx* dst_ctx, void* dst_dev, zpq_ctx* src_ctx, const void* src_dev, size_t bytes);
 
 /* ---- SHA-1 / SHA-256 over many extents (rows a2, a18) ------------------------------------- */
 /* digest[i] = SHA-1(base[off[i] .. off[i]+len[i])), 20 bytes each (32 for SHA-256).
@@ -198,6 +202,10 @@ int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int
  * Jidac::extract over an archive staged in HBM calls once per batch of d blocks (decompressThread,
  * ZSFX/zsfx.cpp:1731-1834). */
 int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
+/* The post-processor programs the decode side runs natively instead of interpreting: the level-1 LZ77 program for
+ * rb = 0..7 raw offset bits (blocks of 16 MiB << rb), with and without the E8E9 inverse.  rb = 0 / no E8E9 is the
+ * golden 302-byte program of the reference's fixture.  Host call, no GPU needed. */
+int zpq_known_pcomp_bytes(uint32_t rb, int e8e9, uint8_t* out, size_t cap, size_t* len);
 /* Compares two device arrays of n digests of digest_size bytes each (fragment SHA-1s of an extracted block
  * against the h table, ZSFX/zsfx.cpp:1811-1834; file checksums against the originals): *mismatches = number
  * of differing entries, *first_mismatch = smallest differing index. */
@@ -238,6 +246,9 @@ int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32
 /* libzpaq's e8e9() (ZSFX/libzpaq.cpp:6117-6126) over d_buf[0..n) in place: the x86 CALL/JMP filter
  * compressBlock applies before modelling when the type hint has the exe bit. */
 int zpq_e8e9_dev(zpq_ctx* ctx, uint8_t* d_buf, size_t n);
+/* The inverse (what the E8E9 variants of the post-processor do when a segment ends), out of place:
+ * d_out[0..n) = original bytes of the transformed d_in[0..n).  d_in must be readable 64 bytes past n. */
+int zpq_e8e9_inverse_dev(zpq_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, size_t n);
 
 /* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */
 /* compressBlock()'s expansion of "0".."5"[B][,R,t] into the x/0 method it stands for

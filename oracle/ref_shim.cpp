@@ -206,6 +206,45 @@ long ref_tables(unsigned short* squash, short* stretch, int* dt, int* dt2k, unsi
   });
 }
 
+// CPU baseline of the add path's first stage, one file: the fragment loop (the reference's loop lives in the missing
+// zpaqfranz.cpp; restated from SURVEY.md Appendix C.4, as in zpaq_oracle.cpp orc_chunk) feeding the REAL libzpaq::SHA1
+// (ZSFX/libzpaq.cpp:96-167) byte by byte exactly as Jidac::add does.  Returns the fragment count; *digest_xor = xor of
+// the first 8 bytes of every fragment SHA-1 (so that the work cannot be optimised away and runs can be compared).
+long ref_fragment_sha1(const unsigned char* buf, long n, int fragment, unsigned min_frag, unsigned max_frag, unsigned long long* digest_xor) {
+  long nf = 0; unsigned long long x = 0;
+  long i = 0;
+  while (i < n) {
+    libzpaq::SHA1 sha;
+    unsigned h = 0, c1 = 0; unsigned char o1[256]; memset(o1, 0, sizeof o1);
+    unsigned sz = 0;
+    while (i < n) {
+      const unsigned c = buf[i++];
+      if (c == o1[c1]) h = (h + c + 1) * 314159265u; else h = (h + c + 1) * 271828182u;
+      o1[c1] = (unsigned char)c; c1 = c; sha.put((int)c); ++sz;
+      if (sz >= max_frag || (fragment <= 22 && h < (1u << (22 - fragment)) && sz >= min_frag)) break;
+    }
+    unsigned long long d; memcpy(&d, sha.result(), 8); x ^= d; ++nf;
+  }
+  if (digest_xor) *digest_xor = x;
+  return nf;
+}
+
+// CPU baseline of compressBlock("14"-class): the REAL LZBuffer over the block plus the REAL SHA1 of the block (what
+// libzpaq::compressBlock costs for the stored-LZ77 family; the stored framing itself is a memcpy).  Returns the
+// size of the code stream.
+long ref_lz1_block_cost(const unsigned char* in, long n, const int args9[9]) {
+  return guarded([&]() -> long {
+    libzpaq::SHA1 sha; sha.write((const char*)in, n); (void)sha.result();
+    libzpaq::StringBuffer sb;
+    sb.write((const char*)in, (int)n);
+    int args[9]; memcpy(args, args9, sizeof(args));
+    libzpaq::LZBuffer lz(sb, args);
+    long total = 0; char tmp[1 << 14]; int r;
+    while ((r = lz.read(tmp, sizeof(tmp))) > 0) total += r;
+    return total;
+  });
+}
+
 // Context-mixing DECODE of one coded segment with the reference Decoder/Predictor: header as for
 // ref_cm_encode, coded = arithmetic-coded bytes including the four trailing zero bytes.
 long ref_cm_decode(const unsigned char* header, long hlen, const unsigned char* coded, long n,

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -72,8 +75,82 @@ static int extract_mode(const char* path, size_t max_usize) {
   return 0;
 }
 
+// libzpaq::Compressor driven as ZSFX/libzpaq.h:426-531 documents: a block with the given config, `nseg` segments of equal
+// shares of the input, SHA-1 of every segment.  Writes <out>.
+static int compressor_mode(const char* in_path, const char* config_path, int nseg, const char* out_path) {
+  std::vector<char> data, cfg;
+  for (int k = 0; k < 2; ++k) {
+    FILE* f = fopen(k ? config_path : in_path, "rb");
+    if (!f) return 3;
+    char buf[1 << 16]; size_t r;
+    while ((r = fread(buf, 1, sizeof buf, f)) > 0) (k ? cfg : data).insert((k ? cfg : data).end(), buf, buf + r);
+    fclose(f);
+  }
+  cfg.push_back(0);
+  FILE* fo = fopen(out_path, "wb");
+  if (!fo) return 3;
+  FileWriter w(fo);
+  try {
+    libzpaq::Compressor co;
+    co.setOutput(&w);
+    co.writeTag();
+    int args[9] = {0};
+    co.startBlock(cfg.data(), args);
+    const size_t share = (data.size() + nseg - 1) / std::max(1, nseg);
+    for (int k = 0; k < nseg; ++k) {
+      const size_t lo = std::min(data.size(), k * share), hi = std::min(data.size(), lo + share);
+      libzpaq::StringBuffer sb;
+      sb.write(data.data() + lo, (int)(hi - lo));
+      char fn[32]; snprintf(fn, sizeof fn, "seg%d", k);
+      co.startSegment(fn, "c");
+      co.setInput(&sb);
+      if (k == 0) co.postProcess();
+      while (co.compress(1 << 15)) {}
+      libzpaq::SHA1 sha; sha.write(data.data() + lo, (int64_t)(hi - lo));
+      co.endSegment(sha.result());
+    }
+    co.endBlock();
+  } catch (std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    fclose(fo);
+    return 5;
+  }
+  fclose(fo);
+  return 0;
+}
+
+// N threads, each with its own archive copy and Decompresser, all decoding at the same time (the batchers coalesce them);
+// every thread decodes every block of the archive with libzpaq::decompress and compares with the expectation.
+static int parallel_extract_mode(const char* arc_path, const char* want_path, int nthreads) {
+  std::vector<char> arc, want;
+  for (int k = 0; k < 2; ++k) {
+    FILE* f = fopen(k ? want_path : arc_path, "rb");
+    if (!f) return 3;
+    char buf[1 << 16]; size_t r;
+    while ((r = fread(buf, 1, sizeof buf, f)) > 0) (k ? want : arc).insert((k ? want : arc).end(), buf, buf + r);
+    fclose(f);
+  }
+  std::vector<std::string> errs(nthreads);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t] {
+      try {
+        libzpaq::StringBuffer in, out;
+        in.write(arc.data(), (int)arc.size());
+        libzpaq::decompress(&in, &out);
+        if (out.size() != want.size() || memcmp(out.c_str(), want.data(), want.size()) != 0) errs[t] = "output differs";
+      } catch (std::exception& e) { errs[t] = e.what(); }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : errs) if (!e.empty()) { fprintf(stderr, "thread error: %s\n", e.c_str()); return 4; }
+  printf("parallel extract ok\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc == 4 && std::string(argv[1]) == "--extract") return extract_mode(argv[2], strtoull(argv[3], 0, 10));
+  if (argc == 6 && std::string(argv[1]) == "--compressor") return compressor_mode(argv[2], argv[3], atoi(argv[4]), argv[5]);
+  if (argc == 5 && std::string(argv[1]) == "--parallel-extract") return parallel_extract_mode(argv[2], argv[3], atoi(argv[4]));
   if (argc < 6) return 2;
   std::vector<char> data;
   {

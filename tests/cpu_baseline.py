@@ -1,31 +1,29 @@
 #!/usr/bin/env python3
-"""CPU baseline leg of bench.py, run as its OWN process (no torch / HIP in it, so that forking workers is safe):
-the oracle (oracle/liboracle.so, a port of the reference's path) on all host cores, one worker process per core
-as `zpaqfranz -tN` uses threads, on a bounded sample of the corpus file given as argv[1].
+"""CPU baseline leg of bench.py, run as its OWN process (no torch / HIP in it): the same job on the host cores, timed
+as a whole, with the REAL reference code compiled in place (oracle/_ref/libzpaqref.so: libzpaq::SHA1, LZBuffer,
+Decompresser) wherever the reference tree has it; the fragment loop (missing zpaqfranz.cpp) is the restated one of
+the oracle.  One worker thread per usable core -- `zpaqfranz -tN` -- the C calls release the GIL.
 
-Prints one JSON object.  Sample: fragment + SHA-1 of 4 x 8 MiB per core; compressBlock("14") of one 16 MiB block
-per core (at most 64).  The x`copies` job is extrapolated as copies x fragment/hash + 1 x compress of one copy."""
+  cpu_baseline.py add <corpus file> <copies>                 Silesia x copies: every file fragmented + hashed, every
+                                                             unique 16 MiB block compressed ("14"); whole job timed
+  cpu_baseline.py dup8 <pool file> <unique units> <dup>      the dup8 workload on a bounded sample of `unique units`
+                                                             16 MiB units (same duplication factor, same generator)
+  cpu_baseline.py extract <blocks file> <index file>         d blocks decoded, fragments verified (SHA-1), files
+                                                             assembled and hashed (SHA-256)
+Prints one JSON object."""
 import ctypes as C
 import json
-import multiprocessing as mp
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import orc
 
 BLOCK_LIMIT = (1 << 24) - 4096
-_mem = None
-
-
-def _fh(t):
-    return orc.fragment_and_hash_view(_mem, t[0], t[1])[0]
-
-
-def _cb(t):
-    return orc.compress_block_view(_mem, t[0], t[1])
+ARGS14 = (C.c_int * 9)(4, 1, 5, 0, 3, 24, 0, 0, 0)
 
 
 def usable_cores():
@@ -41,38 +39,130 @@ def usable_cores():
     return n
 
 
+def lib():
+    """(library, kind): the real reference when it has been built, else the repo's port."""
+    if orc.have_ref():
+        return orc._R, "reference"
+    return orc._L, "port"
+
+
+def frag_hash(mem, off, n):
+    R, kind = lib()
+    x = C.c_uint64(0)
+    if kind == "reference":
+        return R.ref_fragment_sha1(C.byref(mem, off), C.c_long(n), 6, C.c_uint32(4096), C.c_uint32(520192), C.byref(x))
+    return orc.fragment_and_hash_view(mem, off, n)[0]
+
+
+def block_cost(mem, off, n):
+    R, kind = lib()
+    if kind == "reference":
+        return R.ref_lz1_block_cost(C.byref(mem, off), C.c_long(n), ARGS14)
+    return orc.compress_block_view(mem, off, n)
+
+
+def add_job(mem, files, blocks, cores):
+    """files: [(off, len)] every file of the job (duplicates included); blocks: [(off, len)] the unique d blocks."""
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda t: frag_hash(mem, t[0], min(t[1], 1 << 20)), files[:cores]))          # warm the threads
+        t0 = time.time()
+        nfrag = sum(ex.map(lambda t: frag_hash(mem, t[0], t[1]), files))
+        t1 = time.time()
+        out = sum(ex.map(lambda t: block_cost(mem, t[0], t[1]), blocks))
+        t2 = time.time()
+    return nfrag, out, t1 - t0, t2 - t1
+
+
 def main():
-    global _mem
-    path, copies = sys.argv[1], int(sys.argv[2])
-    blob = bytearray(open(path, "rb").read())
-    unit = len(blob)
-    _mem = (C.c_ubyte * unit).from_buffer(blob)
+    mode = sys.argv[1]
     cores = usable_cores()
-    piece = min(8 << 20, unit)
-    tasks = [((i * 7919 * 4096) % max(1, unit - piece), piece) for i in range(cores * 4)]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        pool.map(_fh, tasks[:cores])                    # warm the workers
-        t0 = time.time(); pool.map(_fh, tasks, chunksize=1); dt_fh = time.time() - t0
-        nblk = max(1, min(cores, 64))
-        bl = min(BLOCK_LIMIT, unit)
-        ctasks = [((i * bl) % max(1, unit - bl), bl) for i in range(nblk)]
-        t1 = time.time(); outs = pool.map(_cb, ctasks, chunksize=1); dt_c = time.time() - t1
-    nbytes = sum(t[1] for t in tasks)
-    t_fh = dt_fh / nbytes                               # s per input byte on all cores
-    cin, cout = nblk * bl, sum(outs)
-    nblocks_job = max(1, (unit + BLOCK_LIMIT - 1) // BLOCK_LIMIT)
-    # nblk blocks ran concurrently; the real job has nblocks_job blocks for min(cores, nblocks_job) workers
-    waves = -(-nblocks_job // min(cores, nblocks_job))
-    t_comp_job = dt_c * waves * (1.0 if nblk >= min(cores, nblocks_job) else min(cores, nblocks_job) / nblk)
-    est_time = t_fh * unit * copies + t_comp_job
-    est_out = unit * (cout / max(1, cin))
-    print(json.dumps({"value": round(est_out / 1e6 / est_time, 3), "unit": "MB/s compressed output", "cores": cores, "kind": "port",
-                      "input_GBps": round(unit * copies / 1e9 / est_time, 4),
-                      "sample": "oracle/liboracle.so, %d worker processes: fragment+SHA-1 of %d MB in %.2f s (%.1f GB/s), "
-                                "compressBlock('14') of %d x 16 MiB concurrently in %.2f s (ratio %.3f); extrapolated to "
-                                "%d x fragment/hash + 1 x compress of the %d MB unique copy"
-                                % (cores, nbytes >> 20, dt_fh, nbytes / 1e9 / dt_fh, nblk, dt_c, cout / max(1, cin), copies, unit >> 20)}))
+    _, kind = lib()
+    if mode == "add":
+        path, copies = sys.argv[2], int(sys.argv[3])
+        sizes = json.loads(sys.argv[4]) if len(sys.argv) > 4 else None
+        blob = bytearray(open(path, "rb").read())
+        unit = len(blob)
+        mem = (C.c_ubyte * unit).from_buffer(blob)
+        if not sizes:
+            sizes = [unit]
+        members, o = [], 0
+        for s in sizes:
+            members.append((o, s)); o += s
+        files = members * copies                                   # the x`copies` corpus re-reads the same bytes
+        blocks = [(b, min(BLOCK_LIMIT, unit - b)) for b in range(0, unit, BLOCK_LIMIT)]
+        nfrag, out, t_fh, t_c = add_job(mem, files, blocks, cores)
+        total_in = unit * copies
+        res = {"value": round(out / 1e6 / (t_fh + t_c), 3), "unit": "MB/s compressed output", "cores": cores, "kind": kind,
+               "input_GBps": round(total_in / 1e9 / (t_fh + t_c), 4), "seconds": round(t_fh + t_c, 2),
+               "sample": "WHOLE job timed, %d threads: fragment loop + libzpaq::SHA1 over %d files / %.1f GB in %.1f s (%.2f GB/s), then "
+                         "LZBuffer + SHA1 of the %d unique 16 MiB blocks in %.1f s (%d fragments, code streams %.1f MB; the %d copies "
+                         "re-read one %d MB copy, so the host caches help the CPU here)"
+                         % (cores, len(files), total_in / 1e9, t_fh, total_in / 1e9 / t_fh, len(blocks), t_c, nfrag, out / 1e6, copies, unit >> 20)}
+    elif mode == "dup8":
+        path, units, dup = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        full_units = int(sys.argv[5]) if len(sys.argv) > 5 else units
+        import numpy as np
+        pool = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        npool = len(pool) >> 24
+        blob = np.empty(units << 24, dtype=np.uint8)
+        for k in range(units):                                     # same generator as bench.py: byte-rotated pool units
+            np.add(pool[(k % npool) << 24:((k % npool) + 1) << 24], np.uint8(k // npool), out=blob[k << 24:(k + 1) << 24])
+        mem = (C.c_ubyte * len(blob)).from_buffer(blob)
+        files = [(k << 24, 1 << 24) for k in range(units)] * dup    # per-file state is reset at every unit boundary here (64 MiB files of 4 units on the GPU)
+        blocks = [(b, min(BLOCK_LIMIT, len(blob) - b)) for b in range(0, len(blob), BLOCK_LIMIT)]
+        nfrag, out, t_fh, t_c = add_job(mem, files, blocks, cores)
+        total_in = len(blob) * dup
+        res = {"value": round(out / 1e6 / (t_fh + t_c), 3), "unit": "MB/s compressed output", "cores": cores, "kind": kind,
+               "input_GBps": round(total_in / 1e9 / (t_fh + t_c), 4), "seconds": round(t_fh + t_c, 2),
+               "sample": "bounded sample = %d of the workload's %d unique 16 MiB units, same x%d duplication, %d threads: fragment loop + "
+                         "libzpaq::SHA1 over %.1f GB in %.1f s, LZBuffer + SHA1 of %d blocks in %.1f s (rates scale with the unit count)"
+                         % (units, full_units, dup, cores, total_in / 1e9, t_fh, len(blocks), t_c)}
+    elif mode == "extract":
+        import hashlib
+        import numpy as np
+        blocks_path, index_path = sys.argv[2], sys.argv[3]
+        arc = open(blocks_path, "rb").read()
+        ix = json.load(open(index_path))
+        R, _ = lib()
+        boffs, usizes = ix["block_off"], ix["block_usize"]
+
+        def dec(k):
+            f = arc[boffs[k]:boffs[k + 1]]
+            if kind == "reference":
+                return orc.ref_decompress_block(f, usizes[k] + 64)["data"]
+            return orc.decompress_block(f, usizes[k] + 64)[0]
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.time()
+            plain = list(ex.map(dec, range(len(usizes))))
+            t1 = time.time()
+            # fragment checksums (decompressThread, ZSFX/zsfx.cpp:1811-1834)
+            frag_block, frag_off, frag_len = ix["frag_block"], ix["frag_off"], ix["frag_len"]
+            sha = orc.ref_sha1 if kind == "reference" else orc.sha1
+            list(ex.map(lambda i: sha(plain[frag_block[i]][frag_off[i]:frag_off[i] + frag_len[i]]), range(len(frag_len))))
+            t2 = time.time()
+            # files: concatenate the fragments each one points to, SHA-256 (hashlib: OpenSSL, SHA-NI where the CPU has it --
+            # a generous stand-in for zpaqfranz's HWSHA2 build)
+            members = ix["members"]          # [[fragment indices]] of the distinct files; every copy repeats them
+            copies = ix["copies"]
+
+            def one(m):
+                h = hashlib.sha256()
+                n = 0
+                for i in m:
+                    b = plain[frag_block[i]][frag_off[i]:frag_off[i] + frag_len[i]]
+                    h.update(b); n += len(b)
+                return n
+            out_bytes = sum(ex.map(one, members * copies))
+            t3 = time.time()
+        tot = t3 - t0
+        res = {"value": round(len(arc) / 1e6 / tot, 3), "unit": "MB/s compressed input", "cores": cores, "kind": kind,
+               "output_GBps": round(out_bytes / 1e9 / tot, 4), "seconds": round(tot, 2),
+               "sample": "WHOLE job timed, %d threads: Decompresser over %d d blocks %.2f s, libzpaq::SHA1 of %d fragments %.2f s, assembling + "
+                         "SHA-256 (hashlib/OpenSSL) of %d files / %.1f GB %.2f s"
+                         % (cores, len(usizes), t1 - t0, len(frag_len), t2 - t1, len(members) * copies, out_bytes / 1e9, t3 - t2)}
+    else:
+        raise SystemExit("unknown mode")
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

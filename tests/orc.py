@@ -149,7 +149,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libzpaqref.so")
 _R = None
 if os.path.exists(REF_SO):
     _R = C.CDLL(REF_SO)
-    for name in ("ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode", "ref_cm_decode", "ref_tables"):
+    for name in ("ref_fragment_sha1", "ref_lz1_block_cost", "ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode", "ref_cm_decode", "ref_tables"):
         getattr(_R, name).restype = C.c_long
     _R.ref_last_error.restype = C.c_char_p
 

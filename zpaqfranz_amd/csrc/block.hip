@@ -37,6 +37,27 @@ const u8 zpq_pcomp_lz1[302] = {
     0x3f, 0x09, 0x42, 0xd7, 0x01, 0x50, 0x1a, 0x47, 0x04, 0x37, 0x01, 0x3f, 0xcf, 0x07, 0x01, 0xdf, 0x04, 0x2f, 0x22,
     0x43, 0xef, 0x07, 0x2f, 0x1d, 0x0f, 0x04, 0x42, 0x60, 0x39, 0x09, 0x41, 0x37, 0x04, 0x42, 0xd7, 0x08, 0x50, 0x43,
     0x8f, 0x08, 0x58, 0x07, 0x02, 0x02, 0x37, 0x02, 0xdf, 0x00, 0x2f, 0x03, 0x04, 0x37, 0x01, 0x38, 0x00};
+// The level-1 post-processor programs this engine decodes natively: what its own makeConfig + compiler emit for
+// rb = 0..7 raw offset bits (blocks of 16 MiB << rb) with and without the E8E9 inverse.  rb = 0 / no E8E9 is the
+// golden 302-byte program; the others are pinned by decode parity (the reference's LZBuffer stream under these
+// programs is restored by the reference's own PostProcessor: tests/test_config_cpu.py).
+const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8) {
+  static std::vector<u8> tab[8][2];
+  static bool built = false;
+  if (!built) {
+    for (u32 r = 0; r < 8; ++r)
+      for (int e = 0; e < 2; ++e) {
+        char m[64];
+        snprintf(m, sizeof m, "x%u,%d,5,0,3,24", 4 + r, e ? 5 : 1);
+        std::string xm; int args[9]; std::vector<u8> hdr;
+        if (zpq_build_config(nullptr, m, nullptr, 0, &xm, args, &hdr, &tab[r][e]) != ZPQ_OK) tab[r][e].clear();
+      }
+    built = true;
+  }
+  static const std::vector<u8> none;
+  return rb < 8 ? tab[rb][e8 ? 1 : 0] : none;
+}
+
 namespace {
 #define kPcompLz1 zpq_pcomp_lz1
 
@@ -48,6 +69,7 @@ struct Config {
   std::vector<u8> header;   // hsize[2] hh hm ph pm n COMP 0 HCOMP 0 (config.hip, == libzpaq::Compiler)
   std::vector<u8> pcomp;    // post-processor bytecode, empty = PASS
   u32 ncomp;                // > 0: the Encoder is the arithmetic coder over the context-mixing model
+  bool e8;                  // E8E9 applied to the block before LZ77 (args[1] = 5); the post-processor undoes it
   std::string xmethod;
 };
 
@@ -60,10 +82,11 @@ int parse_method(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, C
   const std::string& m = cfg->xmethod;
   cfg->ncomp = cfg->header.size() > 6 ? cfg->header[6] : 0;
   const int pre = cfg->args[1];
+  cfg->e8 = pre == 5;
   if (m[0] == '0') cfg->kind = KIND_STORE0;
   else if (pre == 0) cfg->kind = KIND_STOREX;
-  else if (pre == 1 && cfg->args[0] <= 4) cfg->kind = KIND_LZ1;
-  else if (pre >= 4 && pre <= 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': E8E9 pre-processor not implemented", m.c_str());
+  else if ((pre == 1 || pre == 5) && cfg->args[0] <= 6) cfg->kind = KIND_LZ1;     // blocks up to 64 MiB (rb = 0..2)
+  else if (pre >= 4 && pre <= 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': this E8E9 / pre-processor combination is not implemented", m.c_str());
   else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s' not implemented", m.c_str());
   if (cfg->kind != KIND_STORE0 && (u64)n > (1ull << (20 + cfg->args[0])))
     return zpq_fail(ctx, ZPQ_ERR_ARG, "block larger than 2^%d", 20 + cfg->args[0]);
@@ -147,6 +170,8 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   size_t lz_out_total = 0, prefix_total = 0;
   int first_err = ZPQ_OK;
   std::vector<u8> hostbuf;
+  std::vector<size_t> e8_jobs;          // jobs whose input is E8E9-transformed (on a copy) before LZ77
+  size_t e8_total = 0;
   std::vector<size_t> cm_jobs;          // jobs whose Encoder is the context-mixing coder
   size_t encin_total = 0;
   for (size_t i = 0; i < njobs; ++i) {
@@ -173,6 +198,7 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     }
     size_t body_cap = jobs[i].n;
     if (cfg[i].kind == KIND_LZ1) {
+      if (cfg[i].e8) { e8_jobs.push_back(i); e8_total += (((size_t)jobs[i].n + 64 + 63) & ~(size_t)63) + ((((size_t)jobs[i].n + 31) / 32 * 4 + 63) & ~(size_t)63); }
       lz_of[i] = lz.size();
       zpq_lz77_job j;
       memset(&j, 0, sizeof j);
@@ -213,6 +239,21 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     int rc = zpq_sha1_chains_on(ctx, ctx->stream2, (const u8*)0, d_sha_off, d_sha_len, sha_job.size(), d_dig);
     if (rc) return rc;
     ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
+  }
+  // E8E9 front end: the transform runs on a copy (the block checksum and the caller see the original bytes)
+  if (!e8_jobs.empty()) {
+    u8* d_e8 = (u8*)zpq_scratch(ctx, 21, e8_total + 64);
+    if (!d_e8) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "e8e9 scratch");
+    size_t o = 0;
+    for (size_t i : e8_jobs) {
+      u8* copy = d_e8 + o; o += ((size_t)jobs[i].n + 64 + 63) & ~(size_t)63;
+      u32* bits = (u32*)(d_e8 + o); o += (((size_t)jobs[i].n + 31) / 32 * 4 + 63) & ~(size_t)63;
+      if (jobs[i].n) ZPQ_HIP(ctx, hipMemcpyAsync(copy, jobs[i].in, jobs[i].n, hipMemcpyDeviceToDevice, st));
+      ZPQ_HIP(ctx, hipMemsetAsync(copy + jobs[i].n, 0, 64, st));
+      int rc = zpq_e8e9_forward_launch(ctx, st, copy, jobs[i].n, bits);
+      if (rc) return rc;
+      lz[lz_of[i]].d_in = copy;
+    }
   }
   // LZ77 streams
   {
@@ -350,7 +391,7 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
   hipStream_t st = ctx->stream;
   // kind: 0 stored+PASS, 2 stored + the known LZ77-L1 PCOMP (native decoder), 3 generic (context-model
   // coded and/or an arbitrary PCOMP: cm.hip decoder + ZPAQL interpreter)
-  struct Parsed { u32 kind; u32 pay_off, pay_len; int has_sha; u8 sha[20]; u32 rb; std::vector<u8> payload;
+  struct Parsed { u32 kind; bool e8; u32 pay_off, pay_len; int has_sha; u8 sha[20]; u32 rb; std::vector<u8> payload;
                   std::vector<u8> header; u32 ncomp, ph, pm; };
   std::vector<Parsed> ps(njobs);
   int first_err = ZPQ_OK;
@@ -408,14 +449,15 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
     else { bad(ZPQ_ERR_FORMAT, "missing segment end"); continue; }
     if (p >= n || a[p] != 255) { bad(ZPQ_ERR_METHOD, "multi-segment block"); continue; }
     j.consumed = p + 1;
-    P.rb = pm > 24 ? pm - 24 : 0;
+    P.rb = pm > 24 ? pm - 24 : 0; P.e8 = false;
     if (P.ncomp) { P.kind = 3; P.pay_off = 0; }
     else if (P.payload[0] == 0) { P.kind = 0; P.pay_off = 1; }
     else {
       if (P.payload.size() < 3) { bad(ZPQ_ERR_FORMAT, "truncated PCOMP"); continue; }
       const u32 psize = P.payload[1] | (u32)P.payload[2] << 8;
-      if (psize == 302 && P.payload.size() >= 3 + 302 && memcmp(&P.payload[3], kPcompLz1, 302) == 0) { P.kind = 2; P.pay_off = 3 + 302; }
-      else { P.kind = 3; P.pay_off = 0; }
+      const std::vector<u8>& plain = zpq_known_pcomp(P.rb, false);
+      if (!plain.empty() && psize == plain.size() && P.payload.size() >= 3 + psize && memcmp(&P.payload[3], plain.data(), psize) == 0) { P.kind = 2; P.pay_off = 3 + psize; }
+      else { P.kind = 3; P.pay_off = 0; }   // (E8E9 variants: generic path below recognises them)
     }
     P.pay_len = (u32)P.payload.size() - P.pay_off;
     in_total += ((size_t)P.pay_len + 31) & ~(size_t)15;
@@ -502,12 +544,26 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
       ZPQ_HIP(ctx, hipMemcpyAsync(pc.data(), d_dec + 3, psize, hipMemcpyDeviceToHost, st));
       ZPQ_HIP(ctx, hipStreamSynchronize(st));
       const u8* d_data = d_dec + 3 + psize; const u32 dlen = dec_len - 3 - psize;
-      if (psize == 302 && memcmp(pc.data(), kPcompLz1, 302) == 0) {
+      const std::vector<u8>& k0 = zpq_known_pcomp(P.rb, false);
+      const std::vector<u8>& k1 = zpq_known_pcomp(P.rb, true);
+      const bool is0 = !k0.empty() && psize == k0.size() && memcmp(pc.data(), k0.data(), psize) == 0;
+      const bool is1 = !is0 && !k1.empty() && psize == k1.size() && memcmp(pc.data(), k1.data(), psize) == 0;
+      if (is0 || is1) {
         zpq_lz77_dec_job d;
         memset(&d, 0, sizeof d);
-        d.d_in = d_data; d.n = dlen; d.rb = P.rb; d.d_out = outp[i]; d.out_cap = jobs[i].out_cap;
+        u8* d_tmp = nullptr;
+        if (is1) {                      // LZ77 into a temporary, E8E9 inverse into the output
+          d_tmp = (u8*)zpq_scratch(ctx, 22, (size_t)jobs[i].out_cap + 128);
+          if (!d_tmp) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+        }
+        d.d_in = d_data; d.n = dlen; d.rb = P.rb; d.d_out = is1 ? d_tmp : outp[i]; d.out_cap = jobs[i].out_cap;
         int rc = zpq_lz77_decode_dev(ctx, &d, 1);
         if (rc || d.status) { fail_job(d.status ? d.status : rc); continue; }
+        if (is1) {
+          ZPQ_HIP(ctx, hipMemsetAsync(d_tmp + d.out_len, 0, 64, st));
+          rc = zpq_e8e9_inverse_dev(ctx, d_tmp, outp[i], d.out_len);
+          if (rc) { fail_job(rc); continue; }
+        }
         jobs[i].out_len = d.out_len;
       } else {
         u32 olen = 0;

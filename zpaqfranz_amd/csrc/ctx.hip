@@ -169,6 +169,24 @@ int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZPQ_OK;
 }
+int zpq_copy_peer(zpq_ctx* dst_ctx, void* dst_dev, zpq_ctx* src_ctx, const void* src_dev, size_t bytes) {
+  if (!dst_ctx || !src_ctx) return ZPQ_ERR_ARG;
+  if (bytes == 0) return ZPQ_OK;
+  (void)hipSetDevice(src_ctx->device);
+  ZPQ_HIP(src_ctx, hipStreamSynchronize(src_ctx->stream));       // the source bytes are final
+  (void)hipSetDevice(dst_ctx->device);
+  if (dst_ctx->device == src_ctx->device) {
+    ZPQ_HIP(dst_ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
+  } else {
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, dst_ctx->device, src_ctx->device);
+    if (can) (void)hipDeviceEnablePeerAccess(src_ctx->device, 0);   // already enabled is not an error worth reporting
+    (void)hipGetLastError();
+    ZPQ_HIP(dst_ctx, hipMemcpyPeerAsync(dst_dev, dst_ctx->device, src_dev, src_ctx->device, bytes, dst_ctx->stream));
+  }
+  ZPQ_HIP(dst_ctx, hipStreamSynchronize(dst_ctx->stream));
+  return ZPQ_OK;
+}
 int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   ZPQ_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));

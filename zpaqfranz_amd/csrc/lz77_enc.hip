@@ -24,6 +24,7 @@
 // Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
 // n bytes: n read + r*n written (r = LZ ratio); the hash tables are implementation traffic.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "zpq_internal.h"
 
@@ -33,7 +34,7 @@ constexpr u32 kMaxMatch = (1u << 14) * 3;   // ZSFX/libzpaq.cpp:6258 (BUFSIZE*3)
 constexpr u32 kMaxLiteral = (1u << 14) / 4;  // :6259
 constexpr u32 kCap = 32;                     // speculative compare cap (bytes)
 constexpr u32 kNoCand = 0xffffffffu;
-constexpr u32 kSegBytes = 1u << 20;          // speculation segment (more segments do not help: the parse is bound by random-access throughput)
+constexpr u32 kSegMin = 1u << 20;            // smallest speculation segment (more segments do not help: the parse is bound by random-access throughput)
 constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB blocks at most)
 
 struct LzCfg {
@@ -746,8 +747,14 @@ static T* carve(u8*& p, size_t count) {
   return r;
 }
 
+// HBM a job needs while it is parsed with segments of kSegBytes: 2*segments-1 hash tables plus the token lists
+static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
+  const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
+  return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + ((size_t)z.n / 4 + 2 + 2 * nseg) * 40;
+}
+
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
-static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) {
+static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes) {
   hipStream_t st = ctx->stream;
   const size_t nj = hi - lo;
   std::vector<LzJobDev> hj(nj);
@@ -853,7 +860,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi) 
         ZPQ_HIP(ctx, hipGetLastError());
       }
       if (srange[k].second) {
-        ZPQ_LAUNCH(ctx, "lz77_table_scatter_kernel", st, lz77_table_scatter_kernel, dim3(kSegBytes / 1024, (unsigned)srange[k].second),
+        ZPQ_LAUNCH(ctx, "lz77_table_scatter_kernel", st, lz77_table_scatter_kernel, dim3(std::min<u32>(kSegBytes / 1024, 4096), (unsigned)srange[k].second),
                    dim3(256), d_scat + srange[k].first);
         ZPQ_HIP(ctx, hipGetLastError());
       }
@@ -933,20 +940,39 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
     if (jobs[i].out_cap < zpq_lz77_bound(jobs[i].n)) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: out_cap too small", i);
     if (((uintptr_t)jobs[i].d_out & 3) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: d_out must be 4-byte aligned", i);
   }
-  // batches whose hash tables (2*segments-1 copies each) fit a fixed HBM budget
+  // A wave parses one segment on its own copy of the hash table (64 MiB for -m1), so HBM bounds the waves in flight.
+  // Segment size: 1 MiB while everything fits one batch; with many blocks the segments grow (up to one per block:
+  // "one wavefront per ZPAQ block") until the batch fits or there are too few waves left to fill the chip, and what
+  // still does not fit runs in batches.
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  const size_t budget = std::max<size_t>((size_t)2 << 30, std::min<size_t>((size_t)48 << 30, (free_b + ctx->scratch_cap[0]) / 3));
+  size_t budget = std::max<size_t>((size_t)2 << 30, (free_b + ctx->scratch_cap[0] + ctx->scratch_cap[1]) / 10 * 6);
+  if (const char* e = getenv("ZPQ_LZ_BUDGET_MB")) budget = (size_t)strtoull(e, 0, 10) << 20;
+  u32 seg = kSegMin, max_n = 0;
+  if (const char* e = getenv("ZPQ_LZ_SEG")) seg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));
+  else {
+    for (size_t i = 0; i < njobs; ++i) max_n = std::max(max_n, jobs[i].n);
+    for (;;) {
+      size_t bytes = 0, nseg = 0;
+      for (size_t i = 0; i < njobs; ++i) { bytes += job_bytes(jobs[i], seg); nseg += std::max<u32>(1, (u32)(((u64)jobs[i].n + seg - 1) / seg)); }
+      if (bytes <= budget || seg >= max_n || nseg <= 2048 || seg >= (1u << 30)) break;
+      seg <<= 1;
+    }
+  }
+  // batches of about equal size (a last batch of a few blocks would leave the chip idle behind its slowest wave)
+  size_t all_bytes = 0;
+  for (size_t i = 0; i < njobs; ++i) all_bytes += job_bytes(jobs[i], seg);
+  const size_t nbatch = (all_bytes + budget - 1) / budget;
+  const size_t target = nbatch > 1 ? std::min(budget, all_bytes / nbatch + (all_bytes / nbatch) / 16) : budget;
   size_t lo = 0;
   while (lo < njobs) {
     size_t hi = lo, bytes = 0;
     while (hi < njobs) {
-      const u32 nseg = std::max<u32>(1, (jobs[hi].n + kSegBytes - 1) / kSegBytes);
-      const size_t b = ((size_t)4 << jobs[hi].args[5]) * (2 * (size_t)nseg - 1);
-      if (hi > lo && bytes + b > budget) break;
+      const size_t b = job_bytes(jobs[hi], seg);
+      if (hi > lo && bytes + b > target) break;
       bytes += b; ++hi;
     }
-    int rc = encode_batch(ctx, jobs, lo, hi);
+    int rc = encode_batch(ctx, jobs, lo, hi, seg);
     if (rc) return rc;
     lo = hi;
   }

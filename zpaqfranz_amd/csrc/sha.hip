@@ -157,16 +157,17 @@ __device__ __forceinline__ void sha256_rounds(u32 (&w)[16], u32 (&s)[8]) {
       u32 s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
       wt = w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
     }
-    u32 t1 = add3(h, xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), bfi(e, f, g)) + K256[t] + wt;
-    u32 t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + maj3(a, b, c);
-    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    const u32 t1 = add3(add3(h, xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), bfi(e, f, g)), K256[t], wt);
+    const u32 na = add3(t1, xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)), maj3(a, b, c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = na;
   }
   s[0] += a; s[1] += b; s[2] += c; s[3] += d; s[4] += e; s[5] += f; s[6] += g; s[7] += h;
 }
 
 __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                               const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
-                                                              u32* __restrict__ counter, const u32* __restrict__ order) {
+                                                              u32* __restrict__ counter, const u32* __restrict__ order,
+                                                              u64 chain_min_len) {
   bool have = false, marker = false;
   u32 idx = 0;
   const u8* p = nullptr;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restric
       idx = atomicAdd(counter, 1u);
       if (idx >= n) return;
       if (order) idx = order[idx];
+      if (len[idx] >= chain_min_len) continue;     // long extents: one wave each (sha256_chain_kernel)
       p = base + off[idx];
       total = rem = len[idx];
       s[0] = 0x6a09e667; s[1] = 0xbb67ae85; s[2] = 0x3c6ef372; s[3] = 0xa54ff53a;
@@ -270,6 +272,79 @@ __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ b
   if (lane == 0) {
     u32* o = (u32*)(digests + (size_t)idx * 20);
     o[0] = bswap32(s.a); o[1] = bswap32(s.b); o[2] = bswap32(s.c); o[3] = bswap32(s.d); o[4] = bswap32(s.e);
+  }
+}
+
+// SHA-256 of a long extent (a whole file on the verify side): same shape as sha1_chain_kernel.  The 64 lanes load,
+// byte-swap and expand the schedules of the next 64 blocks (W[t] + K[t], 64 words per lane); the 64 serial rounds of
+// each block then run on every lane's own schedule from the uniform state and lane b's result is broadcast with
+// eight v_readlane.  A wave issues one instruction per ~4 cycles whatever its dependencies, so what counts is the
+// instruction count on the chain: 14 per round (the schedule's 10 per word are off the chain).
+__device__ __forceinline__ void sha256_rounds_lane(const u32 (&wk)[64], int blk, u32 (&s)[8]) {
+  u32 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    const u32 t1 = add3(h, xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), bfi(e, f, g)) + wk[t];
+    const u32 na = add3(t1, xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)), maj3(a, b, c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = na;
+  }
+  s[0] += __builtin_amdgcn_readlane(a, blk); s[1] += __builtin_amdgcn_readlane(b, blk);
+  s[2] += __builtin_amdgcn_readlane(c, blk); s[3] += __builtin_amdgcn_readlane(d, blk);
+  s[4] += __builtin_amdgcn_readlane(e, blk); s[5] += __builtin_amdgcn_readlane(f, blk);
+  s[6] += __builtin_amdgcn_readlane(g, blk); s[7] += __builtin_amdgcn_readlane(h, blk);
+}
+
+// persistent waves: wave w takes the extents w, w + waves, ... whose length is at least `min_len`
+__global__ __launch_bounds__(64) void sha256_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                          const u64* __restrict__ len, u32 n, u64 min_len,
+                                                          u8* __restrict__ digests) {
+  const int lane = lane_id();
+  for (u32 idx = blockIdx.x; idx < n; idx += gridDim.x) {
+    const u64 total = len[idx];
+    if (total < min_len) continue;
+    const u8* p = base + off[idx];
+    const u64 nfull = total >> 6;
+    u32 s[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    for (u64 b0 = 0; b0 < nfull; b0 += 64) {
+      const u64 mine = b0 + (u64)lane;
+      u32 w[64];
+      if (mine < nfull) {
+        const u32x4_u* q = (const u32x4_u*)(p + mine * 64);
+        const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+        w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+        w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = 0;
+      }
+#pragma unroll
+      for (int t = 16; t < 64; ++t) {
+        const u32 w15 = w[t - 15], w2 = w[t - 2];
+        w[t] = add3(w[t - 16], xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3), w[t - 7]) + xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+      }
+#pragma unroll
+      for (int t = 0; t < 64; ++t) w[t] += K256[t];
+      const int cnt = nfull - b0 < 64 ? (int)(nfull - b0) : 64;
+      for (int b = 0; b < cnt; ++b) sha256_rounds_lane(w, b, s);
+    }
+    {
+      const u8* q = p + nfull * 64;
+      u32 rem = (u32)(total & 63);
+      bool marker = false, last = false;
+      while (!last) {
+        u32 w[16];
+        last = tail_block(w, q, rem, marker, total);
+        q += rem; rem = 0;
+        sha256_rounds(w, s);
+      }
+    }
+    if (lane == 0) {
+      u32* o = (u32*)(digests + (size_t)idx * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = bswap32(s[i]);
+    }
   }
 }
 
@@ -414,9 +489,19 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
   const int grid = persistent_grid(ctx, n, 2);
   const u32* order = extent_order(ctx, ctx->stream, d_len, n, grid);
+  // extents of 1 MiB and more get a wave each (a lane hashes ~25 MB/s, a wave-wide chain ~1.5x that and the chip
+  // has waves to spare on the verify side, where extents are whole files); the rest one lane each
+  u64 chain_min = 1u << 20;
+  if (const char* e = getenv("ZPQ_SHA256_CHAIN_MIN")) chain_min = strtoull(e, 0, 10);
   ZPQ_LAUNCH(ctx, "sha256_extents_kernel", ctx->stream, sha256_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n,
-             d_digests, counter, order);
+             d_digests, counter, order, chain_min);
   ZPQ_HIP(ctx, hipGetLastError());
+  {
+    const unsigned waves = (unsigned)std::min<size_t>(n, (size_t)ctx->cu_count * 16);
+    ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream, sha256_chain_kernel, dim3(waves), dim3(64), d_base, d_off, d_len, (u32)n, chain_min,
+               d_digests);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
   return ZPQ_OK;
 }
 

@@ -30,7 +30,7 @@ struct WalkJob {
 
 struct WalkInfo {
   i32 status;         // ZPQ_OK, a negative zpq_status, or 1 = "host path"
-  u32 kind;           // 0 PASS, 2 LZ77 level 1
+  u32 kind;           // 0 PASS, 2 LZ77 level 1, 4 LZ77 level 1 + E8E9 inverse
   u32 hdr_off, hsize, ncomp, ph, pm;
   u32 pay_len;        // stored payload bytes including the post-processor preamble
   u32 skip;           // preamble bytes stripped (1 or 305)
@@ -42,7 +42,8 @@ struct WalkInfo {
 
 __constant__ u8 c_tag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
 
-__global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restrict__ jobs, u32 njobs, const u8* __restrict__ lz1,
+// progs: u32 off[16], u32 len[16], then the bytes of the known level-1 post-processor programs; index 2*rb + e8
+__global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restrict__ jobs, u32 njobs, const u8* __restrict__ progs,
                                                           WalkInfo* __restrict__ info, u64* __restrict__ t_src,
                                                           u64* __restrict__ t_dst, u32* __restrict__ t_len) {
   const u32 i = blockIdx.x * 64u + threadIdx.x;
@@ -79,10 +80,23 @@ __global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restr
   u32 skip;
   if (f[0] == 0) { I.kind = 0; skip = 1; }
   else if (f[0] == 1) {
-    if (k0 < 3 + 302) return done(1);                // preamble split over sub-blocks: host path
-    if ((f[1] | (u32)f[2] << 8) != 302) return done(1);
-    for (int k = 0; k < 302; ++k) if (f[3 + k] != lz1[k]) return done(1);
-    I.kind = 2; skip = 3 + 302;
+    if (k0 < 3) return done(1);
+    const u32 psize = f[1] | (u32)f[2] << 8;
+    if (k0 < 3 + psize) return done(1);              // preamble split over sub-blocks: host path
+    const u32 rb = I.pm > 24 ? I.pm - 24 : 0;
+    if (rb > 7) return done(1);
+    const u32* poff = (const u32*)progs; const u32* plen = poff + 16;
+    u32 which = 2;
+    for (u32 e = 0; e < 2 && which == 2; ++e) {
+      const u32 ix = 2 * rb + e;
+      if (plen[ix] == 0 || plen[ix] != psize) continue;
+      const u8* q = progs + poff[ix];
+      bool same = true;
+      for (u32 k = 0; k < psize; ++k) same &= f[3 + k] == q[k];
+      if (same) which = e;
+    }
+    if (which == 2) return done(1);                  // some other program: ZPAQL machine on the host-parsed path
+    I.kind = which ? 4 : 2; skip = 3 + psize;
   } else return done(ZPQ_ERR_FORMAT);
   I.skip = skip;
   u8* dst = I.kind == 0 ? J.out : J.stage;
@@ -155,6 +169,16 @@ __global__ __launch_bounds__(256) void digest_compare_kernel(const u8* __restric
 
 }  // namespace
 
+// The level-1 post-processor programs decoded natively (diagnostic / tests; host only, ctx may be NULL).
+extern "C" int zpq_known_pcomp_bytes(uint32_t rb, int e8e9, uint8_t* out, size_t cap, size_t* len) {
+  const std::vector<u8>& pc = zpq_known_pcomp(rb, e8e9 != 0);
+  if (len) *len = pc.size();
+  if (pc.empty()) return ZPQ_ERR_ARG;
+  if (pc.size() > cap) return ZPQ_ERR_CAPACITY;
+  memcpy(out, pc.data(), pc.size());
+  return ZPQ_OK;
+}
+
 extern "C" int zpq_digest_compare_dev(zpq_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, size_t n, uint32_t digest_size,
                                       uint64_t* mismatches, uint64_t* first_mismatch) {
   if (ctx) (void)hipSetDevice(ctx->device);
@@ -198,7 +222,7 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   u8* d_meta = (u8*)zpq_scratch(ctx, 12, njobs * per_block + 1024);
   u8* d_tab = (u8*)zpq_scratch(ctx, 13, tab_total * 20 + 256);
   u8* d_stage = (u8*)zpq_scratch(ctx, 14, stage_total + 64);
-  u8* d_lz1 = (u8*)zpq_scratch(ctx, 15, 512);
+  u8* d_lz1 = (u8*)zpq_scratch(ctx, 15, 16384);
   if (!d_meta || !d_tab || !d_stage || !d_lz1) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode scratch");
   static_assert(sizeof(WalkJob) % 8 == 0 && sizeof(zpq_lzdec_dev) % 8 == 0, "record arrays must keep 8-byte alignment");
   static_assert(sizeof(WalkInfo) % 4 == 0 && sizeof(FinishJob) % 4 == 0 && sizeof(FinishOut) % 4 == 0, "record arrays must keep 4-byte alignment");
@@ -219,7 +243,23 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
     for (size_t i = 0; i < njobs; ++i) { wj[i].stage = d_stage + so; so += ((size_t)jobs[i].n + 64 + 63) & ~(size_t)63; }
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_wj, wj.data(), njobs * sizeof(WalkJob), hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_lz1, zpq_pcomp_lz1, 302, hipMemcpyHostToDevice, st));
+  {
+    static std::vector<u8> progs;                    // built once per process: table + bytes
+    static bool built = false;
+    if (!built) {
+      progs.assign(128, 0);
+      for (u32 r = 0; r < 8; ++r)
+        for (u32 e = 0; e < 2; ++e) {
+          const std::vector<u8>& pc = zpq_known_pcomp(r, e != 0);
+          const u32 off = (u32)progs.size(), len = (u32)pc.size();
+          memcpy(&progs[4 * (2 * r + e)], &off, 4); memcpy(&progs[64 + 4 * (2 * r + e)], &len, 4);
+          progs.insert(progs.end(), pc.begin(), pc.end());
+        }
+      built = true;
+    }
+    if (progs.size() > 16384) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "post-processor table");
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_lz1, progs.data(), progs.size(), hipMemcpyHostToDevice, st));
+  }
   ZPQ_LAUNCH(ctx, "unframe_walk_kernel", st, unframe_walk_kernel, dim3((unsigned)((njobs + 63) / 64)), dim3(64), d_wj, (u32)njobs, d_lz1,
              d_info, t_src, t_dst, t_len);
   ZPQ_HIP(ctx, hipGetLastError());
@@ -230,8 +270,11 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   int first_err = ZPQ_OK;
   std::vector<FinishJob> fj(njobs);
   std::vector<zpq_lzdec_dev> lzj;
+  std::vector<size_t> lzj_job;
   std::vector<u64> shaoff(njobs);
   std::vector<size_t> host_path;
+  std::vector<size_t> e8_jobs;                      // LZ77 output goes to a temporary, the E8E9 inverse writes the caller's buffer
+  size_t e8_total = 0, e8_nstate = 0; u32 e8_maxcap = 0;
   for (size_t i = 0; i < njobs; ++i) {
     const WalkInfo& I = info[i];
     memset(&fj[i], 0, sizeof fj[i]);
@@ -252,7 +295,30 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
       d.in = wj[i].stage; d.n = I.pay_len - I.skip; d.rb = I.pm > 24 ? I.pm - 24 : 0;
       d.out = jobs[i].out; d.out_cap = jobs[i].out_cap; d.result = d_lzres + 2 * lzj.size();
       if (d.rb > 8) { jobs[i].status = ZPQ_ERR_FORMAT; fj[i].kind = 0xffffffffu; if (!first_err) first_err = ZPQ_ERR_FORMAT; continue; }
-      lzj.push_back(d);
+      if (I.kind == 4) {
+        e8_jobs.push_back(i);
+        e8_total += ((size_t)jobs[i].out_cap + 128 + 63) & ~(size_t)63;
+        e8_nstate += (size_t)jobs[i].out_cap / 1024 + 2;
+        if (jobs[i].out_cap > e8_maxcap) e8_maxcap = jobs[i].out_cap;
+      }
+      lzj.push_back(d); lzj_job.push_back(i);
+    }
+  }
+  u8* d_e8 = nullptr; u8* d_e8meta = nullptr;
+  std::vector<zpq_e8inv_job> e8j;
+  if (!e8_jobs.empty()) {
+    d_e8 = (u8*)zpq_scratch(ctx, 22, e8_total + 64);
+    d_e8meta = (u8*)zpq_scratch(ctx, 20, e8_jobs.size() * sizeof(zpq_e8inv_job) + (2 * e8_nstate + 16) * 4 + 64);
+    if (!d_e8 || !d_e8meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "e8e9 staging");
+    size_t o = 0, so = 0, q = 0;
+    for (size_t k = 0; k < lzj.size(); ++k) {
+      const size_t i = lzj_job[k];
+      if (q >= e8_jobs.size() || e8_jobs[q] != i) continue;
+      zpq_e8inv_job e;
+      e.in = d_e8 + o; e.out = jobs[i].out; e.len = d_lzres + 2 * k; e.cap = jobs[i].out_cap; e.st_base = (u32)so;
+      lzj[k].out = d_e8 + o;
+      o += ((size_t)jobs[i].out_cap + 128 + 63) & ~(size_t)63; so += (size_t)jobs[i].out_cap / 1024 + 2; ++q;
+      e8j.push_back(e);
     }
   }
   int rc = zpq_gather_dev(ctx, (const u8*)0, t_src, t_len, t_dst, tab_total, (u8*)0);
@@ -260,6 +326,13 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   if (!lzj.empty()) {
     ZPQ_HIP(ctx, hipMemcpyAsync(d_lzj, lzj.data(), lzj.size() * sizeof(zpq_lzdec_dev), hipMemcpyHostToDevice, st));
     if ((rc = zpq_lz77_decode_launch(ctx, st, d_lzj, lzj.size()))) return rc;
+  }
+  if (!e8j.empty()) {
+    zpq_e8inv_job* d_e8j = (zpq_e8inv_job*)d_e8meta;
+    u32* d_state = (u32*)(d_e8meta + ((e8j.size() * sizeof(zpq_e8inv_job) + 63) & ~(size_t)63));
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_e8j, e8j.data(), e8j.size() * sizeof(zpq_e8inv_job), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipMemsetAsync(d_state + 2 * e8_nstate, 0, 4, st));
+    if ((rc = zpq_e8e9_inverse_launch(ctx, st, d_e8j, e8j.size(), e8_maxcap, d_state, e8_nstate))) return rc;
   }
   // 3. checksums of the results, compared on the device
   ZPQ_HIP(ctx, hipMemcpyAsync(d_fj, fj.data(), njobs * sizeof(FinishJob), hipMemcpyHostToDevice, st));

@@ -91,9 +91,17 @@ struct zpq_lzdec_dev {
 int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs);
 // the 302-byte LZ77 level-1 post-processor program (rb = 0, no E8E9): golden, AUTOTEST/sha256.zpaq i blocks
 extern const u8 zpq_pcomp_lz1[302];
+// the level-1 post-processor programs decoded natively: rb = 0..7 raw offset bits, with / without the E8E9 inverse
+const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8);
 // decode path for blocks that need host parsing (context-model coded data, arbitrary PCOMP programs): jobs[].in are
 // HOST pointers; jobs[].out are device pointers when out_dev, else host pointers (block.hip)
 int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify, bool out_dev);
+
+// E8E9 (e8e9.hip): launches without host round trips.  Inverse jobs: device array of zpq_e8inv_job; d_state holds
+// 2*nstate+1 words (assumed/left states per 1 KiB segment, and a counter of re-walked segments that must be zeroed).
+struct zpq_e8inv_job { const u8* in; u8* out; const u32* len; u32 cap; u32 st_base; };
+int zpq_e8e9_inverse_launch(zpq_ctx* ctx, hipStream_t st, const void* d_jobs, size_t njobs, u32 max_cap, u32* d_state, size_t nstate);
+int zpq_e8e9_forward_launch(zpq_ctx* ctx, hipStream_t st, u8* d_buf, size_t n, u32* bits);
 
 // internal cross-TU entry points
 // method string -> expanded x/0 method, $1..$9, block header bytes (hsize..HCOMP 0) and PCOMP bytecode

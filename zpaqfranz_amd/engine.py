@@ -100,6 +100,9 @@ def load():
     L.zpq_compress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_compress_blocks.argtypes = [C.c_void_p, C.POINTER(BlockJob), C.c_size_t]
     L.zpq_decompress_blocks.argtypes = [C.c_void_p, C.POINTER(UnblockJob), C.c_size_t, C.c_int]
+    L.zpq_decompress_blocks_dev.argtypes = [C.c_void_p, C.POINTER(UnblockJob), C.c_size_t, C.c_int]
+    L.zpq_digest_compare_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.zpq_file_checksums_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.zpq_e8e9_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.zpq_expand_method.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.zpq_make_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -236,6 +239,34 @@ class Engine:
         out = C.create_string_buffer(max(1, n * dsz))
         self._ck(fn(self.ctx, ptrs, lens, n, out))
         return [out.raw[i * dsz:(i + 1) * dsz] for i in range(n)]
+
+    def file_checksums_dev(self, d_base, file_off, crc32=True, xxh64=True, blake3=True):
+        """CRC-32, XXH64 and BLAKE3 of the files [file_off[f], file_off[f+1]) of a device buffer -> three lists (or None)."""
+        n = len(file_off) - 1
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        c = (C.c_uint32 * max(1, n))() if crc32 else None
+        x = (C.c_uint64 * max(1, n))() if xxh64 else None
+        b = (C.c_ubyte * max(1, 32 * n))() if blake3 else None
+        self._ck(self.L.zpq_file_checksums_dev(self.ctx, d_base, arr, n, c, x, b))
+        return (list(c[:n]) if crc32 else None, list(x[:n]) if xxh64 else None,
+                [bytes(b[32 * i:32 * i + 32]) for i in range(n)] if blake3 else None)
+
+    def file_checksums(self, files, **kw):
+        """Host convenience used by the tests: list of bytes -> (crc32 list, xxh64 list, blake3 list)."""
+        file_off = [0]
+        for f in files:
+            file_off.append(file_off[-1] + len(f))
+        d = self.upload(b"".join(files))
+        try:
+            return self.file_checksums_dev(d.ptr, file_off, **kw)
+        finally:
+            d.free()
+
+    def digest_compare_dev(self, d_a, d_b, n, digest_size):
+        """(number of differing digests, index of the first one) of two device digest arrays."""
+        m, f = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.zpq_digest_compare_dev(self.ctx, d_a, d_b, n, digest_size, C.byref(m), C.byref(f)))
+        return m.value, f.value
 
     def sha1_extents_dev(self, d_base, d_off, d_len, n, d_digests):
         self._ck(self.L.zpq_sha1_extents_dev(self.ctx, d_base, d_off, d_len, n, d_digests))
@@ -424,6 +455,29 @@ class Engine:
                      sha1=bytes(jobs[i].sha1)) for i in range(n)]
 
 
+    def decompress_blocks_dev(self, jobs, n, verify=True):
+        """zpq_decompress_blocks_dev on a prepared UnblockJob array (device pointers); per-job status carries the outcome."""
+        return self.L.zpq_decompress_blocks_dev(self.ctx, jobs, n, int(verify))
+
+    def decompress_blocks_resident(self, framed, out_caps, verify=True):
+        """Host convenience used by the tests: uploads the framed blocks, decodes them device to device in ONE call,
+        downloads the results (same return shape as decompress_blocks)."""
+        n = len(framed)
+        jobs = (UnblockJob * max(1, n))()
+        ins = [self.upload(b) for b in framed]
+        outs = [self.alloc(max(1, c)) for c in out_caps]
+        try:
+            for i in range(n):
+                jobs[i].in_, jobs[i].n = ins[i].ptr, len(framed[i])
+                jobs[i].out, jobs[i].out_cap = outs[i].ptr, out_caps[i]
+            self.decompress_blocks_dev(jobs, n, verify)
+            return [dict(status=jobs[i].status, data=outs[i].download(jobs[i].out_len), consumed=jobs[i].consumed,
+                         sha1=bytes(jobs[i].sha1)) for i in range(n)]
+        finally:
+            for b in ins + outs:
+                b.free()
+
+
 # ---- journaling archives (zpaqfranz_amd/shim/jidac_gpu.cpp) ---------------------------------------------
 _shim = None
 
@@ -440,6 +494,8 @@ def load_shim():
         S.zpqj_free.restype = None
         S.zpqj_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_int64, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        S.zpqj_add_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_int64, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_extract.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _shim = S
@@ -447,8 +503,12 @@ def load_shim():
 
 
 def jidac_add(eng, archive, files, version_date, method="14", dates=None):
-    """files: list of (name, bytes).  Returns (bytes to append to the archive, stats dict)."""
+    """files: list of (name, bytes).  Returns (bytes to append to the archive, stats dict).  `eng` may be a list of
+    engines (one per GPU): the files are then sharded across them (zpqj_add_multi), with identical output."""
     S = load_shim()
+    engs = list(eng) if isinstance(eng, (list, tuple)) else None
+    if engs:
+        eng = engs[0]
     n = len(files)
     names = (C.c_char_p * max(1, n))(*[f[0].encode() for f in files])
     keep = [C.create_string_buffer(bytes(f[1]), max(1, len(f[1]))) for f in files]
@@ -457,8 +517,13 @@ def jidac_add(eng, archive, files, version_date, method="14", dates=None):
     dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
     out, out_len = C.c_void_p(), C.c_size_t(0)
     stats = (C.c_uint64 * 6)()
-    rc = S.zpqj_add(eng.ctx, bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
-                    version_date, method.encode(), C.byref(out), C.byref(out_len), stats)
+    if engs:
+        ctxs = (C.c_void_p * len(engs))(*[e.ctx.value for e in engs])
+        rc = S.zpqj_add_multi(ctxs, len(engs), bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
+                              version_date, method.encode(), C.byref(out), C.byref(out_len), stats)
+    else:
+        rc = S.zpqj_add(eng.ctx, bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
+                        version_date, method.encode(), C.byref(out), C.byref(out_len), stats)
     if rc != 0:
         raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
     data = C.string_at(out.value, out_len.value)

@@ -17,6 +17,9 @@
 
 #include <algorithm>
 #include <map>
+#include <new>
+#include <stdexcept>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -76,13 +79,12 @@ struct Index {
 // Parses one block's framing: name, comment, payload extent; returns total block size or 0.
 struct RawBlock { std::string name, comment; size_t size; };
 bool parse_block(const uint8_t* a, size_t n, RawBlock& rb) {
-  if (n < 13 + 5 + 2 || memcmp(a, kTag, 13)) return false;
+  if (n < 13 + 5 + 2 + 7 || memcmp(a, kTag, 13)) return false;
   size_t p = 13;
   if (a[p] != 'z' || a[p + 1] != 'P' || a[p + 2] != 'Q') return false;
-  const bool modelled = a[p + 3] == 1 && false;
-  (void)modelled;
   p += 5;
   const uint32_t hsize = a[p] | (uint32_t)a[p + 1] << 8;
+  if (hsize < 7 || p + 2 + hsize > n) return false;           // the header must be whole before any of it is read
   const uint32_t ncomp = a[p + 6];
   p += 2 + hsize;
   if (p >= n || a[p] != 1) return false;
@@ -136,8 +138,13 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
         rb.comment.compare(rb.comment.size() - 4, 4, "jDC\x01") != 0)
       return ZPQ_ERR_FORMAT;
     const char type = rb.name[17];
-    const uint32_t num = (uint32_t)strtoul(rb.name.c_str() + 18, 0, 10);
-    const size_t usize = (size_t)strtoull(rb.comment.c_str(), 0, 10);
+    const uint64_t num64 = strtoull(rb.name.c_str() + 18, 0, 10);
+    const uint64_t usize64 = strtoull(rb.comment.c_str(), 0, 10);
+    // sizes come from the archive: bound them before they size anything (the reference checks num < 1 and
+    // num + n > 0xffffffff at ZSFX/zsfx.cpp:1470-1480; blocks are < 4 GiB by format)
+    if (usize64 > 0xffffffffull - 4096 || num64 > 0xffffffffull) return ZPQ_ERR_FORMAT;
+    const uint32_t num = (uint32_t)num64;
+    const size_t usize = (size_t)usize64;
     if (type == 'c' || type == 'h' || type == 'i') {
       Bytes os;
       int rc = decompress_host(ctx, arc + pos, rb.size, usize, os);
@@ -152,6 +159,7 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
       } else if (type == 'h') {
         if (os.size() % 24 != 4) return ZPQ_ERR_FORMAT;
         const uint32_t nf = (uint32_t)((os.size() - 4) / 24), bsize = get32(os.data());
+        if (num < 1 || (uint64_t)num + nf > 0xffffffffull) return ZPQ_ERR_FORMAT;
         DBlock b; b.offset = data_offset; b.csize = bsize; b.first_frag = num; b.nfrag = nf; b.usize = 8;
         if (ix.ht.size() < (size_t)num + nf) ix.ht.resize((size_t)num + nf);
         for (uint32_t i = 0; i < nf; ++i) {
@@ -188,20 +196,64 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
   return ZPQ_OK;
 }
 
-}  // namespace
+// ---- add ----------------------------------------------------------------------------------------------------------
+// One context per GPU.  Files (name order) are cut into contiguous ranges of about equal size, one per context;
+// every context fragments and hashes its range; the tables are concatenated in range order (what an RCCL all-gather
+// of the per-GPU tables yields in a multi-process run); first-occurrence dedup and the block
+// packer run once over the global table, so the archive does not depend on the number of GPUs; a d block is
+// compressed by the context that holds its first fragment, fragments that live on another GPU are fetched peer to
+// peer.  With one context this is the whole of zpaqfranz `a` for the -m0/-m1 family.
+struct Shard {
+  zpq_ctx* ctx = nullptr;
+  size_t f0 = 0, f1 = 0;                  // files [f0, f1) in name order
+  std::vector<uint64_t> off;              // file offsets inside this shard's buffer
+  void* d_data = nullptr;
+  std::vector<void*> dev;                 // everything to free
+  std::vector<uint64_t> foff; std::vector<uint32_t> flen, ffile; Bytes dig;
+  size_t nf = 0;
+  int rc = ZPQ_OK;
+  ~Shard() { for (void* q : dev) if (q) zpq_dev_free(ctx, q); }
+};
 
-extern "C" {
+int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes, const std::vector<size_t>& order) {
+  zpq_ctx* ctx = S.ctx;
+  const size_t nfiles = S.f1 - S.f0;
+  S.off.assign(nfiles + 1, 0);
+  for (size_t k = 0; k < nfiles; ++k) S.off[k + 1] = S.off[k] + sizes[order[S.f0 + k]];
+  const uint64_t total = S.off[nfiles];
+  int rc;
+  if ((rc = zpq_dev_alloc(ctx, total + 64, &S.d_data))) return rc;
+  S.dev.push_back(S.d_data);
+  for (size_t k = 0; k < nfiles; ++k)
+    if (sizes[order[S.f0 + k]] && (rc = zpq_h2d(ctx, (uint8_t*)S.d_data + S.off[k], datas[order[S.f0 + k]], sizes[order[S.f0 + k]]))) return rc;
+  if ((rc = zpq_dev_memset(ctx, (uint8_t*)S.d_data + total, 0, 64))) return rc;
+  zpq_fragment_params fp;
+  zpq_fragment_params_default(&fp);
+  const size_t cap = std::max<size_t>(1, zpq_fragment_capacity(S.off.data(), nfiles, &fp));
+  void *d_foff, *d_flen, *d_ffile, *d_dig;
+  if ((rc = zpq_dev_alloc(ctx, cap * 8, &d_foff))) return rc; S.dev.push_back(d_foff);
+  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_flen))) return rc; S.dev.push_back(d_flen);
+  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_ffile))) return rc; S.dev.push_back(d_ffile);
+  if ((rc = zpq_dev_alloc(ctx, cap * 20 + 64, &d_dig))) return rc; S.dev.push_back(d_dig);
+  size_t nf = 0;
+  if (nfiles && (rc = zpq_fragment_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
+                                       (uint32_t*)d_ffile, cap, &nf))) return rc;
+  if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)S.d_data, (const uint64_t*)d_foff, (const uint32_t*)d_flen, nf, (uint8_t*)d_dig))) return rc;
+  S.nf = nf;
+  S.foff.resize(nf); S.flen.resize(nf); S.ffile.resize(nf); S.dig.resize(nf * 20);
+  if (nf) {
+    if ((rc = zpq_d2h(ctx, S.foff.data(), d_foff, nf * 8)) || (rc = zpq_d2h(ctx, S.flen.data(), d_flen, nf * 4)) ||
+        (rc = zpq_d2h(ctx, S.ffile.data(), d_ffile, nf * 4)) || (rc = zpq_d2h(ctx, S.dig.data(), d_dig, nf * 20))) return rc;
+  }
+  return ZPQ_OK;
+}
 
-void zpqj_free(void* p) { free(p); }
-
-// Adds one version holding `nfiles` files to `archive` (may be NULL/0 for a new archive) and returns
-// the NEW bytes to append (malloc'd; release with zpqj_free).  Fragments already stored by earlier
-// versions, and repeats inside this batch, become pointers (dedup).  stats[0..5] = fragments, new
-// fragments, d blocks, unique bytes, d-block bytes written, total bytes written.
-int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
+int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
              const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
              uint8_t** out, size_t* out_len, uint64_t stats[6]) {
   *out = nullptr; *out_len = 0;
+  if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
+  zpq_ctx* ctx = ctxs[0];
   Index ix;
   if (archive && archive_len) { int rc = read_index(ctx, archive, archive_len, ix); if (rc) return rc; }
   std::unordered_map<Sha1Key, uint32_t, Sha1Hash> known;
@@ -210,37 +262,47 @@ int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const cha
   std::vector<size_t> order(nfiles);
   for (size_t i = 0; i < nfiles; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
-  // 1. stage the batch in HBM, fragment, hash, dedup
-  std::vector<uint64_t> off(nfiles + 1, 0);
-  for (size_t k = 0; k < nfiles; ++k) off[k + 1] = off[k] + sizes[order[k]];
-  const uint64_t total = off[nfiles];
-  void* d_data = nullptr;
-  int rc = zpq_dev_alloc(ctx, total + 64, &d_data);
-  if (rc) return rc;
-  struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{ctx, {d_data}};
-  for (size_t k = 0; k < nfiles; ++k)
-    if (sizes[order[k]] && (rc = zpq_h2d(ctx, (uint8_t*)d_data + off[k], datas[order[k]], sizes[order[k]]))) return rc;
-  zpq_fragment_params fp;
-  zpq_fragment_params_default(&fp);
-  const size_t cap = std::max<size_t>(1, zpq_fragment_capacity(off.data(), nfiles, &fp));
-  void *d_foff, *d_flen, *d_ffile, *d_dig, *d_first;
-  if ((rc = zpq_dev_alloc(ctx, cap * 8, &d_foff))) return rc; dev.p.push_back(d_foff);
-  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_flen))) return rc; dev.p.push_back(d_flen);
-  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_ffile))) return rc; dev.p.push_back(d_ffile);
-  if ((rc = zpq_dev_alloc(ctx, cap * 20 + 64, &d_dig))) return rc; dev.p.push_back(d_dig);
-  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_first))) return rc; dev.p.push_back(d_first);
-  size_t nf = 0;
-  if ((rc = zpq_fragment_dev(ctx, (const uint8_t*)d_data, off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
-                             (uint32_t*)d_ffile, cap, &nf))) return rc;
-  if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)d_data, (const uint64_t*)d_foff, (const uint32_t*)d_flen, nf, (uint8_t*)d_dig))) return rc;
-  if ((rc = zpq_dedup_dev(ctx, (const uint8_t*)d_dig, nf, (uint32_t*)d_first))) return rc;
-  std::vector<uint64_t> foff(nf); std::vector<uint32_t> flen(nf), ffile(nf), first(nf); Bytes dig(nf * 20);
-  if (nf) {
-    if ((rc = zpq_d2h(ctx, foff.data(), d_foff, nf * 8)) || (rc = zpq_d2h(ctx, flen.data(), d_flen, nf * 4)) ||
-        (rc = zpq_d2h(ctx, ffile.data(), d_ffile, nf * 4)) || (rc = zpq_d2h(ctx, first.data(), d_first, nf * 4)) ||
-        (rc = zpq_d2h(ctx, dig.data(), d_dig, nf * 20))) return rc;
+  // 1. contiguous file ranges of about equal bytes, one per context; fragment + hash per range (one host thread each)
+  uint64_t total = 0;
+  for (size_t i = 0; i < nfiles; ++i) total += sizes[i];
+  std::vector<Shard> sh(nctx);
+  {
+    size_t f = 0; uint64_t acc = 0;
+    for (size_t r = 0; r < nctx; ++r) {
+      sh[r].ctx = ctxs[r]; sh[r].f0 = f;
+      const uint64_t goal = total / nctx * (r + 1) + (r + 1 == nctx ? total : 0);
+      while (f < nfiles && (r + 1 == nctx || acc + sizes[order[f]] / 2 <= goal)) acc += sizes[order[f++]];
+      sh[r].f1 = f;
+    }
   }
-  // 2. fragment ids: known from earlier versions, else new (first occurrence in this batch)
+  {
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order); });
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
+  }
+  // 2. the global fragment table: ranges in order (the "all-gather"), global first-occurrence dedup on context 0
+  std::vector<size_t> base(nctx + 1, 0);
+  for (size_t r = 0; r < nctx; ++r) base[r + 1] = base[r] + sh[r].nf;
+  const size_t nf = base[nctx];
+  std::vector<uint32_t> flen(nf), ffile(nf), first(nf), shard_of(nf); Bytes dig(nf * 20);
+  for (size_t r = 0; r < nctx; ++r)
+    for (size_t i = 0; i < sh[r].nf; ++i) {
+      flen[base[r] + i] = sh[r].flen[i]; ffile[base[r] + i] = (uint32_t)(sh[r].f0 + sh[r].ffile[i]); shard_of[base[r] + i] = (uint32_t)r;
+    }
+  for (size_t r = 0; r < nctx; ++r) if (sh[r].nf) memcpy(&dig[base[r] * 20], sh[r].dig.data(), sh[r].nf * 20);
+  int rc;
+  if (nf) {
+    void *d_dig = nullptr, *d_first = nullptr;
+    if ((rc = zpq_dev_alloc(ctx, nf * 20 + 64, &d_dig))) return rc;
+    if ((rc = zpq_dev_alloc(ctx, nf * 4, &d_first))) { zpq_dev_free(ctx, d_dig); return rc; }
+    rc = zpq_h2d(ctx, d_dig, dig.data(), nf * 20);
+    if (!rc) rc = zpq_dedup_dev(ctx, (const uint8_t*)d_dig, nf, (uint32_t*)d_first);
+    if (!rc) rc = zpq_d2h(ctx, first.data(), d_first, nf * 4);
+    zpq_dev_free(ctx, d_dig); zpq_dev_free(ctx, d_first);
+    if (rc) return rc;
+  }
+  // fragment ids: known from earlier versions, else new (first occurrence in this batch)
   const uint32_t first_new_id = (uint32_t)ix.ht.size();
   std::vector<uint32_t> id(nf, 0), newfrags;
   for (size_t i = 0; i < nf; ++i) {
@@ -251,60 +313,89 @@ int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const cha
     id[i] = first_new_id + (uint32_t)newfrags.size();
     newfrags.push_back((uint32_t)i);
   }
-  // 3. pack new fragments into d blocks, gather in HBM, compress
+  // 3. pack new fragments into d blocks; a block belongs to the context holding its first fragment
   std::vector<std::pair<size_t, size_t>> blocks;   // [begin, end) into newfrags
   for (size_t b = 0; b < newfrags.size();) {
     size_t e = b; uint64_t bytes = 8;
     while (e < newfrags.size() && (e == b || bytes + flen[newfrags[e]] + 4 <= kBlockLimit)) { bytes += flen[newfrags[e]] + 4; ++e; }
     blocks.push_back({b, e}); b = e;
   }
-  Bytes dpart;                                      // the d blocks, in order
-  std::vector<uint32_t> dsize(blocks.size());
-  if (!blocks.empty()) {
-    std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(blocks.size()); std::vector<uint32_t> bn(blocks.size());
+  std::vector<Bytes> dblock(blocks.size());
+  std::vector<int> brc(nctx, ZPQ_OK);
+  auto compress_owned = [&](size_t r) -> int {
+    zpq_ctx* c = ctxs[r];
+    std::vector<size_t> mine;
+    for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == r) mine.push_back(b);
+    if (mine.empty()) return ZPQ_OK;
+    struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{c, {}};
+    std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(mine.size()); std::vector<uint32_t> bn(mine.size());
+    struct Remote { size_t src_shard; uint64_t src_off; uint64_t dst_off; uint32_t len; };
+    std::vector<Remote> remote;
     uint64_t pos = 0;
-    for (size_t b = 0; b < blocks.size(); ++b) {
-      boff[b] = pos; uint64_t q = pos;
-      for (size_t k = blocks[b].first; k < blocks[b].second; ++k) { const uint32_t f = newfrags[k]; so.push_back(foff[f]); sl.push_back(flen[f]); dso.push_back(q); q += flen[f]; }
+    for (size_t m = 0; m < mine.size(); ++m) {
+      const size_t b = mine[m];
+      boff[m] = pos; uint64_t q = pos;
+      for (size_t k = blocks[b].first; k < blocks[b].second; ++k) {
+        const uint32_t f = newfrags[k]; const size_t s = shard_of[f];
+        const uint64_t src = sh[s].foff[f - base[s]];
+        if (s == r) { so.push_back(src); sl.push_back(flen[f]); dso.push_back(q); }
+        else remote.push_back({s, src, q, flen[f]});
+        q += flen[f];
+      }
       const uint32_t cnt = (uint32_t)(blocks[b].second - blocks[b].first);
-      bn[b] = (uint32_t)(q - pos) + 4 * cnt + 8;
-      pos += (bn[b] + 127) & ~(uint64_t)63;
+      bn[m] = (uint32_t)(q - pos) + 4 * cnt + 8;
+      pos += (bn[m] + 127) & ~(uint64_t)63;
     }
-    void *d_blk, *d_so, *d_sl, *d_dso;
-    if ((rc = zpq_dev_alloc(ctx, pos + 64, &d_blk))) return rc; dev.p.push_back(d_blk);
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
-    if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
-        (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
-    if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blk))) return rc;
-    std::vector<zpq_block_job> jobs(blocks.size());
-    std::vector<std::string> nm(blocks.size());
-    uint64_t opos = 0; std::vector<uint64_t> ooff(blocks.size());
-    for (size_t b = 0; b < blocks.size(); ++b) {
+    int rc;
+    void *d_blk, *d_so = nullptr, *d_sl = nullptr, *d_dso = nullptr;
+    if ((rc = zpq_dev_alloc(c, pos + 64, &d_blk))) return rc; dev.p.push_back(d_blk);
+    if (!so.empty()) {
+      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+      if ((rc = zpq_dev_alloc(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+      if ((rc = zpq_h2d(c, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(c, d_sl, sl.data(), sl.size() * 4)) ||
+          (rc = zpq_h2d(c, d_dso, dso.data(), dso.size() * 8))) return rc;
+      if ((rc = zpq_gather_dev(c, (const uint8_t*)sh[r].d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blk))) return rc;
+    }
+    for (const Remote& R : remote)       // fragments of this block that another GPU holds: peer to peer
+      if (R.len && (rc = zpq_copy_peer(c, (uint8_t*)d_blk + R.dst_off, sh[R.src_shard].ctx, (const uint8_t*)sh[R.src_shard].d_data + R.src_off, R.len))) return rc;
+    std::vector<zpq_block_job> jobs(mine.size());
+    std::vector<std::string> nm(mine.size());
+    uint64_t opos = 0; std::vector<uint64_t> ooff(mine.size());
+    for (size_t m = 0; m < mine.size(); ++m) {
+      const size_t b = mine[m];
       Bytes tr;
       for (size_t k = blocks[b].first; k < blocks[b].second; ++k) put32(tr, flen[newfrags[k]]);
       put32(tr, 0); put32(tr, (uint32_t)(blocks[b].second - blocks[b].first));
-      if ((rc = zpq_h2d(ctx, (uint8_t*)d_blk + boff[b] + bn[b] - tr.size(), tr.data(), tr.size()))) return rc;
-      nm[b] = block_name(version_date, 'd', first_new_id + (uint32_t)blocks[b].first);
-      ooff[b] = opos; opos += (zpq_block_bound(bn[b], nm[b].c_str(), "jDC\x01") + 63) & ~(size_t)63;
+      if ((rc = zpq_h2d(c, (uint8_t*)d_blk + boff[m] + bn[m] - tr.size(), tr.data(), tr.size()))) return rc;
+      nm[m] = block_name(version_date, 'd', first_new_id + (uint32_t)blocks[b].first);
+      ooff[m] = opos; opos += (zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01") + 63) & ~(size_t)63;
     }
     void* d_out;
-    if ((rc = zpq_dev_alloc(ctx, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
-    for (size_t b = 0; b < blocks.size(); ++b) {
-      zpq_block_job& j = jobs[b];
+    if ((rc = zpq_dev_alloc(c, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
+    for (size_t m = 0; m < mine.size(); ++m) {
+      zpq_block_job& j = jobs[m];
       memset(&j, 0, sizeof j);
-      j.in = (uint8_t*)d_blk + boff[b]; j.n = bn[b]; j.method = method; j.filename = nm[b].c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
-      j.out = (uint8_t*)d_out + ooff[b]; j.out_cap = (uint32_t)zpq_block_bound(bn[b], nm[b].c_str(), "jDC\x01");
+      j.in = (uint8_t*)d_blk + boff[m]; j.n = bn[m]; j.method = method; j.filename = nm[m].c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
+      j.out = (uint8_t*)d_out + ooff[m]; j.out_cap = (uint32_t)zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01");
     }
-    if ((rc = zpq_compress_blocks_dev(ctx, jobs.data(), jobs.size()))) return rc;
-    for (size_t b = 0; b < blocks.size(); ++b) {
-      const size_t at = dpart.size();
-      dpart.resize(at + jobs[b].out_len);
-      if ((rc = zpq_d2h(ctx, dpart.data() + at, jobs[b].out, jobs[b].out_len))) return rc;
-      dsize[b] = jobs[b].out_len;
+    if ((rc = zpq_sync(c))) return rc;
+    if ((rc = zpq_compress_blocks_dev(c, jobs.data(), jobs.size()))) return rc;
+    for (size_t m = 0; m < mine.size(); ++m) {
+      dblock[mine[m]].resize(jobs[m].out_len);
+      if ((rc = zpq_d2h(c, dblock[mine[m]].data(), jobs[m].out, jobs[m].out_len))) return rc;
     }
+    return ZPQ_OK;
+  };
+  {
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { brc[r] = compress_owned(r); });
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < nctx; ++r) if (brc[r]) return brc[r];
   }
+  Bytes dpart;                                      // the d blocks, in block order whoever compressed them
+  std::vector<uint32_t> dsize(blocks.size());
+  for (size_t b = 0; b < blocks.size(); ++b) { dsize[b] = (uint32_t)dblock[b].size(); dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end()); }
   // 4. c block, d blocks, h blocks, i blocks
   Bytes outb, tmp;
   put64(tmp, dpart.size());
@@ -344,57 +435,147 @@ int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const cha
   return ZPQ_OK;
 }
 
+// ---- extract --------------------------------------------------------------------------------------------------------
+// Jidac::extract (ZSFX/zsfx.cpp:2018-2281 + decompressThread :1731-1994) with the archive's d blocks staged in HBM:
+// one zpq_decompress_blocks_dev over all of them, every fragment's SHA-1 compared with the h table on the device,
+// the files assembled by one gather, one copy back.
+int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes, char** names,
+                 size_t* nfiles) {
+  Index ix;
+  int rc = read_index(ctx, archive, archive_len, ix);
+  if (rc) return rc;
+  struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{ctx, {}};
+  const size_t nb = ix.blocks.size();
+  // d blocks -> HBM
+  std::vector<uint64_t> aoff(nb), poff(nb);
+  uint64_t apos = 0, ppos = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    const DBlock& B = ix.blocks[b];
+    if (B.offset + B.csize > archive_len || B.usize > 0xffffffffull - 4096) return ZPQ_ERR_FORMAT;
+    aoff[b] = apos; apos += ((uint64_t)B.csize + 64 + 63) & ~(uint64_t)63;
+    poff[b] = ppos; ppos += (B.usize + 64 + 63) & ~(uint64_t)63;
+  }
+  void *d_arc = nullptr, *d_plain = nullptr;
+  if ((rc = zpq_dev_alloc(ctx, apos + 64, &d_arc))) return rc; dev.p.push_back(d_arc);
+  if ((rc = zpq_dev_alloc(ctx, ppos + 64, &d_plain))) return rc; dev.p.push_back(d_plain);
+  if ((rc = zpq_dev_memset(ctx, d_arc, 0, apos + 64))) return rc;
+  std::vector<zpq_unblock_job> jobs(nb);
+  for (size_t b = 0; b < nb; ++b) {
+    const DBlock& B = ix.blocks[b];
+    if ((rc = zpq_h2d(ctx, (uint8_t*)d_arc + aoff[b], archive + B.offset, B.csize))) return rc;
+    memset(&jobs[b], 0, sizeof jobs[b]);
+    jobs[b].in = (uint8_t*)d_arc + aoff[b]; jobs[b].n = B.csize;
+    jobs[b].out = (uint8_t*)d_plain + poff[b]; jobs[b].out_cap = (uint32_t)B.usize + 64;
+  }
+  if (nb) {
+    rc = zpq_decompress_blocks_dev(ctx, jobs.data(), nb, 1);
+    for (size_t b = 0; b < nb; ++b) {
+      if (jobs[b].status) return jobs[b].status;
+      if (jobs[b].out_len != ix.blocks[b].usize) return ZPQ_ERR_FORMAT;
+    }
+    if (rc) return rc;
+  }
+  // fragment id -> offset in d_plain; SHA-1 of every stored fragment against the h table (ZSFX/zsfx.cpp:1811-1834)
+  std::vector<uint64_t> where(ix.ht.size(), ~(uint64_t)0);
+  std::vector<uint64_t> voff; std::vector<uint32_t> vlen; Bytes want;
+  for (size_t b = 0; b < nb; ++b) {
+    uint64_t o = poff[b];
+    for (uint32_t i = 0; i < ix.blocks[b].nfrag; ++i) {
+      const uint32_t f = ix.blocks[b].first_frag + i;
+      where[f] = o;
+      voff.push_back(o); vlen.push_back(ix.ht[f].usize); want.insert(want.end(), ix.ht[f].sha1.d, ix.ht[f].sha1.d + 20);
+      o += ix.ht[f].usize;
+    }
+  }
+  if (!voff.empty()) {
+    void *d_voff, *d_vlen, *d_want, *d_got;
+    const size_t nv = voff.size();
+    if ((rc = zpq_dev_alloc(ctx, nv * 8, &d_voff))) return rc; dev.p.push_back(d_voff);
+    if ((rc = zpq_dev_alloc(ctx, nv * 4, &d_vlen))) return rc; dev.p.push_back(d_vlen);
+    if ((rc = zpq_dev_alloc(ctx, nv * 20 + 64, &d_want))) return rc; dev.p.push_back(d_want);
+    if ((rc = zpq_dev_alloc(ctx, nv * 20 + 64, &d_got))) return rc; dev.p.push_back(d_got);
+    if ((rc = zpq_h2d(ctx, d_voff, voff.data(), nv * 8)) || (rc = zpq_h2d(ctx, d_vlen, vlen.data(), nv * 4)) || (rc = zpq_h2d(ctx, d_want, want.data(), nv * 20))) return rc;
+    if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_voff, (const uint32_t*)d_vlen, nv, (uint8_t*)d_got))) return rc;
+    uint64_t mism = 0, firstbad = 0;
+    if ((rc = zpq_digest_compare_dev(ctx, (const uint8_t*)d_got, (const uint8_t*)d_want, nv, 20, &mism, &firstbad))) return rc;
+    if (mism) return ZPQ_ERR_CHECKSUM;
+  }
+  // files: every pointer becomes one copy extent into the blob
+  std::vector<uint64_t> so, dso; std::vector<uint32_t> sl;
+  std::vector<uint64_t> sz; std::string nm;
+  uint64_t blob_len = 0;
+  for (auto& kv : ix.files) {
+    if (!kv.second.date) continue;
+    uint64_t len = 0;
+    for (uint32_t q : kv.second.ptr) {
+      if (q == 0 || q >= ix.ht.size() || where[q] == ~(uint64_t)0) return ZPQ_ERR_FORMAT;
+      so.push_back(where[q]); sl.push_back(ix.ht[q].usize); dso.push_back(blob_len + len);
+      len += ix.ht[q].usize;
+    }
+    blob_len += len;
+    sz.push_back(len); nm += kv.first; nm.push_back('\0');
+  }
+  *data = (uint8_t*)malloc(blob_len ? blob_len : 1);
+  *sizes = (uint64_t*)malloc((sz.size() ? sz.size() : 1) * 8);
+  *names = (char*)malloc(nm.size() ? nm.size() : 1);
+  if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
+  if (!so.empty()) {
+    void *d_so, *d_sl, *d_dso, *d_blob;
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+    if ((rc = zpq_dev_alloc(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
+    if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
+        (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
+    if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blob))) return rc;
+    if (blob_len && (rc = zpq_d2h(ctx, *data, d_blob, blob_len))) return rc;
+  }
+  memcpy(*sizes, sz.data(), sz.size() * 8); memcpy(*names, nm.data(), nm.size());
+  *nfiles = sz.size();
+  return ZPQ_OK;
+}
+
+// nothing thrown inside (bad_alloc from a hostile size, length_error ...) may cross the C boundary
+template <class F>
+int guarded(F f) {
+  try { return f(); }
+  catch (const std::bad_alloc&) { return ZPQ_ERR_NOMEM; }
+  catch (const std::exception&) { return ZPQ_ERR_FORMAT; }
+}
+
+}  // namespace
+
+extern "C" {
+
+void zpqj_free(void* p) { free(p); }
+
+// Adds one version holding `nfiles` files to `archive` (may be NULL/0 for a new archive) and returns
+// the NEW bytes to append (malloc'd; release with zpqj_free).  Fragments already stored by earlier
+// versions, and repeats inside this batch, become pointers (dedup).  stats[0..5] = fragments, new
+// fragments, d blocks, unique bytes, d-block bytes written, total bytes written.
+int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
+             const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
+             uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats); });
+}
+
+// The same over several GPUs of one node (one context each): the files are sharded across them, the archive
+// bytes are identical to the single-GPU result whatever nctx is.
+int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
+                   const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date,
+                   const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  return guarded([&] { return add_impl(ctxs, nctx, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats); });
+}
+
 // Extracts the latest version of every file: decompresses the d blocks on the GPU, verifies every
 // fragment's SHA-1 against the h table (ZSFX/zsfx.cpp:1811-1834) and returns one malloc'd blob holding
 // the files back to back in name order plus their names/sizes (names: NUL-separated, malloc'd).
 int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes, char** names,
                  size_t* nfiles) {
-  Index ix;
-  int rc = read_index(ctx, archive, archive_len, ix);
-  if (rc) return rc;
-  // decompress every d block (blocks are independent: one batch)
-  std::vector<Bytes> bdata(ix.blocks.size());
-  for (size_t b = 0; b < ix.blocks.size(); ++b) {
-    const DBlock& B = ix.blocks[b];
-    if (B.offset + B.csize > archive_len) return ZPQ_ERR_FORMAT;
-    if ((rc = decompress_host(ctx, archive + B.offset, B.csize, (size_t)B.usize, bdata[b]))) return rc;
-    if (bdata[b].size() != B.usize) return ZPQ_ERR_FORMAT;
-  }
-  // fragment id -> (block, offset)
-  std::vector<std::pair<uint32_t, uint64_t>> where(ix.ht.size(), {0xffffffffu, 0});
-  std::vector<const uint8_t*> vbuf; std::vector<size_t> vlen; std::vector<uint32_t> vid;
-  for (size_t b = 0; b < ix.blocks.size(); ++b) {
-    uint64_t o = 0;
-    for (uint32_t i = 0; i < ix.blocks[b].nfrag; ++i) {
-      const uint32_t f = ix.blocks[b].first_frag + i;
-      where[f] = {(uint32_t)b, o};
-      vbuf.push_back(bdata[b].data() + o); vlen.push_back(ix.ht[f].usize); vid.push_back(f);
-      o += ix.ht[f].usize;
-    }
-  }
-  Bytes dg(vbuf.size() * 20);
-  if (!vbuf.empty() && (rc = zpq_sha1_many(ctx, vbuf.data(), vlen.data(), vbuf.size(), dg.data()))) return rc;
-  for (size_t k = 0; k < vid.size(); ++k)
-    if (memcmp(&dg[20 * k], ix.ht[vid[k]].sha1.d, 20)) return ZPQ_ERR_CHECKSUM;
-  Bytes blob; std::vector<uint64_t> sz; std::string nm;
-  for (auto& kv : ix.files) {
-    if (!kv.second.date) continue;
-    uint64_t len = 0;
-    for (uint32_t q : kv.second.ptr) {
-      if (q == 0 || q >= ix.ht.size() || where[q].first == 0xffffffffu) return ZPQ_ERR_FORMAT;
-      const Bytes& src = bdata[where[q].first];
-      blob.insert(blob.end(), src.begin() + where[q].second, src.begin() + where[q].second + ix.ht[q].usize);
-      len += ix.ht[q].usize;
-    }
-    sz.push_back(len); nm += kv.first; nm.push_back('\0');
-  }
-  *data = (uint8_t*)malloc(blob.size() ? blob.size() : 1);
-  *sizes = (uint64_t*)malloc((sz.size() ? sz.size() : 1) * 8);
-  *names = (char*)malloc(nm.size() ? nm.size() : 1);
-  if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
-  memcpy(*data, blob.data(), blob.size()); memcpy(*sizes, sz.data(), sz.size() * 8); memcpy(*names, nm.data(), nm.size());
-  *nfiles = sz.size();
-  return ZPQ_OK;
+  *data = nullptr; *sizes = nullptr; *names = nullptr; *nfiles = 0;
+  const int rc = guarded([&] { return extract_impl(ctx, archive, archive_len, data, sizes, names, nfiles); });
+  if (rc) { free(*data); free(*sizes); free(*names); *data = nullptr; *sizes = nullptr; *names = nullptr; *nfiles = 0; }
+  return rc;
 }
 
 }  // extern "C"

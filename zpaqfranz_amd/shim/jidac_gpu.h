@@ -12,6 +12,12 @@ void zpqj_free(void* p);
 int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names,
              const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
              int64_t version_date, const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]);
+/* zpqj_add over several GPUs of one node, one context each (files sharded by contiguous ranges in name order, global
+ * dedup, blocks compressed by the GPU that holds their first fragment, other fragments fetched peer to peer).  The
+ * bytes returned do not depend on nctx. */
+int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
+                   const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
+                   int64_t version_date, const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]);
 int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes,
                  char** names, size_t* nfiles);
 #ifdef __cplusplus

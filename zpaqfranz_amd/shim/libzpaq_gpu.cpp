@@ -18,6 +18,7 @@ void Writer::write(const char* buf, int n) { for (int i = 0; i < n; ++i) put(U8(
 namespace {
 
 int g_device = 0;
+const uint8_t kTag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
 
 struct EngineHolder {
   zpq_ctx* ctx = nullptr;
@@ -38,9 +39,12 @@ void fail(zpq_ctx* ctx, int rc, const char* what) {
   error(m.c_str());
 }
 
-// Coalesces compressBlock() calls from concurrent worker threads into one zpq_compress_blocks launch.
+// Coalesces blocking calls from concurrent worker threads into one engine call: the first caller becomes the leader,
+// runs the batch that has gathered (its own job included) and wakes the others; callers that arrive meanwhile form
+// the next batch.  Run(ctx, jobs, n) is the zpq_* batch entry point.
+template <class Job, int (*Run)(zpq_ctx*, Job*, size_t)>
 struct Batcher {
-  struct Item { zpq_block_job job; bool done; };
+  struct Item { Job job; bool done; int rc; };
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Item*> queue;
@@ -67,40 +71,79 @@ struct Batcher {
     EngineHolder& e = engine();
     std::lock_guard<std::mutex> g(e.mu);
     zpq_ctx* ctx = e.get();
-    std::vector<zpq_block_job> jobs(batch.size());
+    std::vector<Job> jobs(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) jobs[i] = batch[i]->job;
-    zpq_compress_blocks(ctx, jobs.data(), jobs.size());   // per-job status carries the outcome
-    for (size_t i = 0; i < batch.size(); ++i) batch[i]->job = jobs[i];
+    const int rc = Run(ctx, jobs.data(), jobs.size());   // per-job status carries the outcome where the job has one
+    for (size_t i = 0; i < batch.size(); ++i) { batch[i]->job = jobs[i]; batch[i]->rc = rc; }
   }
 };
-Batcher& batcher() { static Batcher b; return b; }
+
+int run_compress(zpq_ctx* c, zpq_block_job* j, size_t n) { return zpq_compress_blocks(c, j, n); }
+int run_decompress(zpq_ctx* c, zpq_unblock_job* j, size_t n) { return zpq_decompress_blocks(c, j, n, 0); }   // callers verify through setSHA1 / their own table
+struct HashJob { const uint8_t* p; size_t n; uint8_t* out; };
+int run_sha1(zpq_ctx* c, HashJob* j, size_t n) {
+  std::vector<const uint8_t*> b(n); std::vector<size_t> l(n); std::vector<uint8_t> d(n * 20);
+  for (size_t i = 0; i < n; ++i) { b[i] = j[i].p; l[i] = j[i].n; }
+  const int rc = zpq_sha1_many(c, b.data(), l.data(), n, d.data());
+  for (size_t i = 0; i < n; ++i) memcpy(j[i].out, &d[20 * i], 20);
+  return rc;
+}
+int run_sha256(zpq_ctx* c, HashJob* j, size_t n) {
+  std::vector<const uint8_t*> b(n); std::vector<size_t> l(n); std::vector<uint8_t> d(n * 32);
+  for (size_t i = 0; i < n; ++i) { b[i] = j[i].p; l[i] = j[i].n; }
+  const int rc = zpq_sha256_many(c, b.data(), l.data(), n, d.data());
+  for (size_t i = 0; i < n; ++i) memcpy(j[i].out, &d[32 * i], 32);
+  return rc;
+}
+typedef Batcher<zpq_block_job, run_compress> CompressBatcher;
+typedef Batcher<zpq_unblock_job, run_decompress> DecompressBatcher;
+typedef Batcher<HashJob, run_sha1> Sha1Batcher;
+typedef Batcher<HashJob, run_sha256> Sha256Batcher;
+CompressBatcher& compress_batcher() { static CompressBatcher b; return b; }
+DecompressBatcher& decompress_batcher() { static DecompressBatcher b; return b; }
+Sha1Batcher& sha1_batcher() { static Sha1Batcher b; return b; }
+Sha256Batcher& sha256_batcher() { static Sha256Batcher b; return b; }
+
+// decimal size at the start of a comment (compressBlock's contract, ZSFX/libzpaq.h:73-84); 0 when absent
+size_t comment_size(const uint8_t* blk, size_t n) {
+  size_t q = 13 + 5;
+  if (q + 2 > n) return 0;
+  q += 2 + (blk[q] | (size_t)blk[q + 1] << 8) + 1;
+  while (q < n && blk[q]) ++q;
+  ++q;
+  size_t v = 0;
+  while (q < n && blk[q] >= '0' && blk[q] <= '9') { v = v * 10 + (size_t)(blk[q] - '0'); ++q; }
+  return v;
+}
 
 }  // namespace
 
 void setDevice(int ordinal) { g_device = ordinal; }
 
 const char* SHA1::result() {
-  EngineHolder& e = engine();
-  std::lock_guard<std::mutex> g(e.mu);
-  zpq_ctx* ctx = e.get();
-  const uint8_t* bufs[1] = {p ? p : (const uint8_t*)""};
-  size_t lens[1] = {n};
-  int rc = zpq_sha1_many(ctx, bufs, lens, 1, (uint8_t*)hbuf);
-  if (rc != ZPQ_OK) fail(ctx, rc, "SHA1");
+  Sha1Batcher::Item it;
+  it.job.p = p ? p : (const uint8_t*)""; it.job.n = n; it.job.out = (uint8_t*)hbuf; it.done = false; it.rc = 0;
+  sha1_batcher().submit(&it);
+  if (it.rc != ZPQ_OK) fail(nullptr, it.rc, "SHA1");
   n = 0;
   return hbuf;
 }
 
 const char* SHA256::result() {
+  Sha256Batcher::Item it;
+  it.job.p = p ? p : (const uint8_t*)""; it.job.n = n; it.job.out = (uint8_t*)hbuf; it.done = false; it.rc = 0;
+  sha256_batcher().submit(&it);
+  if (it.rc != ZPQ_OK) fail(nullptr, it.rc, "SHA256");
+  n = 0;
+  return hbuf;
+}
+
+void sha1_many(const char* const* bufs, const size_t* lens, size_t n, char* digests) {
   EngineHolder& e = engine();
   std::lock_guard<std::mutex> g(e.mu);
   zpq_ctx* ctx = e.get();
-  const uint8_t* bufs[1] = {p ? p : (const uint8_t*)""};
-  size_t lens[1] = {n};
-  int rc = zpq_sha256_many(ctx, bufs, lens, 1, (uint8_t*)hbuf);
-  if (rc != ZPQ_OK) fail(ctx, rc, "SHA256");
-  n = 0;
-  return hbuf;
+  const int rc = zpq_sha1_many(ctx, (const uint8_t* const*)bufs, lens, n, (uint8_t*)digests);
+  if (rc != ZPQ_OK) fail(ctx, rc, "sha1_many");
 }
 
 void compressBlock(StringBuffer* in, Writer* out, const char* method, const char* filename, const char* comment,
@@ -109,9 +152,9 @@ void compressBlock(StringBuffer* in, Writer* out, const char* method, const char
   const size_t n = in->size();
   if (n > 0xffffffffu) error("compressBlock: block too large");
   std::vector<uint8_t> framed(zpq_block_bound(n, filename, comment));
-  Batcher::Item it;
+  CompressBatcher::Item it;
   memset(&it.job, 0, sizeof it.job);
-  it.done = false;
+  it.done = false; it.rc = 0;
   it.job.in = in->data() ? in->data() : (const uint8_t*)"";
   it.job.n = (uint32_t)n;
   it.job.method = method;
@@ -120,7 +163,7 @@ void compressBlock(StringBuffer* in, Writer* out, const char* method, const char
   it.job.dosha1 = dosha1 ? 1 : 0;
   it.job.out = framed.data();
   it.job.out_cap = (uint32_t)framed.size();
-  batcher().submit(&it);
+  compress_batcher().submit(&it);
   if (it.job.status != ZPQ_OK) {
     std::string m = std::string("compressBlock(\"") + method + "\"): " + zpq_strerror(it.job.status);
     error(m.c_str());
@@ -159,55 +202,6 @@ void compress(Reader* in, Writer* out, const char* method, const char* filename,
   }
 }
 
-void decompress(Reader* in, Writer* out) {
-  // slurp the archive, then hand every block to the engine (blocks are independent)
-  std::vector<uint8_t> arc;
-  {
-    char buf[1 << 16];
-    int r;
-    while ((r = in->read(buf, sizeof buf)) > 0) arc.insert(arc.end(), buf, buf + r);
-  }
-  static const uint8_t tag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
-  EngineHolder& e = engine();
-  size_t pos = 0;
-  while (pos + 13 <= arc.size()) {
-    // findBlock (ZSFX/libzpaq.cpp:2239-2262): scan for the 13-byte tag
-    size_t at = pos;
-    while (at + 13 <= arc.size() && memcmp(&arc[at], tag, 13) != 0) ++at;
-    if (at + 13 > arc.size()) break;
-    // output size: the comment begins with the decimal size (compressBlock contract); fall back to a generous bound
-    size_t cap = 0;
-    {
-      size_t q = at + 13 + 5;
-      if (q + 2 <= arc.size()) {
-        q += 2 + (arc[q] | arc[q + 1] << 8) + 1;
-        while (q < arc.size() && arc[q]) ++q;
-        ++q;
-        size_t v = 0; bool any = false;
-        while (q < arc.size() && arc[q] >= '0' && arc[q] <= '9') { v = v * 10 + (arc[q] - '0'); ++q; any = true; }
-        if (any) cap = v;
-      }
-    }
-    if (cap == 0) cap = (arc.size() - at) * 64 + 65536;
-    std::vector<uint8_t> outbuf(cap + 64);
-    zpq_unblock_job j;
-    memset(&j, 0, sizeof j);
-    j.in = &arc[at]; j.n = (uint32_t)std::min<size_t>(arc.size() - at, 0xffffffffu);
-    j.out = outbuf.data(); j.out_cap = (uint32_t)outbuf.size();
-    int rc;
-    {
-      std::lock_guard<std::mutex> g(e.mu);
-      rc = zpq_decompress_blocks(e.get(), &j, 1, 1);
-    }
-    if (rc != ZPQ_OK || j.status != ZPQ_OK) {
-      std::string m = std::string("decompress: ") + zpq_strerror(j.status ? j.status : rc);
-      error(m.c_str());
-    }
-    out->write((const char*)outbuf.data(), (int)j.out_len);
-    pos = at + j.consumed;
-  }
-}
-
 // ---- Decompresser ------------------------------------------------------------------------------------------
 struct Decompresser::Impl {
   std::vector<uint8_t> head;      // tag, "zPQ", level, type, header
@@ -220,6 +214,7 @@ struct Decompresser::Impl {
   bool decoded = false, have_marker = false;
   uint8_t marker[21] = {0};       // [0] = 1 if SHA-1 present
   unsigned segments = 0;
+  bool first_was_pass = false;    // the block's first segment opened with 0 (no post-processor program)
   uint64_t usize_hint = 0;
 };
 
@@ -227,7 +222,6 @@ Decompresser::Decompresser() : d_(new Impl), in_(0), out_(0), sha_(0) {}
 Decompresser::~Decompresser() { delete d_; }
 
 bool Decompresser::findBlock(double* memptr) {
-  static const uint8_t tag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
   if (!in_) error("Decompresser: no input");
   Impl& d = *d_;
   // ZSFX/libzpaq.cpp:2239-2262: the block starts right after the 13-byte tag, wherever that is
@@ -237,9 +231,9 @@ bool Decompresser::findBlock(double* memptr) {
     if (c < 0) return false;
     if (have < 13) win[have++] = (uint8_t)c;
     else { memmove(win, win + 1, 12); win[12] = (uint8_t)c; }
-    if (have == 13 && memcmp(win, tag, 13) == 0) break;
+    if (have == 13 && memcmp(win, kTag, 13) == 0) break;
   }
-  d.head.assign(tag, tag + 13);
+  d.head.assign(kTag, kTag + 13);
   uint8_t h[7];
   for (int i = 0; i < 7; ++i) { const int c = in_->get(); if (c < 0) error("unexpected end of block header"); h[i] = (uint8_t)c; }
   if (h[0] != 'z' || h[1] != 'P' || h[2] != 'Q' || (h[3] != 1 && h[3] != 2) || h[4] != 1) error("unsupported ZPAQ level or type");
@@ -270,7 +264,7 @@ bool Decompresser::findBlock(double* memptr) {
     }
     *memptr = mem;
   }
-  d.state = 1; d.segments = 0;
+  d.state = 1; d.segments = 0; d.first_was_pass = false;
   return true;
 }
 
@@ -284,7 +278,7 @@ bool Decompresser::findFilename(Writer* filename) {
   const int c = in_->get();
   if (c == 255) { d.state = 0; return false; }                 // end of block
   if (c != 1) error("missing segment or end of block");
-  if (d.segments++ > 0) error("blocks with more than one segment are not supported by the GPU engine");
+  ++d.segments;
   d.seg.assign(1, 1);
   for (;;) {
     const int b = in_->get();
@@ -349,29 +343,41 @@ bool Decompresser::decompress(int n) {
   if (d.state != 3 && d.state != 4) error("decompress: no segment open");
   if (!d.decoded) {
     if (!d.have_marker) { read_payload(in_, d.ncomp, d.payload, d.marker); d.have_marker = true; d.state = 4; }
-    std::vector<uint8_t> blk(d.head);
-    blk.insert(blk.end(), d.seg.begin(), d.seg.end());
-    blk.insert(blk.end(), d.payload.begin(), d.payload.end());
-    if (d.marker[0]) { blk.push_back(253); blk.insert(blk.end(), d.marker + 1, d.marker + 21); } else blk.push_back(254);
-    blk.push_back(255);
-    blk.resize(blk.size() + 64);                                  // readable padding (include/zpaqhip.h)
-    size_t cap = d.usize_hint ? (size_t)d.usize_hint : d.payload.size() * 64 + 65536;
-    d.plain.resize(cap + 64);
-    zpq_unblock_job j;
-    memset(&j, 0, sizeof j);
-    j.in = blk.data(); j.n = (uint32_t)(blk.size() - 64);
-    j.out = d.plain.data(); j.out_cap = (uint32_t)d.plain.size();
-    EngineHolder& e = engine();
-    int rc;
-    {
-      std::lock_guard<std::mutex> g(e.mu);
-      rc = zpq_decompress_blocks(e.get(), &j, 1, 0);             // the caller verifies through setSHA1 / its own table
+    if (d.segments > 1) {
+      // a later segment of the block continues the first one's decoder: without a model and without a post-processor
+      // program that is a plain copy of the stored bytes (ZSFX/libzpaq.cpp:2307-2337); anything else would need the
+      // first segment's predictor / PCOMP state
+      if (d.ncomp || !d.first_was_pass) error("blocks that continue a model or a post-processor across segments are not supported by the GPU engine");
+      d.plain.clear();
+      for (size_t p = 0; p + 4 <= d.payload.size();) {
+        const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
+        p += 4;
+        if (!k) break;
+        d.plain.insert(d.plain.end(), d.payload.begin() + p, d.payload.begin() + p + k);
+        p += k;
+      }
+    } else {
+      std::vector<uint8_t> blk(d.head);
+      blk.insert(blk.end(), d.seg.begin(), d.seg.end());
+      blk.insert(blk.end(), d.payload.begin(), d.payload.end());
+      if (d.marker[0]) { blk.push_back(253); blk.insert(blk.end(), d.marker + 1, d.marker + 21); } else blk.push_back(254);
+      blk.push_back(255);
+      blk.resize(blk.size() + 64);                                  // readable padding (include/zpaqhip.h)
+      size_t cap = d.usize_hint ? (size_t)d.usize_hint : d.payload.size() * 64 + 65536;
+      d.plain.resize(cap + 64);
+      DecompressBatcher::Item it;
+      memset(&it.job, 0, sizeof it.job);
+      it.done = false; it.rc = 0;
+      it.job.in = blk.data(); it.job.n = (uint32_t)(blk.size() - 64);
+      it.job.out = d.plain.data(); it.job.out_cap = (uint32_t)d.plain.size();
+      decompress_batcher().submit(&it);                             // N decompressThreads -> one launch
+      if (it.job.status != ZPQ_OK) {
+        std::string m = std::string("Decompresser: ") + zpq_strerror(it.job.status);
+        error(m.c_str());
+      }
+      d.plain.resize(it.job.out_len);
+      d.first_was_pass = d.ncomp == 0 && !d.payload.empty() && d.payload.size() > 4 && d.payload[4] == 0;
     }
-    if (rc != ZPQ_OK || j.status != ZPQ_OK) {
-      std::string m = std::string("Decompresser: ") + zpq_strerror(j.status ? j.status : rc);
-      error(m.c_str());
-    }
-    d.plain.resize(j.out_len);
     d.decoded = true; d.given = 0;
   }
   size_t k = d.plain.size() - d.given;
@@ -389,9 +395,194 @@ bool Decompresser::pcomp(Writer*) { return false; }
 void Decompresser::readSegmentEnd(char* sha1string) {
   Impl& d = *d_;
   if (d.state != 3 && d.state != 4) error("readSegmentEnd: no segment open");
-  if (!d.have_marker) { read_payload(in_, d.ncomp, d.payload, d.marker); d.have_marker = true; }   // segment skipped undecoded
+  if (!d.have_marker) {                                                            // segment skipped undecoded
+    read_payload(in_, d.ncomp, d.payload, d.marker); d.have_marker = true;
+    if (d.segments == 1) d.first_was_pass = d.ncomp == 0 && d.payload.size() > 4 && d.payload[4] == 0;
+  }
   if (sha1string) memcpy(sha1string, d.marker, 21);
   d.state = 1;
+}
+
+void decompress(Reader* in, Writer* out) {
+  // the reference's loop (ZSFX/libzpaq.cpp:2368-2381): every block, every segment, SHA-1s verified
+  Decompresser d;
+  d.setInput(in);
+  d.setOutput(out);
+  while (d.findBlock()) {
+    while (d.findFilename()) {
+      d.readComment();
+      SHA1 sha;
+      d.setSHA1(&sha);
+      d.decompress();
+      char rec[21];
+      d.readSegmentEnd(rec);
+      if (rec[0] && memcmp(rec + 1, sha.result(), 20) != 0) error("decompress: checksum mismatch");
+    }
+  }
+}
+
+// ---- Compressor ----------------------------------------------------------------------------------------------
+struct Compressor::Impl {
+  std::vector<uint8_t> header;    // hsize[2] hh hm ph pm n COMP 0 HCOMP 0
+  std::vector<uint8_t> pcomp;     // compiled post-processor byte code (with its closing 0), empty = none
+  std::vector<uint8_t> data;      // what the Encoder sees in the open segment
+  int state = 0;                  // 0 INIT, 1 BLOCK1, 2 SEG1, 3 BLOCK2, 4 SEG2 (ZSFX/libzpaq.h:1369)
+  unsigned segments = 0;
+  bool pp_done = false;
+};
+
+Compressor::Compressor() : d_(new Impl), out_(0), in_(0) {}
+Compressor::~Compressor() { delete d_; }
+
+void Compressor::writeTag() {
+  if (!out_) error("Compressor: no output");
+  out_->write((const char*)kTag, 13);
+}
+
+void Compressor::startBlock(int) {
+  error("Compressor::startBlock(level): the byte code of the built-in models is not part of the reference snapshot; pass a config");
+}
+
+void Compressor::startBlock(const char* hcomp) {
+  if (!out_) error("Compressor: no output");
+  if (d_->state != 0 && d_->state != 3) error("startBlock: a block is already open");
+  const uint8_t* h = (const uint8_t*)hcomp;
+  const size_t len = (h[0] | (size_t)h[1] << 8) + 2;
+  if (len < 9) error("startBlock: header too short");
+  d_->header.assign(h, h + len);
+  d_->pcomp.clear();
+  out_->put('z'); out_->put('P'); out_->put('Q'); out_->put(1 + (d_->header[6] == 0)); out_->put(1);
+  out_->write((const char*)d_->header.data(), (int)d_->header.size());
+  d_->state = 1; d_->segments = 0; d_->pp_done = false;
+}
+
+void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
+  if (!out_) error("Compressor: no output");
+  if (d_->state != 0 && d_->state != 3) error("startBlock: a block is already open");
+  int32_t a[9] = {0};
+  if (args) for (int i = 0; i < 9; ++i) a[i] = args[i];
+  std::vector<uint8_t> h(70000), p(70000);
+  size_t hl = 0, pl = 0;
+  const int rc = zpq_compile_config(nullptr, config, a, h.data(), h.size(), &hl, p.data(), p.size(), &pl);
+  if (rc != ZPQ_OK) fail(nullptr, rc, "Compressor::startBlock: config does not compile");
+  (void)pcomp_cmd;                 // the "pcomp <command> ;" text is only used by external pre-processors
+  d_->header.assign(h.begin(), h.begin() + hl);
+  d_->pcomp.assign(p.begin(), p.begin() + pl);
+  out_->put('z'); out_->put('P'); out_->put('Q'); out_->put(1 + (d_->header[6] == 0)); out_->put(1);
+  out_->write((const char*)d_->header.data(), (int)d_->header.size());
+  d_->state = 1; d_->segments = 0; d_->pp_done = false;
+}
+
+void Compressor::hcomp(Writer* out2) { if (out2) out2->write((const char*)d_->header.data(), (int)d_->header.size()); }
+bool Compressor::pcomp(Writer* out2) {
+  if (d_->pcomp.empty()) return false;
+  if (out2) { out2->put((int)(d_->pcomp.size() & 255)); out2->put((int)(d_->pcomp.size() >> 8)); out2->write((const char*)d_->pcomp.data(), (int)d_->pcomp.size()); }
+  return true;
+}
+
+void Compressor::startSegment(const char* filename, const char* comment) {
+  if (d_->state != 1 && d_->state != 3) error("startSegment: no block open");
+  out_->put(1);
+  if (filename) out_->write(filename, (int)strlen(filename));
+  out_->put(0);
+  if (comment) out_->write(comment, (int)strlen(comment));
+  out_->put(0);
+  out_->put(0);
+  d_->data.clear();
+  ++d_->segments;
+  d_->state = d_->state == 1 ? 2 : 4;
+}
+
+void Compressor::postProcess(const char* pcomp, int len) {
+  Impl& d = *d_;
+  if (d.state == 4 || d.pp_done) return;
+  if (d.state != 2) error("postProcess: no first segment open");
+  const uint8_t* pc = (const uint8_t*)pcomp;
+  if (!pc) { len = (int)d.pcomp.size(); pc = len ? d.pcomp.data() : nullptr; }
+  else if (len == 0) { len = pc[0] | pc[1] << 8; pc += 2; }
+  if (len > 0) {
+    d.data.push_back(1); d.data.push_back((uint8_t)(len & 255)); d.data.push_back((uint8_t)((len >> 8) & 255));
+    d.data.insert(d.data.end(), pc, pc + len);
+  } else d.data.push_back(0);
+  d.pp_done = true;
+}
+
+bool Compressor::compress(int n) {
+  Impl& d = *d_;
+  if (d.state != 2 && d.state != 4) error("compress: no segment open");
+  if (d.state == 2 && !d.pp_done) postProcess();
+  if (!in_) error("compress: no input");
+  char buf[1 << 16];
+  while (n != 0) {
+    int want = (int)sizeof buf;
+    if (n > 0 && n < want) want = n;
+    const int r = in_->read(buf, want);
+    if (r <= 0) return false;
+    d.data.insert(d.data.end(), buf, buf + r);
+    sha1_.write(buf, r);
+    if (n > 0) n -= r;
+  }
+  return true;
+}
+
+void Compressor::endSegment(const char* sha1string) {
+  Impl& d = *d_;
+  if (d.state != 2 && d.state != 4) error("endSegment: no segment open");
+  if (d.state == 2 && !d.pp_done) postProcess();
+  const uint32_t ncomp = d.header[6];
+  if (ncomp == 0) {
+    // Encoder stored mode: sub-blocks of at most 64 KiB with big-endian lengths, then a zero length
+    for (size_t p = 0; p < d.data.size();) {
+      const size_t k = std::min<size_t>(65536, d.data.size() - p);
+      out_->put((int)(k >> 24)); out_->put((int)(k >> 16) & 255); out_->put((int)(k >> 8) & 255); out_->put((int)k & 255);
+      out_->write((const char*)&d.data[p], (int)k);
+      p += k;
+    }
+    out_->put(0); out_->put(0); out_->put(0); out_->put(0);
+  } else {
+    if (d.segments > 1) error("Compressor: a second segment would continue the first one's context model; one segment per block on the GPU engine");
+    EngineHolder& e = engine();
+    std::lock_guard<std::mutex> g(e.mu);
+    zpq_ctx* ctx = e.get();
+    const size_t n = d.data.size(), cap = n + n / 8 + 4096;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc = zpq_dev_alloc(ctx, n + 64, &d_in);
+    if (rc == ZPQ_OK) rc = zpq_dev_alloc(ctx, cap + 64, &d_out);
+    if (rc != ZPQ_OK) { if (d_in) zpq_dev_free(ctx, d_in); fail(ctx, rc, "Compressor"); }
+    if (n) rc = zpq_h2d(ctx, d_in, d.data.data(), n);
+    zpq_cm_job j;
+    memset(&j, 0, sizeof j);
+    j.header = d.header.data(); j.header_len = (uint32_t)d.header.size();
+    j.d_in = (const uint8_t*)d_in; j.n = (uint32_t)n; j.d_out = (uint8_t*)d_out; j.out_cap = (uint32_t)cap;
+    if (rc == ZPQ_OK) rc = zpq_cm_encode_dev(ctx, &j, 1);
+    std::vector<uint8_t> coded;
+    if (rc == ZPQ_OK && j.status == ZPQ_OK) { coded.resize(j.out_len); if (j.out_len) rc = zpq_d2h(ctx, coded.data(), d_out, j.out_len); }
+    zpq_dev_free(ctx, d_in); zpq_dev_free(ctx, d_out);
+    if (rc != ZPQ_OK || j.status != ZPQ_OK) fail(ctx, rc ? rc : j.status, "Compressor: context-model coder");
+    out_->write((const char*)coded.data(), (int)coded.size());    // includes the end-of-segment symbol and the four 0 bytes
+  }
+  if (sha1string) { out_->put(253); out_->write(sha1string, 20); }
+  else out_->put(254);
+  d.data.clear();
+  d.state = 3;
+}
+
+char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
+  if (size) *size = (int64_t)sha1_.usize();
+  if (dosha1) {
+    memcpy(sha1result_, sha1_.result(), 20);
+    endSegment(sha1result_);
+    return sha1result_;
+  }
+  (void)sha1_.result();
+  endSegment(0);
+  return 0;
+}
+
+void Compressor::endBlock() {
+  if (d_->state != 3) error("endBlock: no block to close");
+  out_->put(255);
+  d_->state = 0;
 }
 
 }  // namespace libzpaq

@@ -7,6 +7,7 @@
 //   StringBuffer     ZSFX/libzpaq.h:1377-1494
 //   compressBlock()  ZSFX/libzpaq.h:1505, compress() :1501, decompress() :1268
 //   Decompresser     ZSFX/libzpaq.h:1243-1264
+//   Compressor       ZSFX/libzpaq.h:1340-1371 (streaming: startBlock / startSegment / compress(n) / endSegment / endBlock)
 // so that a Jidac-style caller (one compressBlock per block per worker thread; one Decompresser per block on the
 // extract side, ZSFX/zsfx.cpp:1783-1801) links against this header unchanged.
 //
@@ -15,9 +16,10 @@
 // implements (byte-aligned LZ77, BWT and E8E9 front ends) end in libzpaq::error("...") -- there is
 // no CPU fallback compiled into this library; the host keeps its CPU libzpaq for those if it wants.
 //
-// Batching: compressBlock() blocks the calling thread like the reference's does.  Calls made
-// concurrently from N worker threads (zpaqfranz -tN) are coalesced by a small batcher into one
-// zpq_compress_blocks() launch, which is how a per-block API feeds a GPU.
+// Batching: compressBlock(), Decompresser::decompress() and SHA1/SHA256::result() block the calling thread like
+// the reference's do.  Calls made concurrently from N worker threads (zpaqfranz -tN) are coalesced by small
+// batchers into one zpq_compress_blocks() / zpq_decompress_blocks() / zpq_sha*_many() launch each, which is how a
+// per-block API feeds a GPU.  A caller that can hand over many buffers at once uses sha1_many() below.
 #ifndef LIBZPAQ_GPU_H
 #define LIBZPAQ_GPU_H
 
@@ -115,8 +117,10 @@ void decompress(Reader* in, Writer* out);
 // Block-at-a-time reader with the reference's interface and call sequence (ZSFX/libzpaq.h:1243-1264; used as in
 // ZSFX/zsfx.cpp:1783-1801: setInput, setOutput, findBlock, {findFilename, readComment, decompress(n)*, readSegmentEnd}*).
 // The segment is decoded by the engine on the first decompress() call and then handed out n bytes at a time.
-// Blocks with more than one segment (streaming archives that continue a model across files) are refused through
-// error(): the journaling format zpaqfranz writes has one segment per block.
+// Blocks with several segments are read when they are stored without a model and without a post-processor program
+// (method 0 streaming archives: segments are independent there); a second segment that would continue a
+// context model or a PCOMP machine across files ends in error(): the journaling format zpaqfranz writes has one
+// segment per block.
 class Decompresser {
  public:
   Decompresser();
@@ -131,7 +135,7 @@ class Decompresser {
   bool decompress(int n = -1);              // n bytes (-1 = all); false once the segment is exhausted
   bool pcomp(Writer* out2);                 // not retained by this implementation: returns false
   void readSegmentEnd(char* sha1string = 0);// [0] = 1 if a SHA-1 follows in [1..20], else 0
-  void stat(int) {}
+  int stat(int) { return 0; }               // the reference reports predictor statistics here (debug builds only)
   int buffered() { return 0; }
  private:
   struct Impl;
@@ -139,6 +143,45 @@ class Decompresser {
   Reader* in_; Writer* out_; SHA1* sha_;
   Decompresser(const Decompresser&); void operator=(const Decompresser&);
 };
+
+// Streaming writer with the reference's interface (ZSFX/libzpaq.h:1340-1371, contract :426-531): what
+// libzpaq::compress() and callers with their own block structure use.  The segment's bytes are collected on the host
+// and coded when the segment ends (arithmetic coder + context model on the GPU for models with components, stored
+// sub-blocks otherwise); what reaches the Writer is byte for byte what the reference's Compressor writes.
+class Compressor {
+ public:
+  Compressor();
+  ~Compressor();
+  void setOutput(Writer* out) { out_ = out; }
+  void writeTag();
+  void startBlock(int level);                 // built-in models 1..3: their byte code is not in the reference snapshot -> error()
+  void startBlock(const char* hcomp);         // ZPAQL byte code, starting at hsize[2]
+  void startBlock(const char* config, int* args, Writer* pcomp_cmd = 0);   // ZPAQL source
+  void setVerify(bool) {}
+  void hcomp(Writer* out2);
+  bool pcomp(Writer* out2);
+  void startSegment(const char* filename = 0, const char* comment = 0);
+  void setInput(Reader* i) { in_ = i; }
+  void postProcess(const char* pcomp = 0, int len = 0);
+  bool compress(int n = -1);                  // n bytes, -1 = all; true until the input is exhausted
+  void endSegment(const char* sha1string = 0);
+  char* endSegmentChecksum(int64_t* size = 0, bool dosha1 = true);
+  int64_t getSize() { return (int64_t)sha1_.usize(); }
+  const char* getChecksum() { return sha1_.result(); }
+  void endBlock();
+  int stat(int) { return 0; }
+ private:
+  struct Impl;
+  Impl* d_;
+  Writer* out_; Reader* in_;
+  SHA1 sha1_;
+  char sha1result_[20];
+  Compressor(const Compressor&); void operator=(const Compressor&);
+};
+
+// Many independent buffers -> many SHA-1s in one launch (not in the reference: the three-line change a caller makes in
+// the fragment verification loop of decompressThread, ZSFX/zsfx.cpp:1811-1834).
+void sha1_many(const char* const* bufs, const size_t* lens, size_t n, char* digests /* 20*n */);
 
 // Engine plumbing (not in the reference): which GPU this process uses; call before first use.
 void setDevice(int ordinal);
