@@ -32,6 +32,11 @@ import os
 import sys
 import time
 
+# Every step in flight owns three HIP streams (engine main + checksum chains, torch); the runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue serialise -- a 216 ms checksum chain
+# then holds up another step's kernels.  One queue per stream (must be set before the HIP runtime starts).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -42,10 +47,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from zpaqfranz_amd.sharding import BLOCK_LIMIT, plan as shard_plan
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
-# integer-issue ceiling (the real bound of the hash/fragment passes): 256 CUs x 4 SIMD32 x 32 lanes/clk x 2.4 GHz
-LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9
-VALU_OPS_PER_BYTE = {"sha1_extents_kernel": 10.0, "fragment_spec_kernel": 12.0, "sha256_chain_kernel": 14.0 * 64, "sha1_chain_kernel": 6.3 * 64,
-                     "blake3_chunks_kernel": 12.0}
+# integer-issue ceiling (the real bound of the hash/fragment passes).  Measured with the SQ counters
+# (profiles/r02_pmc_sq.json): SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4 cycles per wave64 integer instruction on every
+# kernel of this path, one wave or many per SIMD -- 16 lanes per clock per SIMD: 256 CUs x 4 SIMDs x 16 x 2.4 GHz
+LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
+# wave-instructions per input byte x 64 lanes (PMC: SQ_INSTS_VALU / bytes): lane-per-extent kernels use every lane,
+# the wave-per-chain kernels one lane's worth of work per instruction
+VALU_OPS_PER_BYTE = {"sha1_extents_kernel": 10.5, "fragment_spec_kernel": 13.7, "sha256_chain_kernel": 14.8 * 64, "sha1_chain_kernel": 6.35 * 64,
+                     "sha256_extents_kernel": 21.5, "blake3_chunks_kernel": 12.0}
 
 
 _CPU_COLLECTIVES = False     # set when the process group is gloo (functional test on one GPU)
@@ -262,10 +271,14 @@ class Pipeline:
             tsync()
             eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
                            blocks_buf.data_ptr())
-            # size tables of all blocks: one host buffer, one upload, one scatter
-            tr_all = np.frombuffer(b"".join(tr for _, tr in trailers), dtype=np.uint8)
-            tr_pos = np.concatenate([np.arange(p_, p_ + len(tr), dtype=np.int64) for p_, tr in trailers])
-            blocks_buf[torch.from_numpy(tr_pos).to(dev)] = torch.from_numpy(tr_all.copy()).to(dev)
+            if len(trailers) <= 64:
+                for p_, tr in trailers:
+                    blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
+            else:
+                # size tables of all blocks: one host buffer, one upload, one scatter
+                tr_all = np.frombuffer(b"".join(tr for _, tr in trailers), dtype=np.uint8)
+                tr_pos = np.concatenate([np.arange(p_, p_ + len(tr), dtype=np.int64) for p_, tr in trailers])
+                blocks_buf[torch.from_numpy(tr_pos).to(dev)] = torch.from_numpy(tr_all.copy()).to(dev)
         if self.coll:
             order.enter(idx, 1)
             self._exchange_seams(P, lens, my_lo, nf, layout, blocks_buf)
@@ -566,6 +579,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
     a = ap.parse_args()
+    if os.environ.get("ZPQ_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack and exit if the run takes too long
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ZPQ_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.same_device:
@@ -586,7 +602,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload])
+    # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
+    # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6
+    # (multi-rank runs keep three: every step in flight adds three collective sections to the fixed order, and that depth
+    # is the one exercised over RCCL)
+    multi = world > 1 or a.force_collectives
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 5, "dup8_m1": 1, "extract_m1": 1}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
@@ -597,8 +618,10 @@ def main():
         layout = silesia_layout(dev, corpus, a.copies)
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
-    engines = [eng] + [Engine(local) for _ in range(1, depth)]
-    pipes = [Pipeline(e_, dev, layout, rank, world, a.force_collectives) for e_ in engines]
+    engines, pipes = [], []
+    for k_ in range(depth):
+        engines.append(eng if k_ == 0 else Engine(local))
+        pipes.append(Pipeline(engines[-1], dev, layout, rank, world, a.force_collectives))
     for p_ in pipes:
         p_.no_block_sha1 = a.no_block_sha1
     ex_pipe = None

@@ -200,6 +200,16 @@ def test_lz77_encoder_segment_size_never_changes_the_stream(eng, monkeypatch):
     monkeypatch.delenv("ZPQ_LZ_SEG")
     assert eng.lz77_encode(blocks, [args] * 3) == want            # automatic segment choice under a tight budget
     monkeypatch.delenv("ZPQ_LZ_BUDGET_MB")
+    # direct mode (one wave per block parses AND emits: what a call with hundreds of blocks selects by itself)
+    monkeypatch.setenv("ZPQ_LZ_DIRECT", "1")
+    more = blocks + [b"", b"a", b"abcd" * 3, bytes(70000), datagen.random_bytes(300000, 44), b"ab" * 150000, datagen.text_like(4097, 45)]
+    assert eng.lz77_encode(more, [args] * len(more)) == want + [orc.lz77_encode(b, args) for b in more[3:]]
+    for a2 in ([5, 1, 5, 0, 3, 25], [4, 1, 4, 0, 1, 18], [2, 1, 6, 0, 0, 20], [4, 1, 8, 0, 2, 22]):      # rb = 1; other bucket widths and match lengths
+        assert eng.lz77_encode(blocks[1:], [a2] * 2) == [orc.lz77_encode(b, a2) for b in blocks[1:]]
+    monkeypatch.setenv("ZPQ_LZ_BUDGET_MB", "100")                 # one block per batch
+    assert eng.lz77_encode(blocks, [args] * 3) == want
+    monkeypatch.delenv("ZPQ_LZ_BUDGET_MB")
+    monkeypatch.delenv("ZPQ_LZ_DIRECT")
 
 
 # ---------------------------------------------------------------------------------------------------

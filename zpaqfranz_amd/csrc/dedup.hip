@@ -106,7 +106,7 @@ extern "C" int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uin
   // scatters every fragment of every file) fewer slots and a persistent grid keep the launch small
   const u32 pieces = n >= 16384 ? 4 : 64;
   const u64 items = (u64)n * pieces;
-  const unsigned grid = (unsigned)(items < 65536 ? items : 65536);
+  const unsigned grid = (unsigned)(items < (1u << 20) ? items : (1u << 20));   // one workgroup per item while that is a sane grid
   ZPQ_LAUNCH(ctx, "gather_kernel", ctx->stream, gather_kernel, dim3(grid), dim3(256), d_src_base,
              d_src_off, d_len, d_dst_off, d_dst_base, pieces, items);
   ZPQ_HIP(ctx, hipGetLastError());

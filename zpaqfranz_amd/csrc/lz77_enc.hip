@@ -163,6 +163,77 @@ __device__ unsigned long long g_lzprof[8];
 #define LZ_T(i) do {} while (0)
 #endif
 
+// Direct emitter: with one wave per block (no segment speculation) the parse order IS the output order, so the wave
+// writes the code stream as it goes -- LZBuffer::write_literal / write_match / putb (ZSFX/libzpaq.cpp:6166-6184,
+// 6455-6520) -- and no token list exists.  Control is wave-uniform; a literal run's bytes are spread over the lanes,
+// each shifting in the bits its left neighbour spills.
+struct BitSink {
+  __attribute__((address_space(1))) u8* out; u32 out_cap;
+  __attribute__((address_space(1))) const u8* in;
+  u64 acc; u32 accbits;        // pending bits, fewer than 8 between calls
+  u32 bytepos;                 // bytes written
+  u32 gap_start;               // first position not yet emitted
+  u32 rb, overflow;
+
+  __device__ __forceinline__ void put(u64 v, u32 k, u32 lane) {           // k <= 56 bits, LSB first
+    acc |= v << accbits;
+    accbits += k;
+    const u32 nb = accbits >> 3;
+    if (lane < nb) {
+      if (bytepos + lane < out_cap) out[bytepos + lane] = (u8)(acc >> (8 * lane)); else overflow = 1;
+    }
+    bytepos += nb;
+    acc = nb >= 8 ? 0ull : acc >> (8 * nb);
+    accbits &= 7u;
+  }
+  __device__ __forceinline__ void literal_run(u32 from, u32 len, u32 lane) {   // 00, gamma(len), bytes (:6455-6478)
+    u64 v = 0; u32 k = 2;
+    for (int b = lg32(len) - 2; b >= 0; --b) { v |= 1ull << k; ++k; v |= (u64)((len >> b) & 1u) << k; ++k; }
+    ++k;
+    put(v, k, lane);
+    const u32 sh = accbits;                  // 0..7 bits already in the byte the run starts in
+    for (u32 j = lane; j < len; j += 64) {
+      const u32 c = in[from + j];
+      const u32 left = j ? (u32)in[from + j - 1] : 0u;
+      const u32 carry = j ? (sh ? left >> (8 - sh) : 0u) : (u32)acc;
+      if (bytepos + j < out_cap) out[bytepos + j] = (u8)((c << sh) | carry); else overflow = 1;
+    }
+    bytepos += len;
+    acc = sh ? (u64)((u32)in[from + len - 1] >> (8 - sh)) : 0ull;
+  }
+  __device__ __forceinline__ void literals(u32 upto, u32 lane) {          // everything in [gap_start, upto) as literal runs
+    u32 g = upto - gap_start, from = gap_start;
+    while (g) {
+      const u32 r = g < kMaxLiteral ? g : kMaxLiteral;
+      literal_run(from, r, lane);
+      from += r; g -= r;
+    }
+    gap_start = upto;
+  }
+  __device__ __forceinline__ void match(u32 pos, u32 len, u32 off, u32 lane) {   // :6481-6520, level 1
+    literals(pos, lane);
+    const u32 o = off + (1u << rb) - 1u;
+    const u32 lo = (u32)lg32(o) - 1u - rb;
+    u64 v = ((lo + 8u) >> 3) | ((u64)(lo & 7u) << 2);
+    u32 k = 5;
+    for (int b = lg32(len) - 2; b >= 2; --b) { v |= 1ull << k; ++k; v |= (u64)((len >> b) & 1u) << k; ++k; }
+    ++k;                                    // terminating 0
+    v |= (u64)(len & 3u) << k; k += 2;      // k <= 34
+    put(v, k, lane);
+    const u64 tail = (u64)(o & ((1u << rb) - 1u)) | ((u64)((o >> rb) & ((1u << lo) - 1u)) << rb);
+    if (rb + lo) put(tail, rb + lo, lane);
+    gap_start = pos + len;
+  }
+  __device__ __forceinline__ u32 finish(u32 n, u32 lane) {                // trailing literals, last partial byte (flush, :6181-6184)
+    literals(n, lane);
+    if (accbits) {
+      if (lane == 0) { if (bytepos < out_cap) out[bytepos] = (u8)acc; else overflow = 1; }
+      ++bytepos; acc = 0; accbits = 0;
+    }
+    return bytepos;
+  }
+};
+
 // Speculative tokens of one segment, consulted by the stitcher after each of its own tokens.
 struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 
@@ -170,9 +241,9 @@ struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 // (which must hold exactly the inserts of all positions < wbase) and continues the greedy parse
 // from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
 // matches ends where a speculative match ends and returns that token's index (else -1).
-template <int NB>
+template <int NB, bool DIRECT = false>
 __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
-                       SpecList* spec, unsigned long long* T_generic) {
+                       SpecList* spec, unsigned long long* T_generic, BitSink* bits = nullptr) {
   const u32 lane = (u32)lane_id();
   g_cu8* in = (g_cu8*)C.in;
   g_u32* ht = (g_u32*)ht_generic;
@@ -398,7 +469,8 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
         tlen = f ? l1 : l0; toff = f ? o1 : o0;
       }
       if (tlen) {
-        if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
+        if (DIRECT) bits->match(cur, tlen, toff, lane);
+        else if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
         ++sink.n;
         lit = 0;
         cur += tlen;
@@ -485,6 +557,28 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
     S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
     S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
   }
+}
+
+// ---- one wave per block, no speculation: parse and emit in one go (many blocks: "one wavefront per ZPAQ block") --------
+template <int NB>
+__global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
+                                                         const u32* __restrict__ list) {
+  const LzJobDev J = jobs[list[blockIdx.x]];
+  const LzSegDev S = segs[J.seg0];
+  __shared__ unsigned long long T[256];
+  const u32 lane = (u32)lane_id();
+  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+  __builtin_amdgcn_wave_barrier();
+  TokSink sink{nullptr, nullptr, nullptr, 0, 0};
+  BitSink bs;
+  bs.out = (__attribute__((address_space(1))) u8*)J.out; bs.out_cap = J.out_cap;
+  bs.in = (__attribute__((address_space(1))) const u8*)J.in;
+  bs.acc = 0; bs.accbits = 0; bs.bytepos = 0; bs.gap_start = 0; bs.rb = J.rb; bs.overflow = 0;
+  u32 cur = 0, lit = 0;
+  lz_walk<NB, true>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
+  const u32 bytes = bs.finish(J.n, lane);
+  const unsigned long long ov = __ballot(bs.overflow != 0);
+  if (lane == 0) { J.result[0] = sink.n; J.result[1] = bytes; J.result[2] = (ov != 0 || bytes > J.out_cap) ? 1u : 0u; }
 }
 
 // ---- seams: one wave per segment boundary -----------------------------------------------------------------
@@ -748,13 +842,18 @@ static T* carve(u8*& p, size_t count) {
 }
 
 // HBM a job needs while it is parsed with segments of kSegBytes: 2*segments-1 hash tables plus the token lists
+static size_t job_bytes_direct(const zpq_lz77_job& z) { return ((size_t)4 << z.args[5]) + 4096; }
 static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
-  return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + ((size_t)z.n / 4 + 2 + 2 * nseg) * 40;
+  // tokens are matches of at least args[2] bytes that do not overlap: n / minMatch of them at most.  Final list 4 words
+  // per token, speculative list 3 per segment, seam list 3 for every segment but the first
+  const size_t mm = (size_t)(z.args[2] >= 4 ? z.args[2] : 4);
+  const size_t toks = (size_t)z.n / mm + 3 + 3 * nseg;
+  return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + toks * (16 + 12 + (nseg > 1 ? 12 : 0));
 }
 
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
-static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes) {
+static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct) {
   hipStream_t st = ctx->stream;
   const size_t nj = hi - lo;
   std::vector<LzJobDev> hj(nj);
@@ -766,10 +865,11 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
     const size_t words = (size_t)1 << z.args[5];
     table_words += words * (2 * (size_t)nseg - 1);
-    tok_words += ((size_t)z.n / 4 + 2) * 4;                 // final pos/len/off/bit
-    for (u32 k = 0; k < nseg; ++k) {
+    const u32 mmt = (u32)(z.args[2] >= 4 ? z.args[2] : 4);
+    if (!direct) tok_words += ((size_t)z.n / mmt + 3) * 4;  // final pos/len/off/bit
+    for (u32 k = 0; k < nseg && !direct; ++k) {
       const u32 x0 = k * kSegBytes, x1 = std::min<u64>((u64)x0 + kSegBytes, z.n);
-      tok_words += ((size_t)(x1 - x0) / 4 + 2) * 6;          // speculative + seam token lists
+      tok_words += ((size_t)(x1 - x0) / mmt + 3) * (k ? 6 : 3);   // speculative (+ seam, except for the first segment) token lists
     }
     max_seg = std::max(max_seg, nseg);
   }
@@ -808,12 +908,13 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     const size_t words = (size_t)1 << a[5];
     LzJobDev& J = hj[i];
     J.in = z.d_in; J.n = z.n; J.rb = c.rb; J.nseg = nseg; J.seg0 = (u32)hs.size();
-    const u32 cap = z.n / 4 + 2;
+    const u32 mmt = (u32)(a[2] >= 4 ? a[2] : 4);
+    const u32 cap = direct ? 1u : z.n / mmt + 3;
     J.tok_pos = d_tok + to; J.tok_len = J.tok_pos + cap; J.tok_off = J.tok_len + cap; J.tok_bit = J.tok_off + cap;
-    J.tok_cap = cap - 1; to += (size_t)cap * 4;
+    J.tok_cap = cap - 1; to += direct ? 0 : (size_t)cap * 4;
     J.result = d_res + 4 * i; J.out = z.d_out; J.out_cap = z.out_cap;
     J.plan = d_plan + 8 * (size_t)hs.size();
-    ZPQ_HIP(ctx, hipMemsetAsync(J.out, 0, J.out_cap, st));
+    if (!direct) ZPQ_HIP(ctx, hipMemsetAsync(J.out, 0, J.out_cap, st));     // (the direct emitter writes whole bytes)
     // tables: work[0..nseg-1], pristine[1..nseg-1]
     u32* work0 = d_tab + tabo;
     u32* prist0 = work0 + words * nseg - words;   // pristine[k] = prist0 + k*words, k >= 1
@@ -824,9 +925,10 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       S.c = c; S.x0 = k * kSegBytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + kSegBytes, z.n);
       S.work = work0 + words * k;
       S.pristine = k ? prist0 + words * k : nullptr;
-      const u32 scap = (S.x1 - S.x0) / 4 + 2;
-      S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap - 1; to += (size_t)scap * 3;
-      S.qpos = d_tok + to; S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; to += (size_t)scap * 3;
+      const u32 scap = direct ? 0u : (S.x1 - S.x0) / mmt + 3;
+      S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap ? scap - 1 : 0; to += (size_t)scap * 3;
+      if (k) { S.qpos = d_tok + to; S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; to += (size_t)scap * 3; }
+      else { S.qpos = S.tpos; S.qlen = S.tlen; S.qoff = S.toff; }       // no seam walk enters a first segment (never written, never read)
       S.state = d_state + 12 * hs.size(); S.seam = S.state + 4;
       if (k) {
         copy_step[k].push_back({k == 1 ? nullptr : prist0 + words * (k - 1), S.pristine, (u32)words});
@@ -885,6 +987,29 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  if (direct) {
+    for (int nb = 0; nb <= 3; ++nb) {
+      if (!rng[nb].jn) continue;
+      dim3 gj((unsigned)rng[nb].jn), blk(64);
+      const u32* jl = d_lists + rng[nb].joff;
+      switch (nb) {
+        case 0: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+        case 1: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+        case 2: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+        default: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+      }
+      ZPQ_HIP(ctx, hipGetLastError());
+    }
+    std::vector<u32> res(nj * 4);
+    ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < nj; ++i) {
+      jobs[lo + i].n_matches = res[4 * i];
+      jobs[lo + i].out_len = res[4 * i + 1];
+      if (res[4 * i + 2]) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: output capacity exceeded", lo + i);
+    }
+    return ZPQ_OK;
+  }
   for (int nb = 0; nb <= 3; ++nb) {
     if (!rng[nb].sn) continue;
     dim3 gs((unsigned)rng[nb].sn), gj((unsigned)rng[nb].jn), blk(64);
@@ -959,20 +1084,29 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
       seg <<= 1;
     }
   }
+  // Two ways to run a batch.  Speculative segments: many waves per block, 2*segments-1 tables and token lists per block
+  // (few blocks: 13 blocks become 212 waves).  Direct: one wave per block that parses and emits in one go, one table per
+  // block and nothing else -- with hundreds of blocks there are waves enough without speculation and HBM is what bounds
+  // the number in flight.  A wave parses at a rate that does not depend on the mode, so the estimate of either is
+  // (number of batches) x (bytes one wave walks); the smaller wins.
+  size_t all_bytes = 0, all_direct = 0;
+  for (size_t i = 0; i < njobs; ++i) { all_bytes += job_bytes(jobs[i], seg); all_direct += job_bytes_direct(jobs[i]); }
+  for (size_t i = 0; i < njobs; ++i) max_n = std::max(max_n, jobs[i].n);
+  const size_t nbatch = (all_bytes + budget - 1) / budget, nbatch_d = (all_direct + budget - 1) / budget;
+  bool direct = (double)nbatch_d * (double)max_n < (double)nbatch * (double)std::min<u32>(seg, max_n ? max_n : 1);
+  if (const char* e = getenv("ZPQ_LZ_DIRECT")) direct = atoi(e) != 0;
   // batches of about equal size (a last batch of a few blocks would leave the chip idle behind its slowest wave)
-  size_t all_bytes = 0;
-  for (size_t i = 0; i < njobs; ++i) all_bytes += job_bytes(jobs[i], seg);
-  const size_t nbatch = (all_bytes + budget - 1) / budget;
-  const size_t target = nbatch > 1 ? std::min(budget, all_bytes / nbatch + (all_bytes / nbatch) / 16) : budget;
+  const size_t total = direct ? all_direct : all_bytes, nb_ = direct ? nbatch_d : nbatch;
+  const size_t target = nb_ > 1 ? std::min(budget, total / nb_ + (total / nb_) / 16) : budget;
   size_t lo = 0;
   while (lo < njobs) {
     size_t hi = lo, bytes = 0;
     while (hi < njobs) {
-      const size_t b = job_bytes(jobs[hi], seg);
+      const size_t b = direct ? job_bytes_direct(jobs[hi]) : job_bytes(jobs[hi], seg);
       if (hi > lo && bytes + b > target) break;
       bytes += b; ++hi;
     }
-    int rc = encode_batch(ctx, jobs, lo, hi, seg);
+    int rc = encode_batch(ctx, jobs, lo, hi, direct ? (1u << 30) : seg, direct);
     if (rc) return rc;
     lo = hi;
   }

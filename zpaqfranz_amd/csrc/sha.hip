@@ -168,11 +168,14 @@ __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restric
                                                               const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
                                                               u32* __restrict__ counter, const u32* __restrict__ order,
                                                               u64 chain_min_len) {
+  // same flat loop as sha1_extents_kernel: the next block (and the one after) are in flight while the 64 rounds run
   bool have = false, marker = false;
   u32 idx = 0;
   const u8* p = nullptr;
   u64 total = 0, rem = 0;
+  u32 pre = 0;
   u32 s[8];
+  u32x4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0, m0 = n0, m1 = n0, m2 = n0, m3 = n0;
   for (;;) {
     if (!have) {
       idx = atomicAdd(counter, 1u);
@@ -185,17 +188,27 @@ __global__ __launch_bounds__(256) void sha256_extents_kernel(const u8* __restric
       s[4] = 0x510e527f; s[5] = 0x9b05688c; s[6] = 0x1f83d9ab; s[7] = 0x5be0cd19;
       marker = false;
       have = true;
+      pre = 0;
     }
     u32 w[16];
     bool last = false;
     if (rem >= 64) {
-      const u32x4_u* q = (const u32x4_u*)p;
-      u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+      if (pre == 0) {
+        const u32x4_u* q = (const u32x4_u*)p; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; pre = 1;
+      }
+      const u32x4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+      p += 64; rem -= 64;
+      if (pre == 2) { n0 = m0; n1 = m1; n2 = m2; n3 = m3; pre = 1; } else pre = 0;
+      if (pre == 0 && rem >= 64) {
+        const u32x4_u* q = (const u32x4_u*)p; n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; pre = 1;
+      }
+      if (pre == 1 && rem >= 128) {
+        const u32x4_u* q = (const u32x4_u*)(p + 64); m0 = q[0]; m1 = q[1]; m2 = q[2]; m3 = q[3]; pre = 2;
+      }
       w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
       w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
       w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
       w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
-      p += 64; rem -= 64;
     } else {
       last = tail_block(w, p, (u32)rem, marker, total);
       p += rem; rem = 0;
@@ -297,9 +310,10 @@ __device__ __forceinline__ void sha256_rounds_lane(const u32 (&wk)[64], int blk,
 // persistent waves: wave w takes the extents w, w + waves, ... whose length is at least `min_len`
 __global__ __launch_bounds__(64) void sha256_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                           const u64* __restrict__ len, u32 n, u64 min_len,
-                                                          u8* __restrict__ digests) {
+                                                          u8* __restrict__ digests, const u32* __restrict__ list) {
   const int lane = lane_id();
-  for (u32 idx = blockIdx.x; idx < n; idx += gridDim.x) {
+  for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+    const u32 idx = list ? list[k] : k;
     const u64 total = len[idx];
     if (total < min_len) continue;
     const u8* p = base + off[idx];
@@ -486,20 +500,58 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   counter += 32;
-  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, ctx->stream));
-  const int grid = persistent_grid(ctx, n, 2);
-  const u32* order = extent_order(ctx, ctx->stream, d_len, n, grid);
-  // extents of 1 MiB and more get a wave each (a lane hashes ~25 MB/s, a wave-wide chain ~1.5x that and the chip
-  // has waves to spare on the verify side, where extents are whole files); the rest one lane each
+  hipStream_t st = ctx->stream;
+  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, st));
+  // A chain is one wave's worth of dependent instructions whichever way it is laid out (about 4.3 cycles each):
+  //   one LANE per extent: 64 extents share a wave's instructions (schedule + rounds, ~1380 per 64-byte block);
+  //   one WAVE per extent: the schedule moves off the chain (~950 per block: 1.45x faster), 63 lanes idle.
+  // Waves on one SIMD share its issue slots, so the wave-wide form only pays while it has a SIMD to itself: the
+  // longest extents (at most one per SIMD, 1 MiB and more) get a wave each on the second stream, everything else
+  // goes lane-wise, longest first, on the main stream; both run at once.
   u64 chain_min = 1u << 20;
+  size_t max_chains = (size_t)ctx->cu_count * 4;
   if (const char* e = getenv("ZPQ_SHA256_CHAIN_MIN")) chain_min = strtoull(e, 0, 10);
-  ZPQ_LAUNCH(ctx, "sha256_extents_kernel", ctx->stream, sha256_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n,
+  if (const char* e = getenv("ZPQ_SHA256_CHAINS")) max_chains = strtoull(e, 0, 10);
+  if (n <= (1u << 18)) {
+    std::vector<u64> hl(n);
+    ZPQ_HIP(ctx, hipMemcpyAsync(hl.data(), d_len, n * 8, hipMemcpyDeviceToHost, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<u32> ord(n);
+    for (size_t i = 0; i < n; ++i) ord[i] = (u32)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hl[a] > hl[b]; });
+    size_t kc = 0;
+    while (kc < n && kc < max_chains && hl[ord[kc]] >= chain_min) ++kc;
+    u32* d_ord = (u32*)zpq_scratch(ctx, 8, n * 4 + 256);
+    if (!d_ord) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_ord, ord.data(), n * 4, hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));              // ord is a local
+    if (kc) {
+      ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
+      ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
+      ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream2, sha256_chain_kernel, dim3((unsigned)kc), dim3(64), d_base, d_off, d_len, (u32)kc, (u64)0,
+                 d_digests, (const u32*)d_ord);
+      ZPQ_HIP(ctx, hipGetLastError());
+      ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
+    }
+    if (n > kc) {
+      const int grid = persistent_grid(ctx, n - kc, 2);
+      ZPQ_LAUNCH(ctx, "sha256_extents_kernel", st, sha256_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)(n - kc),
+                 d_digests, counter, (const u32*)(d_ord + kc), ~(u64)0);
+      ZPQ_HIP(ctx, hipGetLastError());
+    }
+    if (kc) ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev, 0));
+    return ZPQ_OK;
+  }
+  // very many extents: lengths stay on the device (class order), long ones picked out by the kernels themselves
+  const int grid = persistent_grid(ctx, n, 2);
+  const u32* order = extent_order(ctx, st, d_len, n, grid);
+  ZPQ_LAUNCH(ctx, "sha256_extents_kernel", st, sha256_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n,
              d_digests, counter, order, chain_min);
   ZPQ_HIP(ctx, hipGetLastError());
   {
-    const unsigned waves = (unsigned)std::min<size_t>(n, (size_t)ctx->cu_count * 16);
-    ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream, sha256_chain_kernel, dim3(waves), dim3(64), d_base, d_off, d_len, (u32)n, chain_min,
-               d_digests);
+    const unsigned waves = (unsigned)std::min<size_t>(n, max_chains);
+    ZPQ_LAUNCH(ctx, "sha256_chain_kernel", st, sha256_chain_kernel, dim3(waves), dim3(64), d_base, d_off, d_len, (u32)n, chain_min,
+               d_digests, (const u32*)nullptr);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   return ZPQ_OK;
