@@ -714,7 +714,9 @@ def main():
         if extract:
             in_bytes = pipe.total                       # restored bytes
             ub = sum(pipe.usize)
-            alg = {"sha256_chain_kernel": pipe.total, "sha256_extents_kernel": pipe.total, "gather_kernel": 2 * pipe.total + 0,
+            # per STEP: the two SHA-256 kernels split the files between them (wave-wide for the longest, lane-wise for the rest)
+            chain_bytes = sum(sorted((pipe.file_off[i + 1] - pipe.file_off[i] for i in range(pipe.nfiles)), reverse=True)[:1024])
+            alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": pipe.total - chain_bytes, "gather_kernel": pipe.total + ub,
                    "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
             waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": pipe.nfiles}
             alg_step = pipe.arc_bytes + 3 * pipe.total  # r bytes read + 1 byte written + 1 byte read back for SHA-256, + the copy's read
@@ -725,8 +727,8 @@ def main():
             # algorithmic bytes per launch: fragment/hash kernels read every input byte once;
             # the LZ77 and checksum kernels read every unique byte once (+ r bytes written)
             alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
-                   "sha1_chain_kernel": ub // max(1, world)}
-            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20))}
+                   "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
+            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)), "lz77_direct_kernel": st["blocks"]}
             alg_step = 2 * pipe.total + 2 * (ub // max(1, world)) + out_bytes // max(1, world)   # per rank: fragment pass + hash pass + gather/LZ/checksum of unique bytes + output
             metric = ("MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x%d" % a.copies) if a.workload == "silesia_x256_m1" else \
                      ("MB/s compressed output (bit-identical .zpaq) at -m1, %d unique 16 MiB units x%d duplication per GPU" % (a.units, a.dup))
@@ -738,13 +740,13 @@ def main():
         def roof(k):
             cnt, ms = kern[k]
             per = ms / cnt
-            ab = alg.get(k)
+            ab = alg.get(k)          # algorithmic bytes of the kernel per STEP (a step may launch it more than once)
             if not ab:
                 return None
-            ach = ab / 1e9 / (per / 1e3)
+            ach = ab / 1e9 / (ms / steps / 1e3)
             r = {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(k), "avg_launch_ms": round(per, 4),
-                 "algorithmic_bytes_per_launch": int(ab), "ms_per_step": round(ms / steps, 3)}
+                 "launches_per_step": round(cnt / steps, 2), "algorithmic_bytes_per_step": int(ab), "ms_per_step": round(ms / steps, 3)}
             if k in VALU_OPS_PER_BYTE:
                 ceil = LANE_OPS_PER_S / VALU_OPS_PER_BYTE[k] / 1e9
                 r["integer_issue_ceiling_GBps"] = round(ceil, 1)
