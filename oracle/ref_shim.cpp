@@ -77,6 +77,11 @@ long ref_lzbuffer(const unsigned char* in, long n, const int args9[9], unsigned 
   });
 }
 
+// divsufsort (ZSFX/libzpaq.cpp:6047-6072): the suffix array LZBuffer builds for LZ77-SA / BWT
+long ref_divsufsort(const unsigned char* in, long n, int* sa) {
+  return guarded([&]() -> long { return n > 0 ? (long)libzpaq::divsufsort(in, sa, (int)n) : 0; });
+}
+
 // libzpaq::decompress (ZSFX/libzpaq.cpp:2368-2381): all blocks/segments concatenated.
 long ref_decompress(const unsigned char* arc, long n, unsigned char* out, long cap) {
   return guarded([&]() -> long {

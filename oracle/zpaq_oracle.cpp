@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -269,6 +270,122 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
   }
   emit_literals(bs, in, n, lit);                      // :6456-6460
   bs.flush();
+  if (ntrace) *ntrace = nt;
+  if ((long)v.size() > cap) return -2;
+  if (!v.empty()) memcpy(out, v.data(), v.size());
+  return (long)v.size();
+}
+
+// ------------------------------------------------------------------------------------------
+// Suffix array.  The reference calls divsufsort (ZSFX/libzpaq.cpp:6047-6072, body :4334-6040); the
+// suffix array of a string is unique, so any correct construction is a restatement of its RESULT.
+// This one is plain prefix doubling with std::sort (O(n log^2 n)): slow, obviously right, and pinned
+// against the real divsufsort (oracle/_ref, ref_divsufsort) by tests/test_sa_cpu.py.
+// ------------------------------------------------------------------------------------------
+extern "C" long orc_suffix_array(const U8* in, long n_, U32* sa) {
+  const U32 n = (U32)n_;
+  if (!n) return 0;
+  std::vector<U32> rank(n), tmp(n);
+  for (U32 i = 0; i < n; ++i) sa[i] = i, rank[i] = in[i];
+  for (U32 h = 1;; h *= 2) {
+    auto key2 = [&](U32 i) -> long { return i + h < n ? (long)rank[i + h] : -1; };   // the shorter suffix sorts first
+    auto less = [&](U32 a, U32 b) { return rank[a] != rank[b] ? rank[a] < rank[b] : key2(a) < key2(b); };
+    std::sort(sa, sa + n, less);
+    tmp[sa[0]] = 0;
+    for (U32 j = 1; j < n; ++j) tmp[sa[j]] = tmp[sa[j - 1]] + (less(sa[j - 1], sa[j]) ? 1 : 0);
+    rank.swap(tmp);
+    if (rank[sa[n - 1]] == n - 1 || h >= n) break;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// LZ77 with the suffix-array match finder (args[5]-args[0] >= 21): what compressBlock selects for
+// method 2 ("x<N>,1,4,0,7,<21+N>,1": minMatch 4, 127 neighbours either side, one byte of lookahead).
+// Reference: LZBuffer::LZBuffer :6260-6311 (sa, windowed isa), fill :6329-6372 (candidate search)
+// and :6412-6453 (decision, literals), write_literal / write_match :6463-6550 (levels 1 and 2).
+// The windowed inverse (isa[] holds one 2^(17+args[0]) window, rebuilt when the parse enters a new
+// one) is kept as the reference has it, because it decides when the lookahead search is skipped.
+// `sa_in` may be null (the suffix array is then built here).
+// ------------------------------------------------------------------------------------------
+extern "C" long orc_lz77_sa_encode(const U8* in, long n_, const int args[9], const U32* sa_in, U8* out, long cap,
+                                   U32* trace, long trace_cap, long* ntrace) {
+  const U32 n = (U32)n_;
+  const int level = args[1] & 3;
+  if (args[5] - args[0] < 21 || (level != 1 && level != 2)) return -10;
+  const U32 minMatch = args[2];
+  if ((minMatch < 4 && level == 1) || (minMatch < 1 && level == 2)) return -10;
+  const int checkbits = 17 + args[0];                  // :6253
+  const U32 maxMatch = (1u << 14) * 3, maxLiteral = (1u << 14) / 4;
+  const U32 lookahead = args[6];
+  const U32 bucket = (1u << args[4]) - 1;
+  const int rb = args[0] > 4 ? args[0] - 4 : 0;
+  const U32 mask = (1u << checkbits) - 1;
+  std::vector<U32> sav;
+  if (!sa_in) { sav.resize(n ? n : 1); orc_suffix_array(in, n, sav.data()); }
+  const U32* sa = sa_in ? sa_in : sav.data();
+  std::vector<U32> isa((size_t)1 << checkbits, 0);      // Array<unsigned> is zero-filled
+  std::vector<U8> v; v.reserve(n / 2 + 16);
+  BitSink bs(v);
+  auto write_literal = [&](U32 i, U32& lit) {
+    if (level == 1) { emit_literals(bs, in, i, lit); lit = 0; return; }
+    while (lit > 0) {                                    // level 2: 00xxxxxx then x+1 bytes
+      U32 lit1 = lit > 64 ? 64 : lit;
+      v.push_back((U8)(lit1 - 1));
+      for (U32 j = i - lit; j < i - lit + lit1; ++j) v.push_back(in[j]);
+      lit -= lit1;
+    }
+  };
+  auto write_match = [&](U32 len, U32 off) {
+    if (level == 1) { emit_match(bs, len, off, rb); return; }
+    --off;
+    while (len > 0) {
+      const U32 len1 = len > minMatch * 2 + 63 ? minMatch + 63 : len > minMatch + 63 ? len - minMatch : len;
+      if (off < (1u << 16)) { v.push_back((U8)(64 + len1 - minMatch)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      else if (off < (1u << 24)) { v.push_back((U8)(128 + len1 - minMatch)); v.push_back((U8)(off >> 16)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      else { v.push_back((U8)(192 + len1 - minMatch)); v.push_back((U8)(off >> 24)); v.push_back((U8)(off >> 16)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      len -= len1;
+    }
+  };
+  U32 i = 0, lit = 0; long nt = 0;
+  while (i < n) {
+    U32 blen = minMatch - 1, bp = 0, blit = 0; int bscore = 0;
+    if (sa[isa[i & mask]] != i)                          // :6341-6345
+      for (U32 j = 0; j < n; ++j)
+        if ((sa[j] & ~mask) == (i & ~mask)) isa[sa[j] & mask] = j;
+    for (U32 h = 0; h <= lookahead; ++h) {               // :6346-6371
+      const U32 q = isa[(h + i) & mask];
+      if (sa[q] != h + i) continue;
+      for (int j = -1; j <= 1; j += 2) {
+        for (U32 k = 1; k <= bucket; ++k) {
+          U32 p;
+          const U32 qq = q + (U32)(j * (int)k);          // unsigned wrap, as in the reference
+          if (qq < n && (p = sa[qq] - h) < i) {
+            U32 l, l1;
+            for (l = h; i + l < n && l < maxMatch && in[p + l] == in[i + l]; ++l) {}
+            for (l1 = h; l1 > 0 && in[p + l1 - 1] == in[i + l1 - 1]; --l1) {}
+            int score = (int)(l - l1) * 8 - lg(i - p) - 4 * (lit == 0 && l1 > 0) - 11;
+            for (U32 a = 0; a < h; ++a) score = score * 5 / 8;
+            if (score > bscore) blen = l, bp = p, blit = l1, bscore = score;
+            if (l < blen || l < minMatch || l > 255) break;
+          }
+        }
+      }
+      if (bscore <= 0 || blen < minMatch) break;
+    }
+    const U32 off = i - bp;                              // :6414-6427
+    if (off > 0 && bscore > 0 && blen - blit >= minMatch + (level == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)))) {
+      lit += blit;
+      write_literal(i + blit, lit);
+      write_match(blen - blit, off);
+      if (trace && nt < trace_cap) { trace[3 * nt] = i + blit; trace[3 * nt + 1] = blen - blit; trace[3 * nt + 2] = off; }
+      ++nt;
+    } else { blen = 1; ++lit; }
+    i += blen;                                           // :6430-6431
+    if (lit >= maxLiteral) write_literal(i, lit);        // :6450-6452
+  }
+  write_literal(n, lit);
+  if (level == 1) bs.flush();
   if (ntrace) *ntrace = nt;
   if ((long)v.size() > cap) return -2;
   if (!v.empty()) memcpy(out, v.data(), v.size());

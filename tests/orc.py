@@ -19,7 +19,7 @@ def _build():
 
 _L = C.CDLL(_build())
 _u8p = C.POINTER(C.c_ubyte)
-for name in ("orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
+for name in ("orc_suffix_array", "orc_lz77_sa_encode", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
     getattr(_L, name).restype = C.c_long
 
 
@@ -113,6 +113,30 @@ def lz77_encode(b, args, trace=False):
     return bytes(out[:r])
 
 
+def suffix_array(b):
+    import numpy as np
+    sa = np.zeros(max(1, len(b)), dtype=np.uint32)
+    _L.orc_suffix_array(_buf(b), C.c_long(len(b)), sa.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return sa[: len(b)]
+
+
+def lz77_sa_encode(b, args, sa=None, trace=False):
+    """LZ77 with the suffix-array match finder (levels 1 and 2); `sa` (numpy uint32) is optional."""
+    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
+    cap = len(b) + len(b) // 8 + 1024
+    out = (C.c_ubyte * cap)()
+    tcap = len(b) + 16 if trace else 0
+    tr = (C.c_uint32 * (3 * tcap))() if trace else None
+    nt = C.c_long(0)
+    sap = sa.ctypes.data_as(C.POINTER(C.c_uint32)) if sa is not None else None
+    r = _L.orc_lz77_sa_encode(_buf(b), C.c_long(len(b)), a, sap, out, C.c_long(cap), tr, C.c_long(tcap), C.byref(nt))
+    if r < 0:
+        raise RuntimeError("orc_lz77_sa_encode failed: %d" % r)
+    if trace:
+        return bytes(out[:r]), [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(nt.value)]
+    return bytes(out[:r])
+
+
 def lz77_decode(b, cap, rb=0):
     out = (C.c_ubyte * max(1, cap))()
     r = _L.orc_lz77_decode(_buf(b), C.c_long(len(b)), rb, out, C.c_long(cap))
@@ -149,7 +173,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libzpaqref.so")
 _R = None
 if os.path.exists(REF_SO):
     _R = C.CDLL(REF_SO)
-    for name in ("ref_fragment_sha1", "ref_lz1_block_cost", "ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode", "ref_cm_decode", "ref_tables"):
+    for name in ("ref_divsufsort", "ref_fragment_sha1", "ref_lz1_block_cost", "ref_lzbuffer", "ref_decompress", "ref_decompress_block", "ref_compile", "ref_postprocess", "ref_cm_encode", "ref_cm_decode", "ref_tables"):
         getattr(_R, name).restype = C.c_long
     _R.ref_last_error.restype = C.c_char_p
 
@@ -174,6 +198,15 @@ def ref_e8e9(b):
     x = _buf(b)
     _R.ref_e8e9(x, C.c_int(len(b)))
     return bytes(x)[: len(b)]
+
+
+def ref_divsufsort(b):
+    import numpy as np
+    sa = np.zeros(max(1, len(b)), dtype=np.int32)
+    r = _R.ref_divsufsort(_buf(b), C.c_long(len(b)), sa.ctypes.data_as(C.POINTER(C.c_int)))
+    if r < 0:
+        raise RuntimeError("ref_divsufsort: %s" % _R.ref_last_error())
+    return sa[: len(b)].astype(np.uint32)
 
 
 def ref_lzbuffer(b, args):
