@@ -6,6 +6,10 @@ Workloads (BASELINE.json `configs`):
                   fragment -> SHA-1 -> dedup -> pack -> LZ77 level 1 -> ZPAQ block framing.  Method "14" -> x4,1,5,0,3,24.
   dup8_m1         (configs[3] at the largest single-GPU size) 1024 unique 16 MiB units, every unit stored 8 times in
                   shuffled order (128 GiB in 2048 files of 64 MiB): the compressor is the workload (~1000 d blocks).
+  text_m2         (configs[2]) add -m2 of 10^9 bytes of text: 15 blocks of 64 MiB, each through the suffix array and the
+                  LZ77-SA parse (method 2 -> "x6,1,4,0,7,27,1": 127 suffix-array neighbours either side, one byte of
+                  lookahead; no context model at this level).  enwik9 itself cannot be fetched: a seeded word-model text
+                  generated on the device stands in.
   extract_m1      (configs[4]) extract of the silesia_x256_m1 archive: every d block decoded (device-resident
                   Decompresser), every fragment's SHA-1 checked against the h table, the 3072 files assembled in HBM
                   and their SHA-256 compared with the originals'.
@@ -538,6 +542,153 @@ class ExtractPipeline:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def text_blocks_dev(dev, nbytes, seed, block=(1 << 26) - 4096):
+    """Stand-in for enwik9: words drawn (Zipf) from a 2^18-word vocabulary over a skewed alphabet, with capitals,
+    punctuation, line ends, numbers and markup-like tokens mixed in; generated on the device, one tensor per block
+    (padded by 64 readable bytes)."""
+    g = torch.Generator(device=dev); g.manual_seed(1234)            # the vocabulary is the same for every rank and block
+    V = 1 << 18
+    wl = (2 + torch.poisson(torch.full((V,), 4.2, device=dev), generator=g)).clamp_(1, 24).to(torch.int64)
+    wl[:64] = torch.randint(1, 4, (64,), device=dev, generator=g)    # the most frequent words are short
+    tail = torch.rand(V, device=dev, generator=g)
+    sep = torch.full((V,), 32, dtype=torch.uint8, device=dev)
+    sep[tail < 0.06] = 44; sep[tail < 0.03] = 46; sep[tail < 0.012] = 10          # ", " ". " newline
+    vstart = torch.cumsum(wl + 1, 0) - (wl + 1)
+    nlet = int((wl + 1).sum().item())
+    freq = torch.tensor([8.2, 1.5, 2.8, 4.3, 12.7, 2.2, 2.0, 6.1, 7.0, .15, .77, 4.0, 2.4, 6.7, 7.5, 1.9, .1, 6.0, 6.3, 9.1, 2.8, .98, 2.4, .15, 2.0, .07], device=dev)
+    flat = (97 + torch.multinomial(freq, nlet, replacement=True, generator=g)).to(torch.uint8)
+    flat[vstart + wl] = sep
+    cap = torch.rand(V, device=dev, generator=g) < 0.04
+    flat[vstart[cap]] -= 32
+    digits = torch.rand(V, device=dev, generator=g) < 0.02
+    didx = torch.repeat_interleave(vstart[digits], wl[digits]) + (torch.arange(int(wl[digits].sum().item()), device=dev) -
+                                                                  torch.repeat_interleave(torch.cumsum(wl[digits], 0) - wl[digits], wl[digits]))
+    flat[didx] = (48 + torch.randint(0, 10, (didx.numel(),), device=dev, generator=g)).to(torch.uint8)
+    w = 1.0 / (torch.arange(V, device=dev, dtype=torch.float64) + 2.7) ** 1.08
+    cdf = torch.cumsum(w / w.sum(), 0)
+    out = []
+    g2 = torch.Generator(device=dev)
+    for k in range((nbytes + block - 1) // block):
+        n = min(block, nbytes - k * block)
+        g2.manual_seed(seed * 1000 + k)
+        nw = n // 5 + 64
+        ids = torch.searchsorted(cdf, torch.rand(nw, device=dev, dtype=torch.float64, generator=g2)).clamp_(max=V - 1)
+        ln = wl[ids] + 1
+        ostart = torch.cumsum(ln, 0) - ln
+        tot = int(ln.sum().item())
+        assert tot >= n
+        idx = torch.repeat_interleave(vstart[ids] - ostart, ln) + torch.arange(tot, device=dev)
+        t = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+        t[:n] = flat[idx[:n]]
+        out.append((t, n))
+        del idx, ids, ln, ostart
+    return out
+
+
+def main_text_m2(a, rank, world, local, dev):
+    """configs[2]: every rank compresses its own 10^9 bytes of text with method 2's LZ77-SA (blocks are independent: no
+    collective on the data path; weak scaling)."""
+    from zpaqfranz_amd import Engine, engine as E
+    method = b"2"                          # compressBlock: 64 MiB - 4096 byte blocks -> "x6,1,4,0,7,27,1"
+    bs = (1 << 26) - 4096
+    eng = Engine(local)
+    blocks = text_blocks_dev(dev, a.text_bytes, rank)
+    nb = len(blocks)
+    total = sum(n for _, n in blocks)
+    caps = [(eng.block_bound(n, b"", b"") + 63) & ~63 for _, n in blocks]
+    outs = torch.zeros(sum(caps), dtype=torch.uint8, device=dev)
+    jobs = (E.BlockJob * nb)()
+    p_out = 0
+    for k, (t, n) in enumerate(blocks):
+        jobs[k].in_ = t.data_ptr(); jobs[k].n = n; jobs[k].method = method
+        jobs[k].filename = b""; jobs[k].comment = b""; jobs[k].dosha1 = 1
+        jobs[k].out = outs.data_ptr() + p_out; jobs[k].out_cap = caps[k]
+        p_out += caps[k]
+    torch.cuda.synchronize()
+
+    def step():
+        eng.compress_blocks_dev(jobs, nb)
+        return sum(jobs[k].out_len for k in range(nb))
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(); eng.sync()
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup is not None else 1
+    for _ in range(warm):
+        step()
+    eng.profile(not a.no_kernel_timing)
+    barrier()
+    t0 = time.perf_counter()
+    out_bytes = 0
+    for _ in range(steps):
+        out_bytes = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_report(); eng.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt, float(out_bytes)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX); dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        dt = float(tt[0].item()); out_bytes = int(tt[1].item())
+    if rank == 0:
+        sec = dt / steps
+        # algorithmic bytes per step (SURVEY 8d has no figure for the suffix sort; the floor of any construction is the
+        # n input bytes read and the 4n bytes of suffix array written): candidates read SA/ISA/LCP once and write a decision
+        alg = {"sa_radix_sort_pairs": 5 * total, "lz77_sa_candidates_kernel": total * (1 + 4 + 4 + 2) + 16 * total,
+               "sa_lcp_kernel": total * (1 + 4 + 4) + 2 * total, "lz77_sa_walk_kernel": 16 * total, "sha1_chain_kernel": total}
+        sa_ms = sum(m for k_, (c_, m) in kern.items() if k_.startswith("sa_")) / steps
+
+        def roof(k):
+            cnt, ms = kern[k]
+            ach = alg[k] / 1e9 / (ms / steps / 1e3)
+            return {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "traffic": None, "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": round(cnt / steps, 2),
+                    "algorithmic_bytes_per_step": int(alg[k]), "ms_per_step": round(ms / steps, 3)}
+        dom = max((k for k in kern if k in alg), key=lambda k: kern[k][1], default=None)
+        res = {"metric": "MB/s compressed output at -m2 (LZ77 over a suffix array), %d bytes of text in 64 MiB - 4 KiB blocks" % total,
+               "value": round(out_bytes / 1e6 / sec, 3), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm,
+               "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": "synthetic",
+               "config": {"workload": "text_m2", "input_bytes": total * world, "blocks": nb * world, "block_bytes": bs,
+                          "method": "2 -> x6,1,4,0,7,27,1", "ratio": round(out_bytes / (total * world), 4)},
+               "input_GBps": round(total * world / 1e9 / sec, 3),
+               "suffix_array_ms_per_step": round(sa_ms, 2),
+               "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               "roofline": roof(dom) if dom else None,
+               "roofline_all": [roof(k) for k in sorted((k for k in kern if k in alg), key=lambda k: -kern[k][1])]}
+        if world == 1 and not a.no_verify:
+            # every block back through the device decoder (stored SHA-1 checked), bytes compared with the input
+            framed, p_out = [], 0
+            for k in range(nb):
+                framed.append((p_out, jobs[k].out_len)); p_out += caps[k]
+            uj = (E.UnblockJob * nb)()
+            back = [torch.empty(n + 64, dtype=torch.uint8, device=dev) for _, n in blocks]
+            for k in range(nb):
+                uj[k].in_ = outs.data_ptr() + framed[k][0]; uj[k].n = framed[k][1]
+                uj[k].out = back[k].data_ptr(); uj[k].out_cap = blocks[k][1] + 64
+            eng.decompress_blocks_dev(uj, nb, True)
+            ok = all(uj[k].status == 0 and uj[k].out_len == blocks[k][1] and bool(torch.equal(back[k][: blocks[k][1]], blocks[k][0][: blocks[k][1]]))
+                     for k in range(nb))
+            res["verified_roundtrip_all_blocks"] = bool(ok)
+            del back
+        if world == 1 and not a.no_cpu_baseline:
+            # the real reference (divsufsort + LZBuffer) over the same blocks on the host cores, whole job; it also
+            # compares every code stream with the one inside the GPU's framed block
+            blob = b"".join(bytes(t[:n].cpu().numpy()) for t, n in blocks)
+            fr = b"".join(bytes(outs[o:o + l].cpu().numpy()) for o, l in ((sum(caps[:k]), jobs[k].out_len) for k in range(nb)))
+            lens = [jobs[k].out_len for k in range(nb)]
+            cb = cpu_baseline("m2", [bs, json.dumps(lens)], [blob, fr])
+            if "identical_blocks" in cb:
+                res["verified_blocks"] = cb.pop("identical_blocks")
+                res["verified_all_blocks"] = res["verified_blocks"] == "%d of %d" % (nb, nb)
+            res["cpu_baseline"] = cb
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    eng.close()
+
+
 def cpu_baseline(mode, argv, blobs):
     """Runs tests/cpu_baseline.py (the reference's own code on all host cores) in a fresh process and returns its JSON."""
     import subprocess
@@ -564,7 +715,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="silesia_x256_m1", choices=["silesia_x256_m1", "dup8_m1", "extract_m1"])
+    ap.add_argument("--workload", default="silesia_x256_m1", choices=["silesia_x256_m1", "dup8_m1", "extract_m1", "text_m2"])
+    ap.add_argument("--text-bytes", type=int, default=10 ** 9, help="text_m2: bytes of text per GPU (enwik9 is 10^9)")
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--units", type=int, default=1024, help="dup8_m1: unique 16 MiB units per GPU")
     ap.add_argument("--dup", type=int, default=8, help="dup8_m1: copies of every unit")
@@ -600,6 +752,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    if a.workload == "text_m2":
+        return main_text_m2(a, rank, world, local, dev)
     steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few

@@ -250,6 +250,13 @@ int zpq_e8e9_dev(zpq_ctx* ctx, uint8_t* d_buf, size_t n);
  * d_out[0..n) = original bytes of the transformed d_in[0..n).  d_in must be readable 64 bytes past n. */
 int zpq_e8e9_inverse_dev(zpq_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, size_t n);
 
+/* ---- suffix array (row a9) -------------------------------------------------------------------- */
+/* divsufsort(T, SA, n) (ZSFX/libzpaq.cpp:6047-6072, called at :6304 for LZ77-SA and BWT): d_sa[0..n) = the
+ * positions of d_in[0..n) in suffix order (a shorter suffix sorts before a longer one it is a prefix of).
+ * d_isa, when not NULL, receives the inverse (d_isa[d_sa[j]] = j).  n < 2^31.  Jobs of zpq_lz77_encode_dev
+ * with args[5]-args[0] >= 21 (method 2: "x<N>,1,4,0,7,<21+N>,1") build it internally. */
+int zpq_suffix_array_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint32_t* d_sa, uint32_t* d_isa);
+
 /* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */
 /* compressBlock()'s expansion of "0".."5"[B][,R,t] into the x/0 method it stands for
  * (libzpaq 7.15 compressBlock; the snapshot's ZSFX/libzpaq.cpp ends before it, see config.hip).

@@ -8,6 +8,10 @@ the oracle.  One worker thread per usable core -- `zpaqfranz -tN` -- the C calls
                                                              unique 16 MiB block compressed ("14"); whole job timed
   cpu_baseline.py dup8 <pool file> <unique units> <dup>      the dup8 workload on a bounded sample of `unique units`
                                                              16 MiB units (same duplication factor, same generator)
+  cpu_baseline.py m2 <text file> <framed file> <block bytes> <framed lengths json>
+                                                             method 2 ("x6,1,4,0,7,27,1"): divsufsort + LZBuffer + SHA1 of
+                                                             every block; the code streams are compared with the ones
+                                                             inside the GPU's framed blocks (outside the timed part)
   cpu_baseline.py extract <blocks file> <index file>         d blocks decoded, fragments verified (SHA-1), files
                                                              assembled and hashed (SHA-256)
 Prints one JSON object."""
@@ -117,6 +121,55 @@ def main():
                "sample": "bounded sample = %d of the workload's %d unique 16 MiB units, same x%d duplication, %d threads: fragment loop + "
                          "libzpaq::SHA1 over %.1f GB in %.1f s, LZBuffer + SHA1 of %d blocks in %.1f s (rates scale with the unit count)"
                          % (units, full_units, dup, cores, total_in / 1e9, t_fh, len(blocks), t_c)}
+    elif mode == "m2":
+        text = open(sys.argv[2], "rb").read()
+        framed = open(sys.argv[3], "rb").read()
+        bs = int(sys.argv[4]); flens = json.loads(sys.argv[5])
+        nb = (len(text) + bs - 1) // bs
+        a0 = 6
+        args = (C.c_int * 9)(a0, 1, 4, 0, 7, 21 + a0, 1, 0, 0)
+        R, _ = lib()
+        if kind != "reference":
+            raise SystemExit("m2 baseline needs oracle/_ref (the real LZBuffer)")
+        mem = (C.c_ubyte * len(text)).from_buffer_copy(text)
+
+        def one(k):
+            off = k * bs; n = min(bs, len(text) - off)
+            cap = n + n // 8 + 1024
+            out = (C.c_ubyte * cap)()
+            r = R.ref_lzbuffer(C.byref(mem, off), C.c_long(n), args, out, C.c_long(cap))
+            d = (C.c_ubyte * 20)()
+            R.ref_sha1(C.byref(mem, off), C.c_long(n), d)
+            return bytes(out[:r])
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.time()
+            streams = list(ex.map(one, range(nb)))
+            tot = time.time() - t0
+
+        def lz_stream(fr):
+            """the LZ77 code stream inside a framed n=0 block: tag, zPQ, header, segment, stored sub-blocks, PCOMP preamble"""
+            p = 13 + 5
+            p += 2 + (fr[p] | fr[p + 1] << 8)
+            assert fr[p] == 1; p += 1
+            p = fr.index(b"\0", p) + 1; p = fr.index(b"\0", p) + 1
+            assert fr[p] == 0; p += 1
+            parts = []
+            while True:
+                k = int.from_bytes(fr[p:p + 4], "big"); p += 4
+                if not k:
+                    break
+                parts.append(fr[p:p + k]); p += k
+            pay = b"".join(parts)
+            assert pay[0] == 1
+            return pay[3 + (pay[1] | pay[2] << 8):]
+        same, q = 0, 0
+        for k in range(nb):
+            same += lz_stream(framed[q:q + flens[k]]) == streams[k]; q += flens[k]
+        out = sum(len(x) for x in streams)
+        res = {"value": round(out / 1e6 / tot, 3), "unit": "MB/s compressed output", "cores": cores, "kind": kind,
+               "input_GBps": round(len(text) / 1e9 / tot, 4), "seconds": round(tot, 2), "identical_blocks": "%d of %d" % (same, nb),
+               "sample": "WHOLE job timed, %d threads: divsufsort + LZBuffer::fill + libzpaq::SHA1 of %d blocks of %d MiB (%.2f GB) in %.1f s"
+                         % (cores, nb, bs >> 20, len(text) / 1e9, tot)}
     elif mode == "extract":
         import hashlib
         import numpy as np

@@ -1,0 +1,130 @@
+"""GPU parity for the suffix-array path (SURVEY.md rows a9 + a8/SA: what -m2 runs): zpq_suffix_array_dev against the
+oracle / the real divsufsort, and LZ77 jobs with args[5]-args[0] >= 21 against the oracle's restatement of
+LZBuffer::fill (bit-exact code streams), framed blocks through the decoder, and size-independent properties at
+block sizes the CPU oracle does not finish in seconds."""
+import numpy as np
+import pytest
+
+import datagen
+import orc
+from test_sa_cpu import CASES
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zpaqfranz_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_suffix_array_equals_oracle(eng, name, data):
+    sa, isa = eng.suffix_array(data, inverse=True)
+    assert np.array_equal(sa, orc.suffix_array(data))
+    if len(data):
+        assert np.array_equal(isa[sa], np.arange(len(data), dtype=np.uint32))
+
+
+@needs_ref
+def test_suffix_array_equals_divsufsort_4mib(eng):
+    t = datagen.text_like(1 << 20, 31)
+    data = t + datagen.mixed(2 << 20, 32) + t[: 1 << 19] + bytes(1 << 19)       # a long repeat and a run of zeros
+    assert np.array_equal(eng.suffix_array(data), orc.ref_divsufsort(data))
+
+
+def test_suffix_array_without_inverse_and_twice(eng):
+    data = datagen.binary_like(300001, 7)
+    a = eng.suffix_array(data)
+    assert np.array_equal(a, eng.suffix_array(data)) and np.array_equal(a, orc.suffix_array(data))
+
+
+SA_ARGS = [
+    (0, 1, 4, 0, 7, 21, 1),      # method 2 on a block of up to 1 MiB
+    (2, 1, 4, 0, 7, 23, 1),
+    (6, 1, 4, 0, 7, 27, 1),      # method 2 at its default 64 MiB block size (rb = 2)
+    (0, 1, 5, 0, 3, 21, 0),      # no lookahead, 7 neighbours
+    (0, 1, 4, 0, 0, 21, 1),      # no neighbours at all: literals only
+    (1, 1, 6, 0, 9, 23, 1),      # 511 neighbours
+]
+
+
+@pytest.mark.parametrize("args", SA_ARGS)
+def test_sa_parse_equals_oracle(eng, args):
+    blocks = [d for _, d in CASES]
+    out = eng.lz77_encode(blocks, [args] * len(blocks))
+    for (name, d), o in zip(CASES, out):
+        assert o == orc.lz77_sa_encode(d, args), name
+
+
+@pytest.mark.parametrize("seg", ["16", "64", "1000", "4096"])
+def test_sa_parse_does_not_depend_on_the_speculation_segments(eng, seg, monkeypatch):
+    """The chain is walked speculatively per segment and stitched: tiny segments force joins, own steps of the stitcher,
+    matches that jump over whole segments and literal runs that cross many of them."""
+    monkeypatch.setenv("ZPQ_SA_SEG", seg)
+    args = (0, 1, 4, 0, 7, 21, 1)
+    blocks = [d for _, d in CASES]
+    out = eng.lz77_encode(blocks, [args] * len(blocks))
+    for (name, d), o in zip(CASES, out):
+        assert o == orc.lz77_sa_encode(d, args), name
+
+
+def test_sa_parse_window_boundary(eng):
+    t = datagen.text_like(100000, 21)
+    data = t + t + t[:100000]                       # crosses two 2^17 windows at args[0] = 0
+    args = (0, 1, 4, 0, 7, 21, 1)
+    assert eng.lz77_encode([data], [args])[0] == orc.lz77_sa_encode(data, args)
+
+
+def test_sa_and_hash_jobs_in_one_call(eng):
+    a, b, c = datagen.mixed(400000, 1), datagen.text_like(300000, 2), datagen.binary_like(200000, 3)
+    sa_args, ht_args = (0, 1, 4, 0, 7, 21, 1), (4, 1, 4, 0, 3, 24)
+    out = eng.lz77_encode([a, b, c], [sa_args, ht_args, sa_args])
+    assert out[0] == orc.lz77_sa_encode(a, sa_args)
+    assert out[1] == orc.lz77_encode(b, ht_args)
+    assert out[2] == orc.lz77_sa_encode(c, sa_args)
+
+
+@needs_ref
+def test_sa_parse_equals_reference_lzbuffer_8mib(eng):
+    """An 8 MiB block (the real reference takes a few seconds): repeats longer than maxMatch, 4096+ literal runs."""
+    t = datagen.text_like(3 << 20, 41)
+    data = t + datagen.random_bytes(20000, 42) + t[1 << 20:] + datagen.mixed(3 << 20, 43) + bytes(70000)
+    data = data[: 8 << 20]
+    args = (3, 1, 4, 0, 7, 24, 1)
+    assert eng.lz77_encode([data], [args])[0] == orc.ref_lzbuffer(data, args)
+
+
+def test_method2_blocks_roundtrip_and_reference_decode(eng):
+    blocks = [datagen.text_like(900000, 5), datagen.mixed(1 << 20, 6), b"", b"abc", bytes(50000)]
+    methods = ["x0,1,4,0,7,21,1", "x0,1,4,0,7,21,1", "x0,1,4,0,7,21,1", "x0,1,4,0,7,21,1", "x6,1,4,0,7,27,1"]
+    framed = eng.compress_blocks(blocks, methods, None, None, True)
+    assert all(st == 0 for st, _ in framed)
+    res = eng.decompress_blocks_resident([f for _, f in framed], [len(b) + 64 for b in blocks])
+    for b, r in zip(blocks, res):
+        assert r["status"] == 0 and r["data"] == b
+    if orc.have_ref():
+        for b, (_, f) in zip(blocks, framed):
+            assert orc.ref_decompress(f, len(b) + 64) == b
+
+
+def test_block_64mib_properties(eng):
+    """At method 2's real block size the oracle is too slow: the stream must decode to the input (GPU decoder and the
+    oracle's decoder), and the suffix array must be a permutation in suffix order (checked on a sample of neighbours)."""
+    n = 64 << 20
+    unit = datagen.text_like(4 << 20, 51) + datagen.mixed(4 << 20, 52)
+    data = (unit * 8)[:n]                              # 8 MiB period: matches at distance 2^23, maxMatch-long
+    args = (6, 1, 4, 0, 7, 27, 1)
+    lz = eng.lz77_encode([data], [args])[0]
+    assert len(lz) < n // 4
+    assert orc.lz77_decode(lz, n, rb=2) == data
+    small = data[: 3 << 20]
+    sa = eng.suffix_array(small)
+    assert np.array_equal(np.sort(sa), np.arange(len(small), dtype=np.uint32))
+    rng = np.random.default_rng(5)
+    for j in rng.integers(1, len(small), 2000):
+        a, b = int(sa[j - 1]), int(sa[j])
+        assert small[a:a + 70000] < small[b:b + 70000] or small[a:] < small[b:]

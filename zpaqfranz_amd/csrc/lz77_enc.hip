@@ -58,18 +58,7 @@ struct LzSegDev {
                      // [4]=assumed entry cur [5]=assumed entry lit [6]=overflow [7]=valid
 };
 
-// per block (also what the pack kernels read)
-struct LzJobDev {
-  const u8* in;
-  u32 n;
-  u32 rb;
-  u32 nseg, seg0;    // segments seg0 .. seg0+nseg-1 in the segment array
-  u32* tok_pos; u32* tok_len; u32* tok_off; u32* tok_bit;   // final token list
-  u32 tok_cap;
-  u32* result;       // [0]=ntok, [1]=out_len bytes, [2]=overflow flag
-  u8* out; u32 out_cap;
-  u32* plan;         // per segment 2 x {which list (0 spec / 1 seam), from, to, dst}: token ranges to move
-};
+typedef zpq_lzjob_dev LzJobDev;   // per block (also what the pack kernels read): zpq_internal.h
 
 __device__ __forceinline__ int lg32(u32 x) { return x ? 32 - __builtin_clz(x) : 0; }  // lg(), :6224-6233
 // Input, hash tables and token lists are addressed as GLOBAL memory, the collision masks as LDS: with generic
@@ -823,8 +812,29 @@ extern "C" int zpq_debug_lzprof(unsigned long long out[8], int reset) {
 }
 #endif
 
+int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n) {
+  hipStream_t st = ctx->stream;
+  ZPQ_LAUNCH(ctx, "lz77_pack_tokens_kernel", st, lz77_pack_tokens_kernel, dim3((unsigned)nj), dim3(1024), d_jobs);
+  ZPQ_HIP(ctx, hipGetLastError());
+  if (max_n) {
+    ZPQ_LAUNCH(ctx, "lz77_pack_literals_kernel", st, lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)nj), dim3(256), d_jobs);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  return ZPQ_OK;
+}
+
+static bool uses_suffix_array(const int32_t a[9]) { return a[5] - a[0] >= 21; }
+
 static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
   if ((a[1] & 3) != 1 || a[1] > 5) return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 level %d not implemented", a[1]);
+  if (uses_suffix_array(a)) {        // LZ77-SA (method 2): lz77_sa.hip
+    if (a[0] < 0 || a[0] > 6 || a[5] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "suffix-array LZ77: block size 2^%d out of range", 20 + a[0]);
+    if (a[2] < 4 || a[2] > 255) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
+    if (a[4] < 0 || a[4] > 12) return zpq_fail(ctx, ZPQ_ERR_METHOD, "2^%d neighbours not implemented", a[4]);
+    if (a[6] < 0 || a[6] > 1) return zpq_fail(ctx, ZPQ_ERR_METHOD, "lookahead %d not implemented (0 and 1 are)", a[6]);
+    if ((u64)n > (1ull << (20 + a[0]))) return zpq_fail(ctx, ZPQ_ERR_ARG, "block of %u bytes exceeds 2^%d", n, 20 + a[0]);
+    return ZPQ_OK;
+  }
   if (a[3] != 0 || a[6] != 0) return zpq_fail(ctx, ZPQ_ERR_METHOD, "secondary context not implemented");
   if (a[2] < 4 || a[2] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
   if (a[4] < 0 || a[4] > 3) return zpq_fail(ctx, ZPQ_ERR_METHOD, "bucket 2^%d not implemented", a[4]);
@@ -1039,12 +1049,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     ZPQ_HIP(ctx, hipGetLastError());
   }
   // 4. tokens -> bits
-  ZPQ_LAUNCH(ctx, "lz77_pack_tokens_kernel", st, lz77_pack_tokens_kernel, dim3((unsigned)nj), dim3(1024), d_jobs);
-  ZPQ_HIP(ctx, hipGetLastError());
-  if (max_n) {
-    ZPQ_LAUNCH(ctx, "lz77_pack_literals_kernel", st, lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)nj), dim3(256), d_jobs);
-    ZPQ_HIP(ctx, hipGetLastError());
-  }
+  { int rc = zpq_lz77_pack_launch(ctx, d_jobs, nj, max_n); if (rc) return rc; }
   std::vector<u32> res(nj * 4);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
@@ -1064,6 +1069,21 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
     if (rc) return rc;
     if (jobs[i].out_cap < zpq_lz77_bound(jobs[i].n)) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: out_cap too small", i);
     if (((uintptr_t)jobs[i].d_out & 3) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: d_out must be 4-byte aligned", i);
+  }
+  {   // suffix-array jobs take their own path; the rest are parsed with hash tables below
+    std::vector<size_t> sa_jobs;
+    for (size_t i = 0; i < njobs; ++i) if (uses_suffix_array(jobs[i].args)) sa_jobs.push_back(i);
+    if (!sa_jobs.empty()) {
+      int rc = zpq_lz77_sa_encode(ctx, jobs, sa_jobs.data(), sa_jobs.size());
+      if (rc) return rc;
+      if (sa_jobs.size() == njobs) return ZPQ_OK;
+      std::vector<zpq_lz77_job> rest;
+      std::vector<size_t> at;
+      for (size_t i = 0; i < njobs; ++i) if (!uses_suffix_array(jobs[i].args)) { rest.push_back(jobs[i]); at.push_back(i); }
+      rc = zpq_lz77_encode_dev(ctx, rest.data(), rest.size());
+      for (size_t k = 0; k < rest.size(); ++k) jobs[at[k]] = rest[k];
+      return rc;
+    }
   }
   // A wave parses one segment on its own copy of the hash table (64 MiB for -m1), so HBM bounds the waves in flight.
   // Segment size: 1 MiB while everything fits one batch; with many blocks the segments grow (up to one per block:

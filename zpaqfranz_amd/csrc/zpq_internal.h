@@ -10,8 +10,9 @@
 #include "zpaqhip.h"
 
 // grow-only device scratch arenas; slot numbers are fixed per use (see the zpq_scratch callers):
-// 0-11 compress side / hashing, 12-17 the device-resident decode path (unblock.hip), 18-19 checksums
-#define ZPQ_SCRATCH_SLOTS 24
+// 0-11 compress side / hashing, 12-17 the device-resident decode path (unblock.hip), 18-19 checksums, 20-22 E8E9,
+// 24 per-block arrays of the suffix-array LZ77 path
+#define ZPQ_SCRATCH_SLOTS 28
 
 struct zpq_ctx {
   int device;
@@ -87,6 +88,23 @@ struct zpq_lzdec_dev {
   u8* out; u32 out_cap;
   u32* result;
 };
+// device-side record of one LZ77 block as the token -> bit pack kernels read it (lz77_enc.hip); also the job record of
+// the hash-table parse
+struct zpq_lzjob_dev {
+  const u8* in;
+  u32 n;
+  u32 rb;
+  u32 nseg, seg0;    // segments seg0 .. seg0+nseg-1 in the segment array
+  u32* tok_pos; u32* tok_len; u32* tok_off; u32* tok_bit;   // final token list
+  u32 tok_cap;
+  u32* result;       // [0]=ntok, [1]=out_len bytes, [2]=overflow flag
+  u8* out; u32 out_cap;
+  u32* plan;         // per segment 2 x {which list (0 spec / 1 seam), from, to, dst}: token ranges to move
+};
+// tokens -> code bits for nj records (out must be zeroed, result[0] = token count); max_n = longest block
+int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
+// the jobs jobs[which[0..nj)] whose match finder is the suffix array (lz77_sa.hip)
+int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, size_t nj);
 // launches one wave per record on `st`; no host round trip
 int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs);
 // the 302-byte LZ77 level-1 post-processor program (rb = 0, no E8E9): golden, AUTOTEST/sha256.zpaq i blocks

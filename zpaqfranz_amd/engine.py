@@ -104,6 +104,7 @@ def load():
     L.zpq_digest_compare_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.zpq_file_checksums_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.zpq_e8e9_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.zpq_suffix_array_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.zpq_expand_method.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.zpq_make_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zpq_compile_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -334,6 +335,25 @@ class Engine:
     # ---- LZ77 -----------------------------------------------------------------------------------
     def lz77_bound(self, n):
         return self.L.zpq_lz77_bound(n)
+
+    def suffix_array(self, data, inverse=False):
+        """divsufsort's result for `data` (numpy uint32), optionally with the inverse."""
+        import numpy as np
+        n = len(data)
+        d_in = self.upload(data) if n else self.alloc(16)
+        d_sa = self.alloc(max(16, 4 * n))
+        d_isa = self.alloc(max(16, 4 * n)) if inverse else None
+        try:
+            self._ck(self.L.zpq_suffix_array_dev(self.ctx, d_in.ptr, n, d_sa.ptr, d_isa.ptr if inverse else None))
+            sa = np.frombuffer(d_sa.download(4 * n), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+            if inverse:
+                isa = np.frombuffer(d_isa.download(4 * n), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+                return sa, isa
+            return sa
+        finally:
+            d_in.free(); d_sa.free()
+            if d_isa is not None:
+                d_isa.free()
 
     def lz77_encode(self, blocks, argsets):
         """Host convenience: list of bytes + list of args[<=9] -> list of code streams."""

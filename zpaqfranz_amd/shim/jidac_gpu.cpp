@@ -32,6 +32,18 @@ typedef std::vector<uint8_t> Bytes;
 
 const uint8_t kTag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
 const uint32_t kBlockLimit = (1u << 24) - 4096;
+// d block size for a method "LB...": 2^(20+B) - 4096 with B the digits after the level; without them zpaq uses B = 4
+// for levels 0 and 1 and B = 6 (64 MiB) above ("x"/"s" methods: the number after the letter).  Capped at what one
+// compressBlock call accepts here (2^26).
+uint32_t block_limit_for(const char* method) {
+  if (!method || !method[0]) return kBlockLimit;
+  const char* q = method + 1;
+  int b = -1;
+  if (*q >= '0' && *q <= '9') { b = 0; while (*q >= '0' && *q <= '9') b = b * 10 + (*q++ - '0'); }
+  if (b < 0) b = (method[0] == '0' || method[0] == '1' || method[0] == 'x' || method[0] == 's') ? 4 : 6;
+  if (b > 6) b = 6;
+  return (1u << (20 + b)) - 4096;
+}
 
 void put32(Bytes& b, uint32_t x) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(x >> (8 * i))); }
 void put64(Bytes& b, uint64_t x) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(x >> (8 * i))); }
@@ -315,9 +327,10 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   // 3. pack new fragments into d blocks; a block belongs to the context holding its first fragment
   std::vector<std::pair<size_t, size_t>> blocks;   // [begin, end) into newfrags
+  const uint32_t block_limit = block_limit_for(method);
   for (size_t b = 0; b < newfrags.size();) {
     size_t e = b; uint64_t bytes = 8;
-    while (e < newfrags.size() && (e == b || bytes + flen[newfrags[e]] + 4 <= kBlockLimit)) { bytes += flen[newfrags[e]] + 4; ++e; }
+    while (e < newfrags.size() && (e == b || bytes + flen[newfrags[e]] + 4 <= block_limit)) { bytes += flen[newfrags[e]] + 4; ++e; }
     blocks.push_back({b, e}); b = e;
   }
   std::vector<Bytes> dblock(blocks.size());
