@@ -54,6 +54,7 @@ SA_ARGS = [
 
 @pytest.mark.parametrize("args", SA_ARGS)
 def test_sa_parse_equals_oracle(eng, args):
+    """(the 511-neighbour case leaves the workgroup's LDS tile: the scan then reads the global arrays)"""
     blocks = [d for _, d in CASES]
     out = eng.lz77_encode(blocks, [args] * len(blocks))
     for (name, d), o in zip(CASES, out):

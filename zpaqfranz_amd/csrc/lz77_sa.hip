@@ -221,90 +221,124 @@ struct Best { u32 blen, bp, blit; int bscore; };
 constexpr u32 kTileR = 128;                   // neighbours either side held in LDS (method 2 looks at 127)
 constexpr u32 kTile = 256 + 2 * kTileR;
 
-// SA / LCP around the 256 slots of a workgroup: the neighbour scans of adjacent slots overlap almost entirely
+// SA / LCP / preceding byte around the 256 slots of a workgroup, one 8-byte LDS word per slot x:
+// sa[x] | lcp[x] << 32 | lcp[x+1] << 48 -- a scan step in either direction is a single ds_read_b64 (the byte before the
+// suffix, needed by the lookahead pass only, sits in its own array).  The neighbour scans of adjacent slots overlap
+// almost entirely, so the tile is read from HBM once per 256 slots.  INTILE: every neighbour the scan can reach is in
+// the tile (bucket < kTileR); otherwise slots outside it are fetched from the global arrays.
 struct Tile {
-  const u32* sa_g; const u16* lcp_g;
-  u32 t0, tn;                                 // slots [t0, t0+tn) are in LDS
-  const u32* sa_l; const u16* lcp_l;
-  __device__ __forceinline__ u32 sa(u32 qq) const { const u32 r = qq - t0; return r < tn ? sa_l[r] : sa_g[qq]; }
-  __device__ __forceinline__ u32 lcp(u32 qq) const { const u32 r = qq - t0; return r < tn ? lcp_l[r] : lcp_g[qq]; }
+  const u32* sa_g; const u16* lcp_g; const u8* bw_g;
+  u32 t0, tn, n;                              // slots [t0, t0+tn) are in LDS
+  const u64* pk; const u8* bw_l;
+  template <bool INTILE> __device__ __forceinline__ u64 word(u32 qq) const {
+    const u32 r = qq - t0;
+    if (INTILE || r < tn) return pk[r];
+    return (u64)sa_g[qq] | ((u64)lcp_g[qq] << 32) | ((u64)(qq + 1 < n ? lcp_g[qq + 1] : 0) << 48);
+  }
+  template <bool INTILE> __device__ __forceinline__ u32 bw(u32 qq) const { const u32 r = qq - t0; return (INTILE || r < tn) ? bw_l[r] : bw_g[qq]; }
 };
 
-__device__ __forceinline__ void load_tile(Tile& T, const u32* sa, const u16* lcp, u32 n, u32 q0, u32* sa_l, u16* lcp_l) {
-  T.sa_g = sa; T.lcp_g = lcp; T.sa_l = sa_l; T.lcp_l = lcp_l;
+template <bool BW>
+__device__ __forceinline__ void load_tile(Tile& T, const u32* sa, const u16* lcp, const u8* bw, u32 n, u32 q0, u64* pk, u8* bw_l) {
+  T.sa_g = sa; T.lcp_g = lcp; T.bw_g = bw; T.pk = pk; T.bw_l = bw_l; T.n = n;
   T.t0 = q0 >= kTileR ? q0 - kTileR : 0u;
   const u32 end = (u32)std::min<u64>((u64)q0 + 256 + kTileR, n);
   T.tn = end - T.t0;
-  for (u32 t = threadIdx.x; t < T.tn; t += 256) { sa_l[t] = sa[T.t0 + t]; lcp_l[t] = lcp[T.t0 + t]; }
+  for (u32 t = threadIdx.x; t < T.tn; t += 256) {
+    const u32 x = T.t0 + t;
+    pk[t] = (u64)sa[x] | ((u64)lcp[x] << 32) | ((u64)(x + 1 < n ? lcp[x + 1] : 0) << 48);
+    if (BW) bw_l[t] = bw[x];
+  }
   __syncthreads();
 }
 
-// One direction of the neighbour scan around SA slot q for lookahead h (:6350-6365).  The match length against the
-// k-th neighbour is the running minimum of lcp[] between the two slots; candidates at or after i are passed over.
-template <int DIR>
-__device__ __forceinline__ void scan_dir(const SaCfg& C, const Tile& T, u32 q, u32 i, u32 h, bool lit0, Best& B, bool& saw_l1) {
+// One direction of the neighbour scan around SA slot q without lookahead (:6350-6365, h = 0).  The match length against
+// the k-th neighbour is the running minimum of lcp[] between the two slots; neighbours at or after i are passed over.
+template <int DIR, bool INTILE>
+__device__ __forceinline__ void scan_dir0(const SaCfg& C, const Tile& T, u32 q, u32 i, Best& B) {
   u32 run = kLcpCap;
-  for (u32 k = 1; k <= C.bucket; ++k) {
-    u32 qq;
-    if (DIR < 0) { if (k > q) break; qq = q - k; run = std::min<u32>(run, T.lcp(qq + 1)); }
-    else { qq = q + k; if (qq >= C.n) break; run = std::min<u32>(run, T.lcp(qq)); }
-    const u32 s = T.sa(qq);
-    if (s < h) continue;                     // p = s - h wraps: not < i
-    const u32 p = s - h;
+  const u32 total = DIR < 0 ? std::min(C.bucket, q) : std::min(C.bucket, C.n - 1 - q);
+  for (u32 k = 1; k <= total; ++k) {
+    const u32 qq = DIR < 0 ? q - k : q + k;
+    const u64 w = T.word<INTILE>(qq);
+    run = std::min<u32>(run, DIR < 0 ? (u32)(w >> 48) : (u32)(w >> 32) & 0xffffu);      // lcp[qq+1] going down, lcp[qq] going up
+    const u32 p = (u32)w;
     if (p >= i) continue;
-    const u32 l = std::min(run + h, kMaxMatch);  // counted from h: in[p+h..] against in[i+h..]; lcp <= n-(i+h) keeps it inside the block
-    u32 l1 = 0;
-    if (h) { l1 = C.in[p] == C.in[i] ? 0u : 1u; saw_l1 |= l1 != 0; }   // h <= 1: the one byte before the lookahead point
-    int score = (int)(l - l1) * 8 - lg32(i - p) - 4 * (int)(lit0 && l1 > 0) - 11;
-    for (u32 a = 0; a < h; ++a) score = score * 5 / 8;
-    if (score > B.bscore) { B.blen = l; B.bp = p; B.blit = l1; B.bscore = score; }
+    const u32 l = std::min(run, kMaxMatch);      // never past the end of the block: lcp <= n - i
+    const int score = (int)l * 8 - lg32(i - p) - 11;
+    if (score > B.bscore) { B.blen = l; B.bp = p; B.blit = 0; B.bscore = score; }
     if (l < B.blen || l < C.minMatch || l > 255) break;
   }
 }
 
-// pass 1, one lane per SA slot: the search without lookahead (state independent).  rec[2i] = blen:bp, rec[2i+1] = bscore
-__global__ __launch_bounds__(256) void lz77_sa_cand0_kernel(SaCfg C, const u32* __restrict__ sa, const u16* __restrict__ lcp, u64* __restrict__ rec) {
-  __shared__ u32 sa_l[kTile];
-  __shared__ u16 lcp_l[kTile];
+// The lookahead scan (h = 1) around the slot of position i+1, for both parse states at once: the candidates, their
+// lengths and the leading literal are the same, only the score term 4*(lit==0 && l1>0) and with it each state's best
+// and break point differ.
+template <int DIR, bool INTILE>
+__device__ __forceinline__ void scan_dir1(const SaCfg& C, const Tile& T, u32 q, u32 i, u32 my_bw, Best& A, Best& B) {
+  u32 run = kLcpCap;
+  bool actA = true, actB = true;
+  const u32 total = DIR < 0 ? std::min(C.bucket, q) : std::min(C.bucket, C.n - 1 - q);
+  for (u32 k = 1; k <= total; ++k) {
+    const u32 qq = DIR < 0 ? q - k : q + k;
+    const u64 w = T.word<INTILE>(qq);
+    run = std::min<u32>(run, DIR < 0 ? (u32)(w >> 48) : (u32)(w >> 32) & 0xffffu);
+    const u32 s = (u32)w;
+    if (s < 1 || s - 1 >= i) continue;           // p = s - 1 must exist and lie before i
+    const u32 p = s - 1;
+    const u32 l = std::min(run + 1u, kMaxMatch); // counted from the lookahead point; lcp <= n - (i+1) keeps it inside the block
+    const u32 l1 = T.bw<INTILE>(qq) == my_bw ? 0u : 1u;   // in[p] against in[i]
+    const int base = (int)(l - l1) * 8 - lg32(i - p) - 11;
+    const int sA = (base - 4 * (int)l1) * 5 / 8, sB = base * 5 / 8;
+    const bool stop = l < C.minMatch || l > 255;
+    if (actA) { if (sA > A.bscore) { A.blen = l; A.bp = p; A.blit = l1; A.bscore = sA; } if (l < A.blen || stop) actA = false; }
+    if (actB) { if (sB > B.bscore) { B.blen = l; B.bp = p; B.blit = l1; B.bscore = sB; } if (l < B.blen || stop) actB = false; }
+    if (!actA && !actB) break;
+  }
+}
+
+// pass 1, one lane per SA slot: the search without lookahead (state independent).  rec[2i] = blen:bp, rec[2i+1] = bscore;
+// bw[q] = the byte before suffix sa[q] (what pass 2 compares instead of fetching in[p] per candidate)
+template <bool INTILE>
+__global__ __launch_bounds__(256) void lz77_sa_cand0_kernel(SaCfg C, const u32* __restrict__ sa, const u16* __restrict__ lcp, u64* __restrict__ rec,
+                                                            u8* __restrict__ bw) {
+  __shared__ u64 pk[kTile];
   Tile T;
   const u32 q0 = blockIdx.x * 256u;
-  load_tile(T, sa, lcp, C.n, q0, sa_l, lcp_l);
+  load_tile<false>(T, sa, lcp, nullptr, C.n, q0, pk, nullptr);
   const u32 q = q0 + threadIdx.x;
   if (q >= C.n) return;
-  const u32 i = T.sa(q);
+  const u32 i = (u32)T.word<true>(q);
+  bw[q] = i ? C.in[i - 1] : 0;
   Best B{C.minMatch - 1, 0u, 0u, 0};
-  bool dummy = false;
-  scan_dir<-1>(C, T, q, i, 0, false, B, dummy);
-  scan_dir<+1>(C, T, q, i, 0, false, B, dummy);
+  scan_dir0<-1, INTILE>(C, T, q, i, B);
+  scan_dir0<+1, INTILE>(C, T, q, i, B);
   rec[2 * (size_t)i] = ((u64)B.blen << 32) | B.bp;
   rec[2 * (size_t)i + 1] = (u64)(u32)B.bscore;
 }
 
 // pass 2, one lane per SA slot q1 = slot of position i+1: the lookahead search for both values of (lit == 0), then the
 // decision (:6414-6417).  The lane whose suffix is position 0 finishes position n-1, which has no successor.
-__global__ __launch_bounds__(256) void lz77_sa_cand1_kernel(SaCfg C, const u32* __restrict__ sa, const u16* __restrict__ lcp, u64* __restrict__ rec) {
-  __shared__ u32 sa_l[kTile];
-  __shared__ u16 lcp_l[kTile];
+template <bool INTILE>
+__global__ __launch_bounds__(256) void lz77_sa_cand1_kernel(SaCfg C, const u32* __restrict__ sa, const u16* __restrict__ lcp, const u8* __restrict__ bw,
+                                                            u64* __restrict__ rec) {
+  __shared__ u64 pk[kTile];
+  __shared__ u8 bw_l[kTile];
   Tile T;
   const u32 q0 = blockIdx.x * 256u;
-  load_tile(T, sa, lcp, C.n, q0, sa_l, lcp_l);
+  load_tile<true>(T, sa, lcp, bw, C.n, q0, pk, bw_l);
   const u32 q1 = q0 + threadIdx.x;
   if (q1 >= C.n) return;
-  const u32 j = T.sa(q1);
+  const u32 j = (u32)T.word<true>(q1);
   const u32 i = j ? j - 1 : C.n - 1;
   const u64 r0 = rec[2 * (size_t)i], r1 = rec[2 * (size_t)i + 1];
   Best B0{(u32)(r0 >> 32), (u32)r0, 0u, (int)(u32)r1};
   Best BA = B0, BB = B0;                                   // lit == 0 / lit > 0
   // isa[] of the reference holds one window of 2^checkbits positions (:6341-6348): position i+1 is visible from i only inside it
   if (j && C.lookahead >= 1 && !(B0.bscore <= 0 || B0.blen < C.minMatch) && (j >> C.checkbits) == (i >> C.checkbits)) {
-    bool saw_l1 = false;
-    scan_dir<-1>(C, T, q1, i, 1, true, BA, saw_l1);
-    scan_dir<+1>(C, T, q1, i, 1, true, BA, saw_l1);
-    if (saw_l1) {            // the two states differ only through candidates that start with a literal
-      bool d = false;
-      scan_dir<-1>(C, T, q1, i, 1, false, BB, d);
-      scan_dir<+1>(C, T, q1, i, 1, false, BB, d);
-    } else BB = BA;
+    const u32 my_bw = T.bw<true>(q1);                      // in[i]
+    scan_dir1<-1, INTILE>(C, T, q1, i, my_bw, BA, BB);
+    scan_dir1<+1, INTILE>(C, T, q1, i, my_bw, BA, BB);
   }
   const u32 offA = i - BA.bp, offB = i - BB.bp;
   const bool takeA = offA > 0 && BA.bscore > 0 && BA.blen - BA.blit >= C.minMatch;    // level 1
@@ -517,7 +551,7 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
   u32 max_n_all = 0;
   for (size_t w = 0; w < nj_all; ++w) max_n_all = std::max(max_n_all, jobs[which[w]].n);
   const size_t nn_max = ((size_t)max_n_all + 255) & ~(size_t)255;
-  const size_t shared_bytes = nn_max * 4 * 2 + (nn_max + 256) * 2 + 1024 + sa_work_bytes(max_n_all);
+  const size_t shared_bytes = nn_max * 4 * 2 + (nn_max + 256) * 2 + nn_max + 2048 + sa_work_bytes(max_n_all);
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   size_t budget = std::max<size_t>((size_t)2 << 30, (free_b + ctx->scratch_cap[0] + ctx->scratch_cap[24]) / 10 * 6);
@@ -543,6 +577,7 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
     u32* d_sa = carve<u32>(sp, nn_max);
     u32* d_isa = carve<u32>(sp, nn_max);
     u16* d_lcp = carve<u16>(sp, nn_max + 256);
+    u8* d_bw = carve<u8>(sp, nn_max);
     u8* sort_work = sp;
     u8* mp = d_meta;
     zpq_lzjob_dev* d_jobs = carve<zpq_lzjob_dev>(mp, nj);
@@ -592,8 +627,13 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
         ZPQ_LAUNCH(ctx, "sa_lcp_kernel", st, sa_lcp_kernel, dim3(((n + kLcpChunk - 1) / kLcpChunk + 255) / 256), dim3(256), J.in, n, d_sa, d_isa, d_lcp);
         SaCfg C;
         C.in = J.in; C.n = n; C.minMatch = (u32)z.args[2]; C.bucket = (1u << z.args[4]) - 1; C.lookahead = (u32)z.args[6]; C.checkbits = 17 + (u32)z.args[0];
-        ZPQ_LAUNCH(ctx, "lz77_sa_cand0_kernel", st, lz77_sa_cand0_kernel, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, rec);
-        ZPQ_LAUNCH(ctx, "lz77_sa_cand1_kernel", st, lz77_sa_cand1_kernel, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, rec);
+        if (C.bucket < kTileR) {         // every neighbour a scan reaches is inside the workgroup's tile
+          ZPQ_LAUNCH(ctx, "lz77_sa_cand0_kernel", st, lz77_sa_cand0_kernel<true>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, rec, d_bw);
+          ZPQ_LAUNCH(ctx, "lz77_sa_cand1_kernel", st, lz77_sa_cand1_kernel<true>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, d_bw, rec);
+        } else {
+          ZPQ_LAUNCH(ctx, "lz77_sa_cand0_kernel", st, lz77_sa_cand0_kernel<false>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, rec, d_bw);
+          ZPQ_LAUNCH(ctx, "lz77_sa_cand1_kernel", st, lz77_sa_cand1_kernel<false>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, d_bw, rec);
+        }
         ZPQ_LAUNCH(ctx, "lz77_sa_takeb_kernel", st, lz77_sa_takeb_kernel, dim3((n + 255) / 256), dim3(256), rec, n, takeb);
         ZPQ_HIP(ctx, hipGetLastError());
       }
