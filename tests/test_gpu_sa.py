@@ -129,3 +129,19 @@ def test_block_64mib_properties(eng):
     for j in rng.integers(1, len(small), 2000):
         a, b = int(sa[j - 1]), int(sa[j])
         assert small[a:a + 70000] < small[b:b + 70000] or small[a:] < small[b:]
+
+
+def test_jidac_add_with_method_2(eng):
+    """add -m2 through the journaling shim: 64 MiB d blocks (one here), suffix-array LZ77 inside; the archive extracts
+    to the files and the real reference decoder walks it."""
+    from zpaqfranz_amd import engine as E
+    shared = datagen.text_like(3 << 20, 81)
+    files = [("t/one", shared + datagen.mixed(2 << 20, 82)), ("t/two", datagen.binary_like(1 << 20, 83)), ("t/three", shared), ("t/empty", b"")]
+    arc, st = E.jidac_add(eng, b"", files, 20240101120000, method="2")
+    assert st["d_blocks"] == 1 and st["unique_bytes"] == (3 << 20) + (2 << 20) + (1 << 20)      # one 64 MiB block, the shared text once
+    assert E.jidac_extract(eng, arc) == dict(files)
+    arc14, _ = E.jidac_add(eng, b"", files, 20240101120000, method="14")
+    assert len(arc) < len(arc14)                               # the longer search pays on this data
+    if orc.have_ref():
+        out = orc.ref_decompress(arc, 64 << 20)                # c, d, h, i blocks concatenated by libzpaq::decompress
+        assert (shared + files[0][1][3 << 20:] + files[1][1]) in out
