@@ -10,6 +10,8 @@
 // The stream is untrusted (archives come from anywhere): lengths are capped (<= 24 gamma doublings, far
 // beyond what any encoder emits), capacity is checked in 64 bits, offsets must point into produced output,
 // and far matches longer than their offset are copied in pieces that only read what is already written.
+#include <stdlib.h>
+
 #include "zpq_internal.h"
 
 namespace {
@@ -193,11 +195,374 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
   if (lane == 0) { J.result[0] = op; J.result[1] = (u32)status; }
 }
 
+
+// ---- parse off the chain ----------------------------------------------------------------------------------------------
+// The wave above spends ~250 scalar instructions per token on PARSING; the copies are cheap.  The parse state between
+// two tokens is one number (the bit position), so a parse started at any bit merges with the true one at their first
+// common token start and follows it from there -- and on real streams a garbage parse lands on a true token start
+// within a few dozen tokens.  Lanes parse 1 KiB segments of the code stream from 256 bytes before their segment
+// (lzdec_spec_kernel: marks the token starts it visits inside its segment, records where it leaves), one lane per block
+// follows the true chain through those marks (lzdec_stitch_kernel: first true token start of every segment), the lanes
+// then parse their segment again from that start and write the token list (count, scan, emit), and one wave per block
+// replays the list: literal runs and match copies, nothing else (lz77_copy_kernel).  Same results, same error behaviour
+// (a bad code becomes an error token at its place in the list; capacity and offset checks stay with the copies).
+struct LzParDev {
+  const u8* in; u32 n; u32 rb;
+  u8* out; u32 out_cap; u32* result;          // result[0] = out_len, result[1] = status
+  u32 nseg, seg0;
+  u32* visit;                                  // bit per stream bit: token start seen by the segment's lane
+  u32* sexit; u32* entry; u32* cnt; u32* dst;  // per segment
+  u64* tok; u32* ntok;                         // token list (len | kind << 31, offset or literal bit position)
+};
+constexpr u32 kSegBits = 8192, kWarmBits = 2048;
+constexpr u32 kEnd = 0xffffffffu, kDead = 0xfffffffeu, kNone = 0xffffffffu;
+constexpr u32 kTokErr = 0xffffffffu;
+
+struct Tok { u32 kind; u32 len; u32 x; u32 next; };    // kind 0 literal (x = bit position of the bytes), 1 match (x = offset), 2 end, 3 bad code
+
+__device__ __forceinline__ u64 peek_g(g_cu8* in, u32 n, u32 b) {      // 64 bits of the stream from bit b on; bytes past n read as 0
+  const u32 byte = b >> 3, sh = b & 7;
+  u64 lo; u32 hi;
+  if (byte + 9 <= n) { lo = load8(in + byte); hi = in[byte + 8]; }
+  else {
+    lo = 0; hi = 0;
+    for (u32 j = 0; j < 8; ++j) if (byte + j < n) lo |= (u64)in[byte + j] << (8 * j);
+    if (byte + 8 < n) hi = in[byte + 8];
+  }
+  return sh ? (lo >> sh) | ((u64)hi << (64 - sh)) : lo;
+}
+
+// one token at bit position bp: exactly the parse of lz77_decode_kernel
+__device__ __forceinline__ Tok parse_token(g_cu8* in, u32 n, u32 rb, u32 bp0) {
+  Tok T; T.kind = 2; T.len = 0; T.x = 0; T.next = kEnd;
+  const u64 nbits = (u64)n * 8;
+  u64 bp = bp0;
+  if (bp + 2 > nbits) return T;
+  u64 w = peek_g(in, n, bp0);
+  const u32 mmv = (u32)(w & 3);
+  u32 used = 2; w >>= 2;
+  if (mmv == 0) {
+    u32 nb;
+    u32 len = gamma_decode(w, nb);
+    if (nb == 0xffffffffu) { if (bp + used + 50 <= nbits) T.kind = 3; return T; }
+    used += nb;
+    if (bp + used > nbits) return T;
+    bp += used;
+    const u64 avail = (nbits - bp) >> 3;
+    const bool cutoff = avail < len;
+    if (cutoff) len = (u32)avail;
+    T.kind = 0; T.len = len; T.x = (u32)bp;
+    T.next = cutoff ? kEnd : (u32)(bp + 8ull * len);
+    return T;
+  }
+  if (bp + 5 > nbits) return T;
+  const u32 lo = (mmv - 1) * 8 + (u32)(w & 7); w >>= 3; used += 3;
+  u32 nb;
+  u32 len = gamma_decode(w, nb);
+  if (nb == 0xffffffffu) { if (bp + used + 50 <= nbits) T.kind = 3; return T; }
+  w >>= nb; used += nb;
+  if (bp + used + 2 > nbits) return T;
+  len = len * 4 + (u32)(w & 3); used += 2;
+  w >>= 2;
+  bp += used;
+  if (bp + rb + lo > nbits) return T;
+  if (used + rb + lo > 64) w = peek_g(in, n, (u32)bp);
+  const u32 r = (u32)(w & ((1ull << rb) - 1)); w >>= rb;
+  const u32 qv = (u32)(w & ((1ull << lo) - 1)) | (1u << lo);
+  bp += rb + lo;
+  T.kind = 1; T.len = len; T.x = ((qv << rb) | r) - ((1u << rb) - 1u); T.next = (u32)bp;
+  return T;
+}
+
+__global__ __launch_bounds__(64) void lzdec_spec_kernel(const LzParDev* __restrict__ blocks, const u32* __restrict__ seg_block, u32 nseg_total) {
+  const u32 g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= nseg_total) return;
+  const LzParDev B = blocks[seg_block[g]];
+  const u32 k = g - B.seg0;
+  const u32 nbits = B.n * 8u;
+  const u32 beg = k * kSegBits, end = nbits - beg < kSegBits ? nbits : beg + kSegBits;
+  g_cu8* in = (g_cu8*)B.in;
+  u32 p = k ? beg - kWarmBits : 0u;
+  while (p < end) {
+    if (p >= beg) atomicOr(B.visit + (p >> 5), 1u << (p & 31));
+    const Tok T = parse_token(in, B.n, B.rb, p);
+    if (T.kind == 3) { p = kDead; break; }
+    p = T.next;                                   // kEnd after the last token
+  }
+  B.sexit[k] = p;
+}
+
+__global__ __launch_bounds__(64) void lzdec_stitch_kernel(const LzParDev* __restrict__ blocks) {
+  if (threadIdx.x) return;
+  const LzParDev B = blocks[blockIdx.x];
+  g_cu8* in = (g_cu8*)B.in;
+  const u32 nbits = B.n * 8u;
+  u32 p = 0;
+  while (p < nbits) {
+    const u32 k = p / kSegBits;
+    if (B.entry[k] == kNone) B.entry[k] = p;
+    if ((B.visit[p >> 5] >> (p & 31)) & 1u) { p = B.sexit[k]; continue; }   // kEnd / kDead end the loop (both >= nbits)
+    const Tok T = parse_token(in, B.n, B.rb, p);
+    if (T.kind >= 2) break;
+    p = T.next;
+  }
+}
+
+// walks the true chain through segment k from its entry; F(token) for every token produced there
+template <class F>
+__device__ __forceinline__ void walk_segment(const LzParDev& B, u32 k, F f) {
+  u32 p = B.entry[k];
+  if (p == kNone) return;
+  const u32 nbits = B.n * 8u;
+  const u32 beg = k * kSegBits, end = nbits - beg < kSegBits ? nbits : beg + kSegBits;
+  g_cu8* in = (g_cu8*)B.in;
+  while (p < end) {
+    const Tok T = parse_token(in, B.n, B.rb, p);
+    if (T.kind == 2) break;
+    f(T);
+    if (T.kind == 3) break;
+    p = T.next;
+  }
+}
+
+__global__ __launch_bounds__(64) void lzdec_count_kernel(const LzParDev* __restrict__ blocks, const u32* __restrict__ seg_block, u32 nseg_total) {
+  const u32 g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= nseg_total) return;
+  const LzParDev B = blocks[seg_block[g]];
+  u32 c = 0;
+  walk_segment(B, g - B.seg0, [&](const Tok& T) { c += (T.kind == 3 || T.len) ? 1u : 0u; });
+  B.cnt[g - B.seg0] = c;
+}
+
+__global__ __launch_bounds__(1024) void lzdec_scan_kernel(const LzParDev* __restrict__ blocks) {
+  const LzParDev B = blocks[blockIdx.x];
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 k0 = 0; k0 < B.nseg; k0 += 1024) {
+    const u32 k = k0 + tid;
+    const u32 cnt = k < B.nseg ? B.cnt[k] : 0u;
+    u32 x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(x, d); if (lane >= (u32)d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u32 wbase = 0;
+    for (u32 w = 0; w < wave; ++w) wbase += wsum[w];
+    const u32 carry = carry_s;
+    if (k < B.nseg) B.dst[k] = carry + wbase + x - cnt;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
+  }
+  if (tid == 0) *B.ntok = carry_s;
+}
+
+__global__ __launch_bounds__(64) void lzdec_emit_kernel(const LzParDev* __restrict__ blocks, const u32* __restrict__ seg_block, u32 nseg_total) {
+  const u32 g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= nseg_total) return;
+  const LzParDev B = blocks[seg_block[g]];
+  u64* o = B.tok + B.dst[g - B.seg0];
+  walk_segment(B, g - B.seg0, [&](const Tok& T) {
+    if (T.kind == 3) *o++ = (u64)kTokErr;
+    else if (T.len) *o++ = (u64)(T.len | (T.kind == 0 ? 0x80000000u : 0u)) | ((u64)T.x << 32);
+  });
+}
+
+// Replays a token list.  64 tokens per step, one per lane: output positions by a wave prefix sum, then
+//  * short tokens (<= 32 bytes) whose source lies entirely before the step's output are copied by their own lane, all at
+//    once -- from the code stream (literals), from the LDS ring holding the last 64 KiB of output, or from HBM when the
+//    source is further back;
+//  * short matches that read what this step writes (including self-overlapping ones) follow in order, one lane at a time;
+//  * a long token is copied by the whole wave (the loops of lz77_decode_kernel) and splits the step, so that the ring
+//    always receives the output in order.
+// Offsets and capacity are checked per token in order: the first offending token ends the replay with its status and
+// nothing of it is written.
+constexpr u32 kShort = 32;
+
+__device__ __forceinline__ void copy_lit_short(g_cu8* in, u32 n, g_u8* out, l_u8* ring, u32 bit, u32 len, u32 op) {
+  for (u32 j = 0; j < len; j += 8) {
+    u64 w = peek_g(in, n, bit + 8 * j);
+    const u32 m = len - j < 8 ? len - j : 8;
+    for (u32 i = 0; i < m; ++i) { const u8 c = (u8)w; w >>= 8; out[op + j + i] = c; ring[(op + j + i) & (kRing - 1)] = c; }
+  }
+}
+__device__ __forceinline__ void copy_ring_short(g_u8* out, l_u8* ring, u32 off, u32 len, u32 op) {
+  for (u32 j = 0; j < len; ++j) { const u8 c = ring[(op + j - off) & (kRing - 1)]; out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
+}
+__device__ __forceinline__ void copy_far_short(g_u8* out, l_u8* ring, u32 off, u32 len, u32 op) {
+  for (u32 j = 0; j < len; ++j) { const u8 c = __builtin_nontemporal_load((g_cu8*)out + op + j - off); out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
+}
+
+__global__ __launch_bounds__(64) void lz77_copy_kernel(const LzParDev* __restrict__ blocks) {
+  const LzParDev J = blocks[blockIdx.x];
+  __shared__ u8 ring_mem[kRing];
+  l_u8* const ring = (l_u8*)ring_mem;
+  g_u8* const out = (g_u8*)J.out;
+  g_cu8* const in = (g_cu8*)J.in;
+  const u32 lane = (u32)lane_id();
+  const u32 ntok = *J.ntok;
+  u64 op_base = 0; int status = ZPQ_OK;
+  for (u32 t0 = 0; t0 < ntok && status == ZPQ_OK; t0 += 64) {
+    const u32 cnt = ntok - t0 < 64 ? ntok - t0 : 64;
+    const bool valid = lane < cnt;
+    const u64 tk = valid ? J.tok[t0 + lane] : 0ull;
+    const u32 a = (u32)tk, x = (u32)(tk >> 32);
+    const bool is_err = valid && a == kTokErr;
+    const bool is_lit = !is_err && (a >> 31);
+    const u32 len = (valid && !is_err) ? (a & 0x7fffffffu) : 0u;
+    u64 incl = len;                                       // inclusive prefix sum of the lengths
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up((unsigned long long)incl, d); if (lane >= (u32)d) incl += y; }
+    const u64 pos64 = op_base + incl - len;
+    const bool bad_fmt = is_err || (valid && !is_lit && (x == 0 || (u64)x > pos64));
+    const bool bad_cap = valid && pos64 + len > (u64)J.out_cap;
+    const u64 errmask = __ballot(bad_fmt || bad_cap);
+    const u32 nproc = errmask ? (u32)__builtin_ctzll(errmask) : cnt;
+    if (errmask) {
+      const bool f = __builtin_amdgcn_readlane((u32)bad_fmt, nproc) != 0;
+      status = f ? ZPQ_ERR_FORMAT : ZPQ_ERR_CAPACITY;
+    }
+    const u32 pos = (u32)pos64;                           // lanes below nproc are within the capacity: 32 bits
+    const bool act = lane < nproc;
+    const u64 longmask = __ballot(act && len > kShort);
+    u32 cur = 0;
+    while (cur < nproc) {
+      const u64 lm = longmask & ~((1ull << cur) - 1ull);
+      const u32 L = lm ? (u32)__builtin_ctzll(lm) : nproc;
+      if (L > cur) {                                      // short tokens [cur, L)
+        const bool in_sw = act && lane >= cur && lane < L;
+        const u32 sw_start = __builtin_amdgcn_readlane(pos, cur);
+        const bool dep = in_sw && !is_lit && (pos - x + len > sw_start);
+        const bool far = in_sw && !is_lit && !dep && x > kRing - 4096u;
+        if (__ballot(far)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // far sources were stored by earlier steps
+        if (in_sw && !dep) {
+          if (is_lit) copy_lit_short(in, J.n, out, ring, x, len, pos);
+          else if (far) copy_far_short(out, ring, x, len, pos);
+          else copy_ring_short(out, ring, x, len, pos);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (u64 dm = __ballot(dep); dm; dm &= dm - 1) {
+          const u32 bl = (u32)__builtin_ctzll(dm);
+          if (lane == bl) copy_ring_short(out, ring, x, len, pos);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (L < nproc) {                                    // one long token, whole wave
+        const u32 tl = __builtin_amdgcn_readlane(len, L), tx = __builtin_amdgcn_readlane(x, L), op = __builtin_amdgcn_readlane(pos, L);
+        const bool lit = (__builtin_amdgcn_readlane(a, L) >> 31) != 0;
+        if (lit) {
+          const u32 byte0 = tx >> 3, sh = tx & 7;
+          for (u32 j = lane; j < tl; j += 64) {
+            const u32 two = (u32)in[byte0 + j] | (sh ? (u32)in[byte0 + j + 1] << 8 : 0u);
+            const u8 c = (u8)(two >> sh);
+            out[op + j] = c;
+            ring[(op + j) & (kRing - 1)] = c;
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          const u32 off = tx, src0 = op - off;
+          if (off + 64 <= kRing) {
+            for (u32 c0 = 0; c0 < tl; c0 += 64) {
+              const u32 j = c0 + lane;
+              u8 c = 0;
+              if (j < tl) c = ring[(off >= 64 ? op + j - off : src0 + (j % off)) & (kRing - 1)];
+              __builtin_amdgcn_wave_barrier();
+              if (j < tl) { out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
+              __builtin_amdgcn_wave_barrier();
+            }
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (u32 c0 = 0; c0 < tl; c0 += 32768u) {     // see lz77_decode_kernel: pieces that only read what is stored
+              const u32 pl = tl - c0 < 32768u ? tl - c0 : 32768u;
+              if (c0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              u32 j = lane;
+              for (; j + 192 < pl; j += 256) {
+                g_cu8* sp = (g_cu8*)out + src0 + c0 + j;
+                const u8 a0 = __builtin_nontemporal_load(sp), a1 = __builtin_nontemporal_load(sp + 64),
+                         a2 = __builtin_nontemporal_load(sp + 128), a3 = __builtin_nontemporal_load(sp + 192);
+                g_u8* dp = out + op + c0 + j;
+                dp[0] = a0; dp[64] = a1; dp[128] = a2; dp[192] = a3;
+                const u32 r0 = op + c0 + j;
+                ring[r0 & (kRing - 1)] = a0; ring[(r0 + 64) & (kRing - 1)] = a1; ring[(r0 + 128) & (kRing - 1)] = a2; ring[(r0 + 192) & (kRing - 1)] = a3;
+              }
+              for (; j < pl; j += 64) {
+                const u8 c = __builtin_nontemporal_load((g_cu8*)out + src0 + c0 + j);
+                out[op + c0 + j] = c;
+                ring[(op + c0 + j) & (kRing - 1)] = c;
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+      }
+      cur = L + 1;
+    }
+    if (nproc) op_base += (u64)__builtin_amdgcn_readlane((u32)incl, nproc - 1) | ((u64)__builtin_amdgcn_readlane((u32)(incl >> 32), nproc - 1) << 32);
+  }
+  if (lane == 0) { J.result[0] = (u32)op_base; J.result[1] = (u32)status; }
+}
+
 }  // namespace
 
-// Launch only (no host round trip): results land in d_res[2*i] = out_len, d_res[2*i+1] = status.
-int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs) {
-  ZPQ_LAUNCH(ctx, "lz77_decode_kernel", st, lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), d_jobs);
+// Launch only (no host round trip): results land in result[0] = out_len, result[1] = status of every job.  h_jobs is the
+// host copy of d_jobs (sizes for the scratch layout).
+int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* h_jobs, const zpq_lzdec_dev* d_jobs, size_t njobs) {
+  bool par = true;
+  if (const char* e = getenv("ZPQ_LZDEC_SERIAL")) par = atoi(e) == 0;
+  size_t nseg_total = 0, bytes = 0;
+  for (size_t i = 0; i < njobs && par; ++i) {
+    if (h_jobs[i].n >= (1u << 29)) par = false;          // bit positions are 32-bit in the token path
+    const size_t nseg = ((size_t)h_jobs[i].n * 8 + kSegBits - 1) / kSegBits + 1;
+    nseg_total += nseg;
+    bytes += (((size_t)h_jobs[i].n + 8 + 255) & ~(size_t)255) + nseg * 16 + 256 + (((size_t)h_jobs[i].n + 2) * 8 + 255 & ~(size_t)255);
+  }
+  u8* work = nullptr; u8* meta = nullptr;
+  if (par) {
+    work = (u8*)zpq_scratch(ctx, 25, bytes + 4096);
+    meta = (u8*)zpq_scratch(ctx, 26, njobs * (sizeof(LzParDev) + 16) + nseg_total * 4 + 4096);
+    if (!work || !meta) par = false;                       // not enough memory for the token lists: the one-wave decoder needs none
+  }
+  if (!par) {
+    ZPQ_LAUNCH(ctx, "lz77_decode_kernel", st, lz77_decode_kernel, dim3((unsigned)njobs), dim3(64), d_jobs);
+    ZPQ_HIP(ctx, hipGetLastError());
+    return ZPQ_OK;
+  }
+  std::vector<LzParDev> hb(njobs);
+  std::vector<u32> segblock(nseg_total);
+  LzParDev* d_blocks = (LzParDev*)meta;
+  u32* d_ntok = (u32*)(meta + ((njobs * sizeof(LzParDev) + 255) & ~(size_t)255));
+  u32* d_segblock = d_ntok + ((njobs + 63) & ~(size_t)63);
+  u8* p = work;
+  u32 seg0 = 0;
+  for (size_t i = 0; i < njobs; ++i) {
+    LzParDev& B = hb[i];
+    const zpq_lzdec_dev& z = h_jobs[i];
+    const size_t nseg = ((size_t)z.n * 8 + kSegBits - 1) / kSegBits + 1;
+    B.in = z.in; B.n = z.n; B.rb = z.rb; B.out = z.out; B.out_cap = z.out_cap; B.result = z.result;
+    B.nseg = (u32)nseg; B.seg0 = seg0;
+    const size_t vbytes = ((size_t)z.n + 8 + 255) & ~(size_t)255;
+    B.visit = (u32*)p; p += vbytes;
+    B.sexit = (u32*)p; B.entry = B.sexit + nseg; B.cnt = B.entry + nseg; B.dst = B.cnt + nseg; p += (nseg * 16 + 255) & ~(size_t)255;
+    B.tok = (u64*)p; p += (((size_t)z.n + 2) * 8 + 255) & ~(size_t)255;
+    B.ntok = d_ntok + i;
+    ZPQ_HIP(ctx, hipMemsetAsync(B.visit, 0, vbytes, st));
+    ZPQ_HIP(ctx, hipMemsetAsync(B.sexit, 0xff, nseg * 8, st));       // sexit = end, entry = none
+    for (size_t k = 0; k < nseg; ++k) segblock[seg0 + k] = (u32)i;
+    seg0 += (u32)nseg;
+  }
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_blocks, hb.data(), njobs * sizeof(LzParDev), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_segblock, segblock.data(), nseg_total * 4, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));                  // hb / segblock are stack-lifetime host buffers
+  const dim3 gs((unsigned)((nseg_total + 63) / 64)), blk(64);
+  ZPQ_LAUNCH(ctx, "lzdec_spec_kernel", st, lzdec_spec_kernel, gs, blk, d_blocks, d_segblock, (u32)nseg_total);
+  ZPQ_LAUNCH(ctx, "lzdec_stitch_kernel", st, lzdec_stitch_kernel, dim3((unsigned)njobs), blk, d_blocks);
+  ZPQ_LAUNCH(ctx, "lzdec_count_kernel", st, lzdec_count_kernel, gs, blk, d_blocks, d_segblock, (u32)nseg_total);
+  ZPQ_LAUNCH(ctx, "lzdec_scan_kernel", st, lzdec_scan_kernel, dim3((unsigned)njobs), dim3(1024), d_blocks);
+  ZPQ_LAUNCH(ctx, "lzdec_emit_kernel", st, lzdec_emit_kernel, gs, blk, d_blocks, d_segblock, (u32)nseg_total);
+  ZPQ_LAUNCH(ctx, "lz77_copy_kernel", st, lz77_copy_kernel, dim3((unsigned)njobs), blk, d_blocks);
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
@@ -218,7 +583,7 @@ extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, h.data(), njobs * sizeof(LzDecDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  int rc = zpq_lz77_decode_launch(ctx, st, d_jobs, njobs);
+  int rc = zpq_lz77_decode_launch(ctx, st, h.data(), d_jobs, njobs);
   if (rc) return rc;
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));

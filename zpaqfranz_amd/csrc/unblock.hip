@@ -325,7 +325,7 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   if (rc) return rc;
   if (!lzj.empty()) {
     ZPQ_HIP(ctx, hipMemcpyAsync(d_lzj, lzj.data(), lzj.size() * sizeof(zpq_lzdec_dev), hipMemcpyHostToDevice, st));
-    if ((rc = zpq_lz77_decode_launch(ctx, st, d_lzj, lzj.size()))) return rc;
+    if ((rc = zpq_lz77_decode_launch(ctx, st, lzj.data(), d_lzj, lzj.size()))) return rc;
   }
   if (!e8j.empty()) {
     zpq_e8inv_job* d_e8j = (zpq_e8inv_job*)d_e8meta;

@@ -105,8 +105,8 @@ struct zpq_lzjob_dev {
 int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
 // the jobs jobs[which[0..nj)] whose match finder is the suffix array (lz77_sa.hip)
 int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, size_t nj);
-// launches one wave per record on `st`; no host round trip
-int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* d_jobs, size_t njobs);
+// decodes every record on `st`; no host round trip for results (h_jobs = host copy of d_jobs, for the scratch layout)
+int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* h_jobs, const zpq_lzdec_dev* d_jobs, size_t njobs);
 // the 302-byte LZ77 level-1 post-processor program (rb = 0, no E8E9): golden, AUTOTEST/sha256.zpaq i blocks
 extern const u8 zpq_pcomp_lz1[302];
 // the level-1 post-processor programs decoded natively: rb = 0..7 raw offset bits, with / without the E8E9 inverse
