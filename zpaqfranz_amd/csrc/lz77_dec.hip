@@ -382,18 +382,64 @@ __global__ __launch_bounds__(64) void lzdec_emit_kernel(const LzParDev* __restri
 // nothing of it is written.
 constexpr u32 kShort = 32;
 
-__device__ __forceinline__ void copy_lit_short(g_cu8* in, u32 n, g_u8* out, l_u8* ring, u32 bit, u32 len, u32 op) {
-  for (u32 j = 0; j < len; j += 8) {
-    u64 w = peek_g(in, n, bit + 8 * j);
-    const u32 m = len - j < 8 ? len - j : 8;
-    for (u32 i = 0; i < m; ++i) { const u8 c = (u8)w; w >>= 8; out[op + j + i] = c; ring[(op + j + i) & (kRing - 1)] = c; }
+// up to 32 source bytes into registers -- every load is issued before the first one is waited for -- then out and ring
+struct Bytes32 { u64 v[4]; };
+typedef __attribute__((address_space(1))) u64_u g_u64_u;
+__device__ __forceinline__ Bytes32 gather_lit(g_cu8* in, u32 n, u32 bit, u32 len) {
+  Bytes32 r;
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) r.v[k] = 8 * k < len ? peek_g(in, n, bit + 64 * k) : 0ull;
+  return r;
+}
+__device__ __forceinline__ Bytes32 gather_far(g_cu8* src, u32 len) {      // src .. src+len is at least 60 KiB behind the write frontier:
+  Bytes32 r;                                                               // the up to 7 bytes read past src+len are inside the buffer too
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) r.v[k] = 8 * k < len ? __builtin_nontemporal_load((g_cu64_u*)(src + 8 * k)) : 0ull;
+  return r;
+}
+// The ring is accessed 8 / 4 / 2 / 1 bytes at a time at any byte address (gfx950 has unaligned LDS access: one ds_read_b64 /
+// ds_write_b64 each); only an access that would run over the end of the ring goes byte by byte.
+typedef __attribute__((address_space(3))) u64_u l_u64_u;
+typedef __attribute__((address_space(3))) u32_u l_u32_u;
+typedef u16 __attribute__((aligned(1))) u16_u;
+typedef __attribute__((address_space(3))) u16_u l_u16_u;
+typedef __attribute__((address_space(1))) u32_u g_u32_u;
+typedef __attribute__((address_space(1))) u16_u g_u16_u;
+__device__ __forceinline__ u64 ring_read8(l_u8* ring, u32 at) {
+  const u32 i = at & (kRing - 1);
+  if (i <= kRing - 8) return *(l_u64_u*)(ring + i);
+  u64 w = 0;
+  for (u32 k = 0; k < 8; ++k) w |= (u64)ring[(i + k) & (kRing - 1)] << (8 * k);
+  return w;
+}
+__device__ __forceinline__ Bytes32 gather_ring(l_u8* ring, u32 src, u32 len) {
+  Bytes32 r;
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) r.v[k] = 8 * k < len ? ring_read8(ring, src + 8 * k) : 0ull;    // (bytes past len are read and ignored)
+  return r;
+}
+// m (1..8) bytes of w to out[pos..] and to the ring
+__device__ __forceinline__ void put_bytes(g_u8* out, l_u8* ring, u32 pos, u64 w, u32 m) {
+  const u32 i = pos & (kRing - 1);
+  if (i > kRing - 8) {                                    // over the end of the ring: byte by byte (1 in 8192)
+    for (u32 k = 0; k < m; ++k) { const u8 c = (u8)(w >> (8 * k)); out[pos + k] = c; ring[(i + k) & (kRing - 1)] = c; }
+    return;
+  }
+  if (m == 8) { *(g_u64_u*)(out + pos) = w; *(l_u64_u*)(ring + i) = w; return; }
+  u32 o = 0;
+  if (m & 4) { *(g_u32_u*)(out + pos) = (u32)w; *(l_u32_u*)(ring + i) = (u32)w; o = 4; w >>= 32; }
+  if (m & 2) { *(g_u16_u*)(out + pos + o) = (u16)w; *(l_u16_u*)(ring + i + o) = (u16)w; o += 2; w >>= 16; }
+  if (m & 1) { out[pos + o] = (u8)w; ring[i + o] = (u8)w; }
+}
+__device__ __forceinline__ void scatter(g_u8* out, l_u8* ring, u32 pos, u32 len, const Bytes32& r) {
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) {
+    if (8 * k >= len) break;
+    put_bytes(out, ring, pos + 8 * k, r.v[k], len - 8 * k < 8 ? len - 8 * k : 8);
   }
 }
-__device__ __forceinline__ void copy_ring_short(g_u8* out, l_u8* ring, u32 off, u32 len, u32 op) {
+__device__ __forceinline__ void copy_ring_bytewise(g_u8* out, l_u8* ring, u32 off, u32 len, u32 op) {     // self-overlapping: in order
   for (u32 j = 0; j < len; ++j) { const u8 c = ring[(op + j - off) & (kRing - 1)]; out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
-}
-__device__ __forceinline__ void copy_far_short(g_u8* out, l_u8* ring, u32 off, u32 len, u32 op) {
-  for (u32 j = 0; j < len; ++j) { const u8 c = __builtin_nontemporal_load((g_cu8*)out + op + j - off); out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
 }
 
 __global__ __launch_bounds__(64) void lz77_copy_kernel(const LzParDev* __restrict__ blocks) {
@@ -405,17 +451,52 @@ __global__ __launch_bounds__(64) void lz77_copy_kernel(const LzParDev* __restric
   const u32 lane = (u32)lane_id();
   const u32 ntok = *J.ntok;
   u64 op_base = 0; int status = ZPQ_OK;
+  // Software pipeline.  A step would otherwise open with dependent memory round trips (tokens -> stream bytes of the
+  // literals / far match sources).  Tokens are loaded two steps ahead; one step ahead their lengths are scanned into
+  // output positions and every short token's source that is not in the LDS ring is fetched into registers: stream
+  // bytes for literals, HBM bytes for matches reaching further back than the ring -- provided that source was complete
+  // when the CURRENT step began (it lies before this step's output), which the drain at the top of each step makes true.
+  auto load_tok = [&](u32 t) -> u64 { return t + lane < ntok ? J.tok[t + lane] : 0ull; };
+  struct Step { u64 tk; u64 incl; Bytes32 pre; bool have; };      // `have`: pre holds this lane's source bytes
+  auto scan_len = [&](u64 tkn, bool valid_) -> u64 {
+    const u32 a_ = (u32)tkn;
+    u64 incl_ = (valid_ && a_ != kTokErr) ? (a_ & 0x7fffffffu) : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up((unsigned long long)incl_, d); if (lane >= (u32)d) incl_ += y; }
+    return incl_;
+  };
+  // sources of the step whose tokens are tkn, given where its output starts and what is known to be stored (< done)
+  auto prefetch = [&](u64 tkn, u64 incl_, u64 base, u64 done, bool valid_, Bytes32& pre, bool& have) {
+    const u32 a_ = (u32)tkn, x_ = (u32)(tkn >> 32), l_ = a_ & 0x7fffffffu;
+    pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = 0; have = false;
+    if (!valid_ || a_ == kTokErr || l_ == 0 || l_ > kShort) return;
+    const u64 p_ = base + incl_ - l_;
+    if (a_ >> 31) { pre = gather_lit(in, J.n, x_, l_); have = true; return; }
+    if (x_ > kRing - 4096u && (u64)x_ <= p_ && p_ - x_ + l_ <= done && p_ + l_ <= (u64)J.out_cap) {
+      pre = gather_far((g_cu8*)out + (p_ - x_), l_); have = true;
+    }
+  };
+  Step A, B;
+  A.tk = load_tok(0); B.tk = load_tok(64);
+  A.incl = scan_len(A.tk, lane < ntok);
+  prefetch(A.tk, A.incl, 0, 0, lane < ntok, A.pre, A.have);
   for (u32 t0 = 0; t0 < ntok && status == ZPQ_OK; t0 += 64) {
     const u32 cnt = ntok - t0 < 64 ? ntok - t0 : 64;
     const bool valid = lane < cnt;
-    const u64 tk = valid ? J.tok[t0 + lane] : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // everything earlier steps stored is in memory (and what they prefetched has arrived)
+    const u64 tkC = load_tok(t0 + 128);                   // two steps ahead
+    const u64 totalA = (u64)__builtin_amdgcn_readlane((u32)A.incl, 63) | ((u64)__builtin_amdgcn_readlane((u32)(A.incl >> 32), 63) << 32);
+    const bool validB = t0 + 64 + lane < ntok;
+    B.incl = scan_len(B.tk, validB);
+    prefetch(B.tk, B.incl, op_base + totalA, op_base, validB, B.pre, B.have);    // (if this step ends early nothing of B is used)
+    const u64 tk = A.tk, incl = A.incl;
+    const Bytes32 pre = A.pre;
+    const bool have = A.have;
+    A = B; B.tk = tkC;
     const u32 a = (u32)tk, x = (u32)(tk >> 32);
     const bool is_err = valid && a == kTokErr;
     const bool is_lit = !is_err && (a >> 31);
     const u32 len = (valid && !is_err) ? (a & 0x7fffffffu) : 0u;
-    u64 incl = len;                                       // inclusive prefix sum of the lengths
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u64 y = __shfl_up((unsigned long long)incl, d); if (lane >= (u32)d) incl += y; }
     const u64 pos64 = op_base + incl - len;
     const bool bad_fmt = is_err || (valid && !is_lit && (x == 0 || (u64)x > pos64));
     const bool bad_cap = valid && pos64 + len > (u64)J.out_cap;
@@ -433,21 +514,26 @@ __global__ __launch_bounds__(64) void lz77_copy_kernel(const LzParDev* __restric
       const u64 lm = longmask & ~((1ull << cur) - 1ull);
       const u32 L = lm ? (u32)__builtin_ctzll(lm) : nproc;
       if (L > cur) {                                      // short tokens [cur, L)
-        const bool in_sw = act && lane >= cur && lane < L;
-        const u32 sw_start = __builtin_amdgcn_readlane(pos, cur);
-        const bool dep = in_sw && !is_lit && (pos - x + len > sw_start);
-        const bool far = in_sw && !is_lit && !dep && x > kRing - 4096u;
-        if (__ballot(far)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // far sources were stored by earlier steps
-        if (in_sw && !dep) {
-          if (is_lit) copy_lit_short(in, J.n, out, ring, x, len, pos);
-          else if (far) copy_far_short(out, ring, x, len, pos);
-          else copy_ring_short(out, ring, x, len, pos);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (u64 dm = __ballot(dep); dm; dm &= dm - 1) {
-          const u32 bl = (u32)__builtin_ctzll(dm);
-          if (lane == bl) copy_ring_short(out, ring, x, len, pos);
+        // rounds: a token is ready when it is a literal, when its source ends before the output of the first token
+        // still pending, or when it is that first token itself (only then may it read its own output)
+        u64 pend = __ballot(act && lane >= cur && lane < L);
+        while (pend) {
+          const u32 f = (u32)__builtin_ctzll(pend);
+          const u32 pos_f = __builtin_amdgcn_readlane(pos, f);
+          const bool mine = (pend >> lane) & 1ull;
+          const u32 src = pos - x;                          // (matches only)
+          const bool ready = mine && (is_lit || lane == f || src + len <= pos_f);
+          const bool far = ready && !is_lit && x > kRing - 4096u;
+          if (__ballot(far && !have)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (rare: a source inside this or the previous step's long token)
+          if (ready) {
+            if (have) scatter(out, ring, pos, len, pre);           // literal bytes / far source, fetched a step ago
+            else if (is_lit) scatter(out, ring, pos, len, gather_lit(in, J.n, x, len));
+            else if (x < len) copy_ring_bytewise(out, ring, x, len, pos);
+            else if (far) scatter(out, ring, pos, len, gather_far((g_cu8*)out + src, len));
+            else scatter(out, ring, pos, len, gather_ring(ring, src, len));
+          }
           __builtin_amdgcn_wave_barrier();
+          pend &= ~__ballot(ready);
         }
       }
       if (L < nproc) {                                    // one long token, whole wave

@@ -307,12 +307,18 @@ __device__ __forceinline__ void sha256_rounds_lane(const u32 (&wk)[64], int blk,
   s[6] += __builtin_amdgcn_readlane(g, blk); s[7] += __builtin_amdgcn_readlane(h, blk);
 }
 
-// persistent waves: wave w takes the extents w, w + waves, ... whose length is at least `min_len`
-__global__ __launch_bounds__(64) void sha256_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
-                                                          const u64* __restrict__ len, u32 n, u64 min_len,
-                                                          u8* __restrict__ digests, const u32* __restrict__ list) {
+// persistent waves: wave w takes the extents w, w + waves, ... whose length is at least `min_len`.  Workgroups of four
+// waves: a workgroup then owns the four SIMDs of a compute unit, and the chains leave WHOLE compute units to whatever
+// else runs beside them (the lane-wise kernel) instead of one SIMD here and there.
+__global__ __launch_bounds__(256) void sha256_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                           const u64* __restrict__ len, u32 n, u64 min_len,
+                                                           u8* __restrict__ digests, const u32* __restrict__ list, u32* __restrict__ queue) {
   const int lane = lane_id();
-  for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+  const u32 waves = gridDim.x * 4u;
+  // with a queue the waves take the (longest-first) list entries as they get free; without, in strides
+  for (u32 k = blockIdx.x * 4u + (threadIdx.x >> 6);; k += waves) {
+    if (queue) { u32 q = 0; if (lane == 0) q = atomicAdd(queue, 1u); k = __builtin_amdgcn_readfirstlane(q); }
+    if (k >= n) break;
     const u32 idx = list ? list[k] : k;
     const u64 total = len[idx];
     if (total < min_len) continue;
@@ -501,7 +507,7 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   if (!counter) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
   counter += 32;
   hipStream_t st = ctx->stream;
-  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, st));
+  ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 8, st));
   // A chain is one wave's worth of dependent instructions whichever way it is laid out (about 4.3 cycles each):
   //   one LANE per extent: 64 extents share a wave's instructions (schedule + rounds, ~1380 per 64-byte block);
   //   one WAVE per extent: the schedule moves off the chain (~950 per block: 1.45x faster), 63 lanes idle.
@@ -519,8 +525,25 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
     std::vector<u32> ord(n);
     for (size_t i = 0; i < n; ++i) ord[i] = (u32)i;
     std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return hl[a] > hl[b]; });
+    // How many of the longest extents get a wave: one persistent wave per SIMD takes chains off a longest-first queue
+    // (36 MB/s each), the rest goes lane-wise (11 MB/s per lane, 64 lanes per wave: 20x the throughput per SIMD, a
+    // third of the speed per extent).  K minimises the later of the two finishes:
+    //   chains: max(longest / 36, bytes of the K longest / (SIMDs x 36));  lanes: extent K / 11.
     size_t kc = 0;
-    while (kc < n && kc < max_chains && hl[ord[kc]] >= chain_min) ++kc;
+    if (!getenv("ZPQ_SHA256_CHAIN_MIN") && !getenv("ZPQ_SHA256_CHAINS")) {
+      const double rw = 36e6, rl = 11e6, simds = (double)ctx->cu_count * 4;
+      double best = 1e300, sum = 0;
+      for (size_t k = 0; k <= n; ++k) {
+        if (k && hl[ord[k - 1]] < chain_min) break;       // short extents never get a wave
+        const double tc = k ? std::max((double)hl[ord[0]] / rw, sum / (simds * rw)) : 0.0;
+        const double tl = k < n ? (double)hl[ord[k]] / (k >= (size_t)simds ? rl / 2 : rl) : 0.0;   // lanes beside a chain on every SIMD get half the issue slots
+        const double t = std::max(tc, tl);
+        if (t < best * 0.98) { best = t; kc = k; }        // (a later K must be clearly better: lanes are the cheaper way)
+        if (k < n) sum += (double)hl[ord[k]];
+      }
+    } else {
+      while (kc < n && kc < max_chains && hl[ord[kc]] >= chain_min) ++kc;
+    }
     u32* d_ord = (u32*)zpq_scratch(ctx, 8, n * 4 + 256);
     if (!d_ord) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
     ZPQ_HIP(ctx, hipMemcpyAsync(d_ord, ord.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -528,8 +551,9 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
     if (kc) {
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
       ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
-      ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream2, sha256_chain_kernel, dim3((unsigned)kc), dim3(64), d_base, d_off, d_len, (u32)kc, (u64)0,
-                 d_digests, (const u32*)d_ord);
+      const size_t cw = std::min(kc, max_chains);         // persistent waves, one per SIMD at most
+      ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream2, sha256_chain_kernel, dim3((unsigned)((cw + 3) / 4)), dim3(256), d_base, d_off, d_len, (u32)kc, (u64)0,
+                 d_digests, (const u32*)d_ord, counter + 1);
       ZPQ_HIP(ctx, hipGetLastError());
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
     }
@@ -550,8 +574,8 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   ZPQ_HIP(ctx, hipGetLastError());
   {
     const unsigned waves = (unsigned)std::min<size_t>(n, max_chains);
-    ZPQ_LAUNCH(ctx, "sha256_chain_kernel", st, sha256_chain_kernel, dim3(waves), dim3(64), d_base, d_off, d_len, (u32)n, chain_min,
-               d_digests, (const u32*)nullptr);
+    ZPQ_LAUNCH(ctx, "sha256_chain_kernel", st, sha256_chain_kernel, dim3((waves + 3) / 4), dim3(256), d_base, d_off, d_len, (u32)n, chain_min,
+               d_digests, (const u32*)nullptr, (u32*)nullptr);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   return ZPQ_OK;
