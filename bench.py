@@ -802,11 +802,11 @@ def main():
     steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
-    # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6
+    # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6: six by default
     # (multi-rank runs keep three: every step in flight adds three collective sections to the fixed order, and that depth
     # is the one exercised over RCCL)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 5, "dup8_m1": 1, "extract_m1": 1}[a.workload])
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 1}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)

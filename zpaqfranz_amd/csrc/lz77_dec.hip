@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
 // The wave above spends ~250 scalar instructions per token on PARSING; the copies are cheap.  The parse state between
 // two tokens is one number (the bit position), so a parse started at any bit merges with the true one at their first
 // common token start and follows it from there -- and on real streams a garbage parse lands on a true token start
-// within a few dozen tokens.  Lanes parse 1 KiB segments of the code stream from 256 bytes before their segment
+// within a few dozen tokens.  Lanes parse 4 KiB segments of the code stream from 256 bytes before their segment
 // (lzdec_spec_kernel: marks the token starts it visits inside its segment, records where it leaves), one lane per block
 // follows the true chain through those marks (lzdec_stitch_kernel: first true token start of every segment), the lanes
 // then parse their segment again from that start and write the token list (count, scan, emit), and one wave per block
@@ -214,7 +214,7 @@ struct LzParDev {
   u32* sexit; u32* entry; u32* cnt; u32* dst;  // per segment
   u64* tok; u32* ntok;                         // token list (len | kind << 31, offset or literal bit position)
 };
-constexpr u32 kSegBits = 8192, kWarmBits = 2048;
+constexpr u32 kSegBits = 32768, kWarmBits = 2048;   // 4 KiB segments (the stitcher pays per segment), 256 bytes of run-up
 constexpr u32 kEnd = 0xffffffffu, kDead = 0xfffffffeu, kNone = 0xffffffffu;
 constexpr u32 kTokErr = 0xffffffffu;
 
