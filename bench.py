@@ -672,9 +672,10 @@ def main_text_m2(a, rank, world, local, dev):
             kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
         e_.profile(False)
     if world > 1:
-        tt = torch.tensor([dt, float(out_bytes)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX); dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
-        dt = float(tt[0].item()); out_bytes = int(tt[1].item())
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
+        tsum = torch.tensor([float(out_bytes)], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax.item()); out_bytes = int(tsum.item())
     if rank == 0:
         sec = dt / steps
         # algorithmic bytes per step (SURVEY 8d has no figure for the suffix sort; the floor of any construction is the
@@ -903,7 +904,7 @@ def main():
             kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
         e_.profile(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:

@@ -146,3 +146,19 @@ def test_jidac_add_with_method_2(eng):
     if orc.have_ref():
         out = orc.ref_decompress(arc, 64 << 20)                # c, d, h, i blocks concatenated by libzpaq::decompress
         assert files[0][1] in out and files[1][1] in out          # the new fragments of a file sit in the d block in order
+
+
+def test_text_m2_two_ranks(tmp_path):
+    """bench.py --workload text_m2 under torch.distributed.run with two ranks (gloo through the host, both on GPU 0):
+    blocks are independent, every rank compresses its own text, rank 0 reports the sum."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "text_m2", "--text-bytes", "5000000",
+           "--steps", "1", "--warmup", "0", "--dist-backend", "gloo", "--same-device", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["input_bytes"] == 10000000 and d["scaling"] == "weak"
+    assert 0.2 < d["config"]["ratio"] < 0.7 and d["value"] > 0

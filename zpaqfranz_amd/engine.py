@@ -518,11 +518,14 @@ def load_shim():
                                      C.c_int64, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_extract.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        S.zpqj_verify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        S.zpqj_add_opts.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         _shim = S
     return _shim
 
 
-def jidac_add(eng, archive, files, version_date, method="14", dates=None):
+def jidac_add(eng, archive, files, version_date, method="14", dates=None, checksums=False):
     """files: list of (name, bytes).  Returns (bytes to append to the archive, stats dict).  `eng` may be a list of
     engines (one per GPU): the files are then sharded across them (zpqj_add_multi), with identical output."""
     S = load_shim()
@@ -537,7 +540,12 @@ def jidac_add(eng, archive, files, version_date, method="14", dates=None):
     dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
     out, out_len = C.c_void_p(), C.c_size_t(0)
     stats = (C.c_uint64 * 6)()
-    if engs:
+    if checksums:
+        es = engs or [eng]
+        ctxs = (C.c_void_p * len(es))(*[e.ctx.value for e in es])
+        rc = S.zpqj_add_opts(ctxs, len(es), bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
+                             version_date, method.encode(), 1, C.byref(out), C.byref(out_len), stats)
+    elif engs:
         ctxs = (C.c_void_p * len(engs))(*[e.ctx.value for e in engs])
         rc = S.zpqj_add_multi(ctxs, len(engs), bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
                               version_date, method.encode(), C.byref(out), C.byref(out_len), stats)
@@ -550,6 +558,15 @@ def jidac_add(eng, archive, files, version_date, method="14", dates=None):
     S.zpqj_free(out)
     keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
     return data, dict(zip(keys, [int(x) for x in stats]))
+
+
+def jidac_verify(eng, archive):
+    """zpaqfranz t: (status, stats dict).  status 0 = every block, fragment and stored file checksum verified."""
+    S = load_shim()
+    st = (C.c_uint64 * 7)()
+    rc = S.zpqj_verify(eng.ctx, bytes(archive), len(archive), st)
+    keys = ("files", "fragments", "bytes", "files_with_checksums", "xxh64_mismatches", "crc32_mismatches", "d_blocks")
+    return rc, dict(zip(keys, [int(x) for x in st]))
 
 
 def jidac_extract(eng, archive):

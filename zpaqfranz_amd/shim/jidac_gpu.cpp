@@ -24,7 +24,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "zpaqhip.h"
+#include "jidac_gpu.h"
 
 namespace {
 
@@ -222,12 +222,13 @@ struct Shard {
   void* d_data = nullptr;
   std::vector<void*> dev;                 // everything to free
   std::vector<uint64_t> foff; std::vector<uint32_t> flen, ffile; Bytes dig;
+  std::vector<uint32_t> crc; std::vector<uint64_t> xxh;      // per file, when asked for
   size_t nf = 0;
   int rc = ZPQ_OK;
   ~Shard() { for (void* q : dev) if (q) zpq_dev_free(ctx, q); }
 };
 
-int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes, const std::vector<size_t>& order) {
+int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes, const std::vector<size_t>& order, bool checksums) {
   zpq_ctx* ctx = S.ctx;
   const size_t nfiles = S.f1 - S.f0;
   S.off.assign(nfiles + 1, 0);
@@ -251,6 +252,10 @@ int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes,
   if (nfiles && (rc = zpq_fragment_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
                                        (uint32_t*)d_ffile, cap, &nf))) return rc;
   if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)S.d_data, (const uint64_t*)d_foff, (const uint32_t*)d_flen, nf, (uint8_t*)d_dig))) return rc;
+  if (checksums && nfiles) {       // zpaqfranz stores XXHASH64 + CRC-32 of every file in its i-block attribute: same pass over HBM
+    S.crc.resize(nfiles); S.xxh.resize(nfiles);
+    if ((rc = zpq_file_checksums_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, S.crc.data(), S.xxh.data(), nullptr))) return rc;
+  }
   S.nf = nf;
   S.foff.resize(nf); S.flen.resize(nf); S.ffile.resize(nf); S.dig.resize(nf * 20);
   if (nf) {
@@ -262,9 +267,10 @@ int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes,
 
 int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
              const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
-             uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+             uint8_t** out, size_t* out_len, uint64_t stats[6], uint32_t flags = 0) {
   *out = nullptr; *out_len = 0;
   if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
+  const bool checksums = (flags & ZPQJ_FILE_CHECKSUMS) != 0;
   zpq_ctx* ctx = ctxs[0];
   Index ix;
   if (archive && archive_len) { int rc = read_index(ctx, archive, archive_len, ix); if (rc) return rc; }
@@ -289,7 +295,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order); });
+    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
   }
@@ -427,7 +433,20 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     put64(tmp, (uint64_t)dates[order[k]]);
     const char* nmz = names[order[k]];
     tmp.insert(tmp.end(), nmz, nmz + strlen(nmz) + 1);
-    put32(tmp, 3); tmp.push_back('u'); tmp.push_back(0xa4); tmp.push_back(0x81);     // unix mode 0100644
+    if (checksums) {
+      // the attribute as zpaqfranz writes it in the fixture's i blocks: 58 bytes, attribute tag and value
+      // in the first 8, XXHASH64 as 16 hex digits at [16,32), CRC-32 as 8 hex digits at [49,57)
+      size_t r = 0; while (r + 1 < nctx && k >= sh[r].f1) ++r;
+      char a[58]; memset(a, 0, sizeof a);
+      a[0] = 'u'; a[1] = (char)0xa4; a[2] = (char)0x81;                              // unix mode 0100644
+      snprintf(a + 16, 17, "%016llX", (unsigned long long)sh[r].xxh[k - sh[r].f0]);
+      char c8[9]; snprintf(c8, sizeof c8, "%08X", (unsigned)sh[r].crc[k - sh[r].f0]);
+      memcpy(a + 49, c8, 8);
+      a[32] = 0;
+      put32(tmp, 58); tmp.insert(tmp.end(), a, a + 58);
+    } else {
+      put32(tmp, 3); tmp.push_back('u'); tmp.push_back(0xa4); tmp.push_back(0x81);   // unix mode 0100644
+    }
     std::vector<uint32_t> ptr;
     while (fi < nf && ffile[fi] == k) ptr.push_back(id[fi++]);
     put32(tmp, (uint32_t)ptr.size());
@@ -452,8 +471,32 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
 // Jidac::extract (ZSFX/zsfx.cpp:2018-2281 + decompressThread :1731-1994) with the archive's d blocks staged in HBM:
 // one zpq_decompress_blocks_dev over all of them, every fragment's SHA-1 compared with the h table on the device,
 // the files assembled by one gather, one copy back.
+// zpaqfranz's i-block attribute extension as the fixture archives carry it (8 bytes of zpaq attribute,
+// then 50 bytes holding the file's XXHASH64 as 16 hex digits at [16,32) and its CRC-32 as 8 hex digits at [49,57)).
+// Returns false when the attribute has another shape (then there is nothing stored to compare with).
+bool stored_checksums(const std::string& attr, uint64_t* xxh, uint32_t* crc) {
+  if (attr.size() != 58) return false;
+  auto hex = [&](size_t at, size_t n, uint64_t* v) {
+    uint64_t r = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const unsigned char c = (unsigned char)attr[at + i];
+      int d = c >= '0' && c <= '9' ? c - '0' : c >= 'A' && c <= 'F' ? c - 'A' + 10 : c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1;
+      if (d < 0) return false;
+      r = r << 4 | (uint64_t)d;
+    }
+    *v = r; return true;
+  };
+  uint64_t c = 0;
+  if (!hex(16, 16, xxh) || !hex(49, 8, &c)) return false;
+  *crc = (uint32_t)c;
+  return true;
+}
+
+// verify != nullptr: nothing is returned to the host; the files are assembled in HBM and their stored XXHASH64 / CRC-32
+// (when the attributes carry them) recomputed there.  verify[0..6] = files, fragments checked, bytes restored, files
+// with stored checksums, XXHASH64 mismatches, CRC-32 mismatches, d blocks.
 int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes, char** names,
-                 size_t* nfiles) {
+                 size_t* nfiles, uint64_t* verify = nullptr) {
   Index ix;
   int rc = read_index(ctx, archive, archive_len, ix);
   if (rc) return rc;
@@ -516,9 +559,11 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
   // files: every pointer becomes one copy extent into the blob
   std::vector<uint64_t> so, dso; std::vector<uint32_t> sl;
   std::vector<uint64_t> sz; std::string nm;
+  std::vector<const FileRec*> recs;
   uint64_t blob_len = 0;
   for (auto& kv : ix.files) {
     if (!kv.second.date) continue;
+    recs.push_back(&kv.second);
     uint64_t len = 0;
     for (uint32_t q : kv.second.ptr) {
       if (q == 0 || q >= ix.ht.size() || where[q] == ~(uint64_t)0) return ZPQ_ERR_FORMAT;
@@ -528,21 +573,42 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     blob_len += len;
     sz.push_back(len); nm += kv.first; nm.push_back('\0');
   }
-  *data = (uint8_t*)malloc(blob_len ? blob_len : 1);
-  *sizes = (uint64_t*)malloc((sz.size() ? sz.size() : 1) * 8);
-  *names = (char*)malloc(nm.size() ? nm.size() : 1);
-  if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
+  if (verify) {
+    verify[0] = sz.size(); verify[1] = voff.size(); verify[2] = blob_len; verify[3] = verify[4] = verify[5] = 0; verify[6] = nb;
+  } else {
+    *data = (uint8_t*)malloc(blob_len ? blob_len : 1);
+    *sizes = (uint64_t*)malloc((sz.size() ? sz.size() : 1) * 8);
+    *names = (char*)malloc(nm.size() ? nm.size() : 1);
+    if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
+  }
+  void* d_blob = nullptr;
+  if ((rc = zpq_dev_alloc(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
   if (!so.empty()) {
-    void *d_so, *d_sl, *d_dso, *d_blob;
+    void *d_so, *d_sl, *d_dso;
     if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
     if ((rc = zpq_dev_alloc(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
     if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
-    if ((rc = zpq_dev_alloc(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
     if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
         (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
     if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blob))) return rc;
-    if (blob_len && (rc = zpq_d2h(ctx, *data, d_blob, blob_len))) return rc;
+    if (!verify && blob_len && (rc = zpq_d2h(ctx, *data, d_blob, blob_len))) return rc;
   }
+  if (verify && !sz.empty()) {
+    // the `t` command: per-file XXHASH64 + CRC-32 of the assembled bytes against what the i blocks store
+    std::vector<uint64_t> foff(sz.size() + 1, 0);
+    for (size_t i = 0; i < sz.size(); ++i) foff[i + 1] = foff[i] + sz[i];
+    std::vector<uint32_t> crc(sz.size()); std::vector<uint64_t> xx(sz.size());
+    if ((rc = zpq_file_checksums_dev(ctx, (const uint8_t*)d_blob, foff.data(), sz.size(), crc.data(), xx.data(), nullptr))) return rc;
+    for (size_t i = 0; i < sz.size(); ++i) {
+      uint64_t wx = 0; uint32_t wc = 0;
+      if (!stored_checksums(recs[i]->attr, &wx, &wc)) continue;
+      ++verify[3];
+      if (wx != xx[i]) ++verify[4];
+      if (wc != crc[i]) ++verify[5];
+    }
+    if (verify[4] || verify[5]) return ZPQ_ERR_CHECKSUM;
+  }
+  if (verify) return ZPQ_OK;
   memcpy(*sizes, sz.data(), sz.size() * 8); memcpy(*names, nm.data(), nm.size());
   *nfiles = sz.size();
   return ZPQ_OK;
@@ -572,6 +638,14 @@ int zpqj_add(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const cha
   return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats); });
 }
 
+// zpqj_add_multi with options: ZPQJ_FILE_CHECKSUMS stores every file's XXHASH64 + CRC-32 (computed on the device in
+// the pass that fragments the files) in its i-block attribute, as zpaqfranz does by default; zpqj_verify checks them.
+int zpqj_add_opts(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
+                  const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date,
+                  const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  return guarded([&] { return add_impl(ctxs, nctx, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats, flags); });
+}
+
 // The same over several GPUs of one node (one context each): the files are sharded across them, the archive
 // bytes are identical to the single-GPU result whatever nctx is.
 int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
@@ -589,6 +663,16 @@ int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
   const int rc = guarded([&] { return extract_impl(ctx, archive, archive_len, data, sizes, names, nfiles); });
   if (rc) { free(*data); free(*sizes); free(*names); *data = nullptr; *sizes = nullptr; *names = nullptr; *nfiles = 0; }
   return rc;
+}
+
+// The `t` (test) command: everything zpqj_extract does except handing the files to the host -- every d block decoded with
+// its stored SHA-1, every fragment's SHA-1 against the h table, the files assembled in HBM -- plus, where the i blocks
+// carry zpaqfranz's per-file XXHASH64 / CRC-32 attribute, those recomputed on the device and compared.
+// stats[0..6] = files, fragments checked, bytes restored, files with stored checksums, XXHASH64 mismatches, CRC-32
+// mismatches, d blocks.  ZPQ_ERR_CHECKSUM if anything differs.
+int zpqj_verify(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint64_t stats[7]) {
+  for (int i = 0; i < 7; ++i) stats[i] = 0;
+  return guarded([&] { return extract_impl(ctx, archive, archive_len, nullptr, nullptr, nullptr, nullptr, stats); });
 }
 
 }  // extern "C"
