@@ -816,6 +816,7 @@ def main():
         layout = dup8_layout(dev, corpus, a.units, a.dup, rank)
     else:
         layout = silesia_layout(dev, corpus, a.copies)
+    torch.cuda.empty_cache()       # what the generators left in torch's cache is HBM the engine cannot see (its LZ77 batches are sized by free memory)
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
     engines, pipes = [], []

@@ -26,16 +26,19 @@ def short(name):
     return name.split("(")[0]
 
 
-def main(root, tag):
+def main(root, tag, work=""):
+    """work = "" for the default workload (directories prof_stats/fetch/write, files <tag>_rocprof_summary.txt and
+    traffic.json); otherwise a label: directories prof_stats_<work>..., file <tag>_rocprof_summary_<work>.txt"""
     out = []
-    cur = q(os.path.join(root, "prof_stats"))
+    sfx = "_" + work if work else ""
+    cur = q(os.path.join(root, "prof_stats" + sfx))
     if cur:
-        out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1   (%s)\n" % tag)
+        out.append("# rocprofv3 --kernel-trace --stats -- python bench.py %s  (%s)\n" % ("--workload " + work if work else "--steps 3 --warmup 1", tag))
         out.append("%-34s %6s %14s %14s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
         for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             out.append("%-34s %6d %14.1f %14.1f %7.2f" % (short(name)[:34], calls, total / 1e3, avg / 1e3, pct))
         out.append("")
-    for sub, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
+    for sub, ctr in (("prof_fetch" + sfx, "FETCH_SIZE"), ("prof_write" + sfx, "WRITE_SIZE")):
         cur = q(os.path.join(root, sub))
         if not cur:
             continue
@@ -47,7 +50,7 @@ def main(root, tag):
         out.append("")
     # bytes per launch for bench.py's roofline.traffic: FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE
     per = {}
-    for sub, ctr, mul in (("prof_fetch", "FETCH_SIZE", 2.0), ("prof_write", "WRITE_SIZE", 1.0)):
+    for sub, ctr, mul in (("prof_fetch" + sfx, "FETCH_SIZE", 2.0), ("prof_write" + sfx, "WRITE_SIZE", 1.0)):
         cur = q(os.path.join(root, sub))
         if not cur:
             continue
@@ -60,11 +63,11 @@ def main(root, tag):
         json.dump({"source": "profiles/%s_rocprof_summary.txt: per launch, FETCH_SIZE*2 (gfx950 correction, calibrated on the copyBuffer "
                              "dispatches of the same run) + WRITE_SIZE" % tag,
                    "bytes_per_launch": dict(sorted(per.items(), key=lambda kv: -kv[1]))},
-                  open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json"), "w"), indent=1)
+                  open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic%s.json" % sfx), "w"), indent=1)
     txt = "\n".join(out)
-    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_rocprof_summary.txt" % tag), "w").write(txt)
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_rocprof_summary%s.txt" % (tag, sfx)), "w").write(txt)
     print(txt)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")

@@ -1091,7 +1091,9 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
   // still does not fit runs in batches.
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  size_t budget = std::max<size_t>((size_t)2 << 30, (free_b + ctx->scratch_cap[0] + ctx->scratch_cap[1]) / 10 * 6);
+  // what is free now plus what this path already holds, less a reserve for everything else that allocates later
+  const size_t have_b = free_b + ctx->scratch_cap[0] + ctx->scratch_cap[1], reserve_b = std::max<size_t>((size_t)8 << 30, total_b / 10);
+  size_t budget = std::max<size_t>((size_t)2 << 30, have_b > reserve_b ? have_b - reserve_b : 0);
   if (const char* e = getenv("ZPQ_LZ_BUDGET_MB")) budget = (size_t)strtoull(e, 0, 10) << 20;
   u32 seg = kSegMin, max_n = 0;
   if (const char* e = getenv("ZPQ_LZ_SEG")) seg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));

@@ -554,7 +554,9 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
   const size_t shared_bytes = nn_max * 4 * 2 + (nn_max + 256) * 2 + nn_max + 2048 + sa_work_bytes(max_n_all);
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  size_t budget = std::max<size_t>((size_t)2 << 30, (free_b + ctx->scratch_cap[0] + ctx->scratch_cap[24]) / 10 * 6);
+  // what is free now plus what this path already holds, less a reserve for everything else that allocates later
+  const size_t have_b = free_b + ctx->scratch_cap[0] + ctx->scratch_cap[24], reserve_b = std::max<size_t>((size_t)8 << 30, total_b / 10);
+  size_t budget = std::max<size_t>((size_t)2 << 30, have_b > reserve_b ? have_b - reserve_b : 0);
   if (const char* e = getenv("ZPQ_LZ_BUDGET_MB")) budget = (size_t)strtoull(e, 0, 10) << 20;
   budget = budget > shared_bytes ? budget - shared_bytes : 0;
 
