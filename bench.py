@@ -103,12 +103,20 @@ class CollectiveOrder:
                 if 0 <= st < steps:
                     self.seq.append((st, sec))
         self.head = 0
+        self.failed = False
         self.cv = threading.Condition()
+
+    def abort(self):                   # a step failed on some thread: nobody waits for its turn any more
+        with self.cv:
+            self.failed = True
+            self.cv.notify_all()
 
     def enter(self, step, sec, timeout=600.0):
         with self.cv:
             t0 = time.monotonic()
             while self.seq[self.head] != (step, sec):
+                if self.failed:
+                    raise RuntimeError("another step in flight failed")
                 self.cv.wait(5.0)
                 if time.monotonic() - t0 > timeout:       # fail loudly rather than hang the job
                     raise RuntimeError("collective order stalled at %r waiting for %r" % (self.seq[self.head], (step, sec)))
@@ -713,9 +721,12 @@ def main_text_m2(a, rank, world, local, dev):
                 uj[k].in_ = outs.data_ptr() + framed[k][0]; uj[k].n = framed[k][1]
                 uj[k].out = back[k].data_ptr(); uj[k].out_cap = blocks[k][1] + 64
             eng.decompress_blocks_dev(uj, nb, True)
-            ok = all(uj[k].status == 0 and uj[k].out_len == blocks[k][1] and bool(torch.equal(back[k][: blocks[k][1]], blocks[k][0][: blocks[k][1]]))
-                     for k in range(nb))
-            res["verified_roundtrip_all_blocks"] = bool(ok)
+            torch.cuda.synchronize()
+            bad = [(k, int(uj[k].status), int(uj[k].out_len)) for k in range(nb)
+                   if not (uj[k].status == 0 and uj[k].out_len == blocks[k][1] and bool(torch.equal(back[k][: blocks[k][1]], blocks[k][0][: blocks[k][1]])))]
+            res["verified_roundtrip_all_blocks"] = not bad
+            if bad:
+                res["roundtrip_failures"] = bad[:8]
             del back
         if world == 1 and not a.no_cpu_baseline:
             # the real reference (divsufsort + LZBuffer) over the same blocks on the host cores, whole job; it also
@@ -869,6 +880,8 @@ def main():
                         last_pipe[0] = p_
             except Exception as ex:       # surface worker failures in the main thread
                 errs.append(ex)
+                if hasattr(order, "abort"):
+                    order.abort()
                 if world > 1:              # a rank that stops would leave the others waiting in a collective
                     import traceback
                     traceback.print_exc()

@@ -89,3 +89,13 @@ def test_many_streams_in_one_call(eng, monkeypatch):
     streams = [orc.lz77_encode(b, [4, 1, 5, 0, 3, 24]) for b in blocks]
     a, b = both(eng, monkeypatch, streams, [len(x) + 64 for x in blocks])
     assert a == b and [o for _, o in b] == blocks
+
+
+def test_more_than_65536_stream_segments_in_one_call():
+    """11 blocks of 64 MiB of text through method 2 and back: 325 MB of code stream (79 000 4-KiB segments) in ONE decode
+    call.  The token path splits such a call into groups of launches (see zpq_lz77_decode_launch); both decoders must
+    restore every block.  (Own process: the text is generated with torch, which wants to start the HIP runtime itself.)"""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(orc.ROOT, "tests", "lzdec_big_roundtrip.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "roundtrip ok serial=1" in r.stdout and "roundtrip ok serial=0" in r.stdout
