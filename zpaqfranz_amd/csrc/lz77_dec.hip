@@ -385,10 +385,11 @@ __global__ __launch_bounds__(256) void lzdec_emit_kernel(const LzParDev* __restr
   const LzParDev B = blocks[block_of(blocks, nblocks, g)];
   typedef __attribute__((address_space(1))) u64 g_u64;
   typedef __attribute__((address_space(1))) const u32 g_cu32;
-  g_u64* o = (g_u64*)B.tok + ((g_cu32*)B.dst)[g - B.seg0];
+  g_u64* const tok = (g_u64*)B.tok;
+  u32 o = ((g_cu32*)B.dst)[g - B.seg0];                    // index, not a running pointer
   walk_segment(B, g - B.seg0, [&](const Tok& T) {
-    if (T.kind == 3) *o++ = (u64)kTokErr;
-    else if (T.len) *o++ = (u64)(T.len | (T.kind == 0 ? 0x80000000u : 0u)) | ((u64)T.x << 32);
+    if (T.kind == 3) { tok[o] = (u64)kTokErr; ++o; }
+    else if (T.len) { tok[o] = (u64)(T.len | (T.kind == 0 ? 0x80000000u : 0u)) | ((u64)T.x << 32); ++o; }
   });
 }
 
