@@ -620,11 +620,12 @@ __global__ __launch_bounds__(64) void lz77_copy_kernel(const LzParDev* __restric
 static int decode_group(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* h_jobs, const zpq_lzdec_dev* d_jobs, size_t njobs);
 
 int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* h_jobs, const zpq_lzdec_dev* d_jobs, size_t njobs) {
-  // Jobs are decoded in groups of at most 2^15 stream segments (128 MiB of code stream) per set of launches.  Measured
-  // on gfx950 / ROCm 7.2: with more than 2^16 segment lanes in one launch the token lists of the segments beyond that
-  // came out wrong (the lanes compute the right tokens -- a hashing copy of the kernel agrees with a host parse -- yet
-  // memory holds others; not explained), while any number of launches of up to 60000 lanes is exact.  The token path is
-  // always checked against the one-wave decoder in tests/test_gpu_lzdec.py, also above this size.
+  // Jobs are decoded in groups of at most 2^15 stream segments (128 MiB of code stream) per set of launches: bounded
+  // scratch per group, and a margin around a code-generation problem met here -- lzdec_emit_kernel first wrote its tokens
+  // through a running pointer captured by the walk's lambda ("*o++ = ..."); with more than 2^16 lanes in one launch the
+  // lists of the lanes beyond 2^16 then held wrong tokens (the lanes computed the right ones: a hashing copy of the kernel
+  // agreed with a host parse, every slot had one writer).  Indexed stores ("tok[o] = ...; ++o") are exact at any size
+  // (tests/lzdec_big_roundtrip.py runs 79 000 lanes; ZPQ_LZDEC_GROUP lifts the grouping).
   size_t maxseg = 32768;
   if (const char* e = getenv("ZPQ_LZDEC_GROUP")) maxseg = (size_t)strtoull(e, 0, 10);
   size_t lo = 0;
