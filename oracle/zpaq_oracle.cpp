@@ -392,6 +392,55 @@ extern "C" long orc_lz77_sa_encode(const U8* in, long n_, const int args[9], con
   return (long)v.size();
 }
 
+// The candidate search of the suffix-array parse as a FUNCTION of (position, lit == 0): what LZBuffer::fill computes at
+// :6339-6372 and decides at :6414-6417 when it stands at position i with or without pending literals.  The search reads
+// only the input, SA and the (windowed) inverse, never the parse so far -- which is what lets the GPU evaluate every
+// position up front (lz77_sa.hip) and leaves the chain "take the match and skip, or count a literal" as the only serial
+// part.  rec[2*i + (lit>0)] = 0 when no match is taken, else blen | blit << 16 | (u64)offset << 32 (blen includes blit).
+// tests/test_sa_chain_cpu.py replays the chain over these records and must get orc_lz77_sa_encode's tokens.
+extern "C" long orc_lz77_sa_decisions(const U8* in, long n_, const int args[9], const U32* sa, U64* rec) {
+  const U32 n = (U32)n_;
+  const int level = args[1] & 3;
+  if (args[5] - args[0] < 21 || (level != 1 && level != 2)) return -10;
+  const U32 minMatch = args[2];
+  const int checkbits = 17 + args[0];
+  const U32 maxMatch = (1u << 14) * 3;
+  const U32 lookahead = args[6];
+  const U32 bucket = (1u << args[4]) - 1;
+  std::vector<U32> isa(n ? n : 1);
+  for (U32 j = 0; j < n; ++j) isa[sa[j]] = j;
+  for (U32 i = 0; i < n; ++i)
+    for (int state = 0; state < 2; ++state) {
+      const bool lit0 = state == 0;
+      U32 blen = minMatch - 1, bp = 0, blit = 0; int bscore = 0;
+      for (U32 h = 0; h <= lookahead; ++h) {
+        // the reference's isa[] holds the window of i only: a position in the next window is not found (:6347-6349)
+        if (h + i >= n || ((h + i) >> checkbits) != (i >> checkbits)) continue;
+        const U32 q = isa[h + i];
+        for (int j = -1; j <= 1; j += 2) {
+          for (U32 k = 1; k <= bucket; ++k) {
+            U32 p;
+            const U32 qq = q + (U32)(j * (int)k);
+            if (qq < n && (p = sa[qq] - h) < i) {
+              U32 l, l1;
+              for (l = h; i + l < n && l < maxMatch && in[p + l] == in[i + l]; ++l) {}
+              for (l1 = h; l1 > 0 && in[p + l1 - 1] == in[i + l1 - 1]; --l1) {}
+              int score = (int)(l - l1) * 8 - lg(i - p) - 4 * (lit0 && l1 > 0) - 11;
+              for (U32 a = 0; a < h; ++a) score = score * 5 / 8;
+              if (score > bscore) blen = l, bp = p, blit = l1, bscore = score;
+              if (l < blen || l < minMatch || l > 255) break;
+            }
+          }
+        }
+        if (bscore <= 0 || blen < minMatch) break;
+      }
+      const U32 off = i - bp;
+      const bool take = off > 0 && bscore > 0 && blen - blit >= minMatch + (level == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)));
+      rec[2 * (size_t)i + state] = take ? (U64)blen | ((U64)blit << 16) | ((U64)off << 32) : 0;
+    }
+  return n;
+}
+
 // LZ77 level 1 decoder: a native restatement of what the level-1 PCOMP program does
 // (SURVEY.md Appendix D disassembly; code format ZSFX/libzpaq.cpp:6211-6222).  The PCOMP is a
 // byte-at-a-time state machine; codes that are cut short by end of input are dropped, as the

@@ -19,7 +19,7 @@ def _build():
 
 _L = C.CDLL(_build())
 _u8p = C.POINTER(C.c_ubyte)
-for name in ("orc_suffix_array", "orc_lz77_sa_encode", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
+for name in ("orc_suffix_array", "orc_lz77_sa_encode", "orc_lz77_sa_decisions", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
     getattr(_L, name).restype = C.c_long
 
 
@@ -135,6 +135,17 @@ def lz77_sa_encode(b, args, sa=None, trace=False):
     if trace:
         return bytes(out[:r]), [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(nt.value)]
     return bytes(out[:r])
+
+
+def lz77_sa_decisions(b, args, sa):
+    """numpy uint64[2n]: the decision at every position for lit == 0 / lit > 0 (0 = literal, else blen | blit<<16 | off<<32)."""
+    import numpy as np
+    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
+    rec = np.zeros(max(1, 2 * len(b)), dtype=np.uint64)
+    r = _L.orc_lz77_sa_decisions(_buf(b), C.c_long(len(b)), a, sa.ctypes.data_as(C.POINTER(C.c_uint32)), rec.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if r < 0:
+        raise RuntimeError("orc_lz77_sa_decisions failed: %d" % r)
+    return rec[: 2 * len(b)]
 
 
 def lz77_decode(b, cap, rb=0):
