@@ -258,6 +258,7 @@ template <int DIR, bool INTILE>
 __device__ __forceinline__ void scan_dir0(const SaCfg& C, const Tile& T, u32 q, u32 i, Best& B) {
   u32 run = kLcpCap;
   const u32 total = DIR < 0 ? std::min(C.bucket, q) : std::min(C.bucket, C.n - 1 - q);
+#pragma unroll 4
   for (u32 k = 1; k <= total; ++k) {
     const u32 qq = DIR < 0 ? q - k : q + k;
     const u64 w = T.word<INTILE>(qq);
@@ -279,6 +280,7 @@ __device__ __forceinline__ void scan_dir1(const SaCfg& C, const Tile& T, u32 q, 
   u32 run = kLcpCap;
   bool actA = true, actB = true;
   const u32 total = DIR < 0 ? std::min(C.bucket, q) : std::min(C.bucket, C.n - 1 - q);
+#pragma unroll 4
   for (u32 k = 1; k <= total; ++k) {
     const u32 qq = DIR < 0 ? q - k : q + k;
     const u64 w = T.word<INTILE>(qq);
