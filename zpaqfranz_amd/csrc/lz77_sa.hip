@@ -291,10 +291,16 @@ __device__ __forceinline__ void scan_dir1(const SaCfg& C, const Tile& T, u32 q, 
     const u32 l = std::min(run + 1u, kMaxMatch); // counted from the lookahead point; lcp <= n - (i+1) keeps it inside the block
     const u32 l1 = T.bw<INTILE>(qq) == my_bw ? 0u : 1u;   // in[p] against in[i]
     const int base = (int)(l - l1) * 8 - lg32(i - p) - 11;
-    const int sA = (base - 4 * (int)l1) * 5 / 8, sB = base * 5 / 8;
+    const int sB = base * 5 / 8;
     const bool stop = l < C.minMatch || l > 255;
-    if (actA) { if (sA > A.bscore) { A.blen = l; A.bp = p; A.blit = l1; A.bscore = sA; } if (l < A.blen || stop) actA = false; }
-    if (actB) { if (sB > B.bscore) { B.blen = l; B.bp = p; B.blit = l1; B.bscore = sB; } if (l < B.blen || stop) actB = false; }
+    // inside a plateau of equal lengths almost no candidate beats the best: sA <= sB, so nothing can change unless sB does
+    if (sB > A.bscore || sB > B.bscore) {
+      const int sA = (base - 4 * (int)l1) * 5 / 8;
+      if (actA && sA > A.bscore) { A.blen = l; A.bp = p; A.blit = l1; A.bscore = sA; }
+      if (actB && sB > B.bscore) { B.blen = l; B.bp = p; B.blit = l1; B.bscore = sB; }
+    }
+    if (l < A.blen || stop) actA = false;
+    if (l < B.blen || stop) actB = false;
     if (!actA && !actB) break;
   }
 }
