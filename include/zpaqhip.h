@@ -256,6 +256,11 @@ int zpq_e8e9_inverse_dev(zpq_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, size
  * d_isa, when not NULL, receives the inverse (d_isa[d_sa[j]] = j).  n < 2^31.  Jobs of zpq_lz77_encode_dev
  * with args[5]-args[0] >= 21 (method 2: "x<N>,1,4,0,7,<21+N>,1") build it internally. */
 int zpq_suffix_array_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint32_t* d_sa, uint32_t* d_isa);
+/* What LZBuffer emits for (args[1] & 3) == 3, the BWT front end of methods 3 and 4 (ZSFX/libzpaq.cpp:6317-6326):
+ * d_out[0] = last input byte, d_out[1..n] = the byte before every suffix in suffix order (255 for the suffix that is
+ * the whole block), d_out[n+1..n+4] = that suffix's 1-based rank, LSB first.  d_out holds n+5 bytes.  (compressBlock
+ * does not offer the BWT methods yet: their post-processor program is not pinned) */
+int zpq_bwt_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint8_t* d_out);
 
 /* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */
 /* compressBlock()'s expansion of "0".."5"[B][,R,t] into the x/0 method it stands for

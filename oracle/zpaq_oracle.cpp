@@ -392,6 +392,25 @@ extern "C" long orc_lz77_sa_encode(const U8* in, long n_, const int args[9], con
   return (long)v.size();
 }
 
+// BWT output of LZBuffer (level 3, ZSFX/libzpaq.cpp:6317-6326): n+5 bytes -- the last input byte, then for every suffix
+// in order the byte before it (255 where the suffix is the whole block, whose 1-based rank goes to the last four bytes,
+// LSB first).  `sa_in` may be null.
+extern "C" long orc_bwt_encode(const U8* in, long n_, const U32* sa_in, U8* out, long cap) {
+  const U32 n = (U32)n_;
+  if (cap < (long)n + 5) return -2;
+  std::vector<U32> sav;
+  if (!sa_in) { sav.resize(n ? n : 1); orc_suffix_array(in, n, sav.data()); }
+  const U32* sa = sa_in ? sa_in : sav.data();
+  U32 idx = 0;
+  for (U32 i = 0; i < n + 5; ++i) {
+    if (i == 0) out[i] = n > 0 ? in[n - 1] : 255;
+    else if (i > n) { out[i] = (U8)(idx & 255); idx >>= 8; }
+    else if (sa[i - 1] == 0) { idx = i; out[i] = 255; }
+    else out[i] = in[sa[i - 1] - 1];
+  }
+  return (long)n + 5;
+}
+
 // The candidate search of the suffix-array parse as a FUNCTION of (position, lit == 0): what LZBuffer::fill computes at
 // :6339-6372 and decides at :6414-6417 when it stands at position i with or without pending literals.  The search reads
 // only the input, SA and the (windowed) inverse, never the parse so far -- which is what lets the GPU evaluate every

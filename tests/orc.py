@@ -19,7 +19,7 @@ def _build():
 
 _L = C.CDLL(_build())
 _u8p = C.POINTER(C.c_ubyte)
-for name in ("orc_suffix_array", "orc_lz77_sa_encode", "orc_lz77_sa_decisions", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
+for name in ("orc_suffix_array", "orc_bwt_encode", "orc_lz77_sa_encode", "orc_lz77_sa_decisions", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
     getattr(_L, name).restype = C.c_long
 
 
@@ -134,6 +134,14 @@ def lz77_sa_encode(b, args, sa=None, trace=False):
         raise RuntimeError("orc_lz77_sa_encode failed: %d" % r)
     if trace:
         return bytes(out[:r]), [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(nt.value)]
+    return bytes(out[:r])
+
+
+def bwt_encode(b):
+    out = (C.c_ubyte * (len(b) + 5))()
+    r = _L.orc_bwt_encode(_buf(b), C.c_long(len(b)), None, out, C.c_long(len(b) + 5))
+    if r < 0:
+        raise RuntimeError("orc_bwt_encode failed: %d" % r)
     return bytes(out[:r])
 
 

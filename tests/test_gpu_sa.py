@@ -162,3 +162,14 @@ def test_text_m2_two_ranks(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["input_bytes"] == 10000000 and d["scaling"] == "weak"
     assert 0.2 < d["config"]["ratio"] < 0.7 and d["value"] > 0
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_bwt_equals_oracle(eng, name, data):
+    assert eng.bwt(data) == orc.bwt_encode(data)
+
+
+@needs_ref
+def test_bwt_equals_lzbuffer_level3_2mib(eng):
+    data = datagen.mixed(2 << 20, 77)
+    assert eng.bwt(data) == orc.ref_lzbuffer(data, (1, 3, 0, 0, 0, 0, 0))

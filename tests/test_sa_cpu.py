@@ -63,3 +63,9 @@ def test_level1_stream_decodes_to_the_input():
     for a0 in (0, 6):
         lz = orc.lz77_sa_encode(data, (a0, 1, 4, 0, 7, 21 + a0, 1))
         assert orc.lz77_decode(lz, len(data), rb=max(a0 - 4, 0)) == data
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_bwt_output_equals_lzbuffer_level3(name, data):
+    """LZBuffer with args[1] & 3 == 3 (what methods 3 and 4 put in front of their models) is the BWT of the block."""
+    assert orc.bwt_encode(data) == orc.ref_lzbuffer(data, (0, 3, 0, 0, 0, 0, 0))

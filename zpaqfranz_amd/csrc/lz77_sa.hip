@@ -179,6 +179,21 @@ int build_suffix_array(zpq_ctx* ctx, hipStream_t st, const u8* d_in, u32 n, u32*
   return ZPQ_OK;
 }
 
+// ---- BWT output (LZBuffer level 3, ZSFX/libzpaq.cpp:6317-6326) ----------------------------------------------------------
+// out[0] = last byte, out[j+1] = the byte before suffix sa[j] (255 for the suffix that is the whole block; its 1-based rank
+// goes LSB first into the four bytes after the n+1 transformed ones)
+__global__ __launch_bounds__(256) void bwt_output_kernel(const u8* __restrict__ in, u32 n, const u32* __restrict__ sa, u8* __restrict__ out) {
+  const u32 j = blockIdx.x * 256u + threadIdx.x;
+  if (j == 0) out[0] = n ? in[n - 1] : 255;
+  if (j >= n) return;
+  const u32 s = sa[j];
+  if (s == 0) {
+    out[j + 1] = 255;
+    const u32 idx = j + 1;
+    out[n + 1] = (u8)idx; out[n + 2] = (u8)(idx >> 8); out[n + 3] = (u8)(idx >> 16); out[n + 4] = (u8)(idx >> 24);
+  } else out[j + 1] = in[s - 1];
+}
+
 // ---- LCP of neighbouring suffixes (Kasai), capped ------------------------------------------------------------------
 // lcp[q] = min(kLcpCap, longest common prefix of suffixes sa[q-1] and sa[q]); lcp[0] = 0
 __global__ __launch_bounds__(256) void sa_lcp_kernel(const u8* __restrict__ in, u32 n, const u32* __restrict__ sa, const u32* __restrict__ isa,
@@ -527,6 +542,34 @@ extern "C" int zpq_suffix_array_dev(zpq_ctx* ctx, const void* d_in, size_t n, ui
   int rc = build_suffix_array(ctx, ctx->stream, (const u8*)d_in, (u32)n, d_sa, rank, work, nullptr);
   if (rc) return rc;
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZPQ_OK;
+}
+
+// The Burrows-Wheeler transform as LZBuffer emits it for (args[1] & 3) == 3 (ZSFX/libzpaq.cpp:6317-6326): n+5 bytes.
+extern "C" int zpq_bwt_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint8_t* d_out) {
+  if (!ctx) return ZPQ_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  if (n >= (1ull << 31)) return zpq_fail(ctx, ZPQ_ERR_ARG, "BWT of %zu bytes: blocks are below 2 GiB", n);
+  if (!d_out || (n && !d_in)) return zpq_fail(ctx, ZPQ_ERR_ARG, "null buffer");
+  hipStream_t st = ctx->stream;
+  u32* d_sa = nullptr;
+  if (n) {
+    const size_t wb = sa_work_bytes((u32)n) + (n * 4 + 256) * 2;
+    u8* work = (u8*)zpq_scratch(ctx, 0, wb);
+    if (!work) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "suffix array scratch (%zu MiB)", wb >> 20);
+    d_sa = (u32*)work; work += (n * 4 + 255) & ~(size_t)255;
+    u32* rank = (u32*)work; work += (n * 4 + 255) & ~(size_t)255;
+    int rc = build_suffix_array(ctx, st, (const u8*)d_in, (u32)n, d_sa, rank, work, nullptr);
+    if (rc) return rc;
+  } else {
+    const u8 tail[5] = {255, 0, 0, 0, 0};
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_out, tail, 5, hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    return ZPQ_OK;
+  }
+  ZPQ_LAUNCH(ctx, "bwt_output_kernel", st, bwt_output_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (const u8*)d_in, (u32)n, d_sa, d_out);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
   return ZPQ_OK;
 }
 

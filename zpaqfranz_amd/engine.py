@@ -105,6 +105,7 @@ def load():
     L.zpq_file_checksums_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.zpq_e8e9_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.zpq_suffix_array_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.zpq_bwt_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_expand_method.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     L.zpq_make_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zpq_compile_config.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -335,6 +336,17 @@ class Engine:
     # ---- LZ77 -----------------------------------------------------------------------------------
     def lz77_bound(self, n):
         return self.L.zpq_lz77_bound(n)
+
+    def bwt(self, data):
+        """LZBuffer's level-3 output for `data` (n + 5 bytes)."""
+        n = len(data)
+        d_in = self.upload(data) if n else self.alloc(16)
+        d_out = self.alloc(n + 16)
+        try:
+            self._ck(self.L.zpq_bwt_dev(self.ctx, d_in.ptr if n else None, n, d_out.ptr))
+            return d_out.download(n + 5)
+        finally:
+            d_in.free(); d_out.free()
 
     def suffix_array(self, data, inverse=False):
         """divsufsort's result for `data` (numpy uint32), optionally with the inverse."""
