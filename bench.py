@@ -828,6 +828,10 @@ def main():
     else:
         layout = silesia_layout(dev, corpus, a.copies)
     torch.cuda.empty_cache()       # what the generators left in torch's cache is HBM the engine cannot see (its LZ77 batches are sized by free memory)
+    if a.workload == "silesia_x256_m1" and a.pipeline is None:
+        # every job in flight holds its own hash-table states (~26 GB for the 13 blocks): no deeper than HBM allows
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        depth = max(1, min(depth, int((free_b - (20 << 30)) // (30 << 30))))
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
     engines, pipes = [], []
