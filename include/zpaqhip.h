@@ -254,7 +254,8 @@ int zpq_e8e9_inverse_dev(zpq_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, size
 /* divsufsort(T, SA, n) (ZSFX/libzpaq.cpp:6047-6072, called at :6304 for LZ77-SA and BWT): d_sa[0..n) = the
  * positions of d_in[0..n) in suffix order (a shorter suffix sorts before a longer one it is a prefix of).
  * d_isa, when not NULL, receives the inverse (d_isa[d_sa[j]] = j).  n < 2^31.  Jobs of zpq_lz77_encode_dev
- * with args[5]-args[0] >= 21 (method 2: "x<N>,1,4,0,7,<21+N>,1") build it internally. */
+ * with args[5]-args[0] >= 21 (method 2: "x<N>,1,4,0,7,<21+N>,1"; with args[1] & 3 == 2 the byte-aligned codes of
+ * methods 3 and 4, e.g. "x<N>,2,12,0,7,<21+N>,1") build it internally. */
 int zpq_suffix_array_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint32_t* d_sa, uint32_t* d_isa);
 /* What LZBuffer emits for (args[1] & 3) == 3, the BWT front end of methods 3 and 4 (ZSFX/libzpaq.cpp:6317-6326):
  * d_out[0] = last input byte, d_out[1..n] = the byte before every suffix in suffix order (255 for the suffix that is

@@ -173,3 +173,29 @@ def test_bwt_equals_oracle(eng, name, data):
 def test_bwt_equals_lzbuffer_level3_2mib(eng):
     data = datagen.mixed(2 << 20, 77)
     assert eng.bwt(data) == orc.ref_lzbuffer(data, (1, 3, 0, 0, 0, 0, 0))
+
+
+L2_ARGS = [
+    (0, 2, 12, 0, 7, 21, 1),     # what method 3 puts in front of its model (type < 640, not text)
+    (1, 2, 5, 0, 7, 22, 1),      # method 4, types 24..47
+    (0, 2, 1, 0, 4, 21, 0),      # shortest matches the byte codes allow
+    (6, 2, 12, 0, 7, 27, 1),     # at the 64 MiB block size
+]
+
+
+@pytest.mark.parametrize("args", L2_ARGS)
+def test_sa_parse_level2_byte_codes_equal_oracle(eng, args):
+    """Byte-aligned codes (level 2): literal runs of at most 64 behind a length byte, matches in pieces of
+    minMatch .. minMatch+63 with 2/3/4 offset bytes; a far match must be longer to be taken."""
+    blocks = [d for _, d in CASES]
+    out = eng.lz77_encode(blocks, [args] * len(blocks))
+    for (name, d), o in zip(CASES, out):
+        assert o == orc.lz77_sa_encode(d, args), name
+
+
+def test_levels_mixed_in_one_call(eng):
+    a, b = datagen.mixed(300000, 11), datagen.text_like(200000, 12)
+    out = eng.lz77_encode([a, b, a], [(0, 2, 12, 0, 7, 21, 1), (0, 1, 4, 0, 7, 21, 1), (4, 1, 5, 0, 3, 24)])
+    assert out[0] == orc.lz77_sa_encode(a, (0, 2, 12, 0, 7, 21, 1))
+    assert out[1] == orc.lz77_sa_encode(b, (0, 1, 4, 0, 7, 21, 1))
+    assert out[2] == orc.lz77_encode(a, (4, 1, 5, 0, 3, 24))

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev*
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------
-extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 512 + 64; }
+extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 64 + 64; }   // level 2 spends a byte per 64 literals, level 1 15 bits per 4096
 
 #ifdef ZPQ_LZ_PROFILE
 extern "C" int zpq_debug_lzprof(unsigned long long out[8], int reset) {
@@ -826,10 +826,12 @@ int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u
 static bool uses_suffix_array(const int32_t a[9]) { return a[5] - a[0] >= 21; }
 
 static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
-  if ((a[1] & 3) != 1 || a[1] > 5) return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 level %d not implemented", a[1]);
-  if (uses_suffix_array(a)) {        // LZ77-SA (method 2): lz77_sa.hip
+  const int lvl = a[1] & 3;
+  if (a[1] < 1 || a[1] > 7 || a[1] == 4 || lvl == 3 || lvl == 0 || (lvl == 2 && !uses_suffix_array(a)))
+    return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 pre-processor %d not implemented (level 1, and level 2 over a suffix array, are)", a[1]);
+  if (uses_suffix_array(a)) {        // LZ77-SA (methods 2..4): lz77_sa.hip
     if (a[0] < 0 || a[0] > 6 || a[5] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "suffix-array LZ77: block size 2^%d out of range", 20 + a[0]);
-    if (a[2] < 4 || a[2] > 255) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
+    if (lvl == 1 ? (a[2] < 4 || a[2] > 255) : (a[2] < 1 || a[2] > 64)) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
     if (a[4] < 0 || a[4] > 12) return zpq_fail(ctx, ZPQ_ERR_METHOD, "2^%d neighbours not implemented", a[4]);
     if (a[6] < 0 || a[6] > 1) return zpq_fail(ctx, ZPQ_ERR_METHOD, "lookahead %d not implemented (0 and 1 are)", a[6]);
     if ((u64)n > (1ull << (20 + a[0]))) return zpq_fail(ctx, ZPQ_ERR_ARG, "block of %u bytes exceeds 2^%d", n, 20 + a[0]);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void sa_lcp_kernel(const u8* __restrict__ in, 
 // ---- per-position decisions ------------------------------------------------------------------------------------------
 struct SaCfg {
   const u8* in; u32 n;
-  u32 minMatch, bucket, lookahead, checkbits;
+  u32 minMatch, bucket, lookahead, checkbits, level;
 };
 
 // final decision record: bit 63 take, bit 62 blit (leading literal), bits 32..47 blen (blit included), bits 0..31 offset
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(256) void lz77_sa_cand1_kernel(SaCfg C, const u32* 
     scan_dir1<+1, INTILE>(C, T, q1, i, my_bw, BA, BB);
   }
   const u32 offA = i - BA.bp, offB = i - BB.bp;
-  const bool takeA = offA > 0 && BA.bscore > 0 && BA.blen - BA.blit >= C.minMatch;    // level 1
-  const bool takeB = offB > 0 && BB.bscore > 0 && BB.blen - BB.blit >= C.minMatch;
+  // :6414-6417 -- at level 2 a far match must be one / two bytes longer to pay for its longer offset
+  const u32 needA = C.minMatch + (C.level == 2 ? (u32)(offA >= (1u << 16)) + (u32)(offA >= (1u << 24)) : 0u);
+  const u32 needB = C.minMatch + (C.level == 2 ? (u32)(offB >= (1u << 16)) + (u32)(offB >= (1u << 24)) : 0u);
+  const bool takeA = offA > 0 && BA.bscore > 0 && BA.blen - BA.blit >= needA;
+  const bool takeB = offB > 0 && BB.bscore > 0 && BB.blen - BB.blit >= needB;
   rec[2 * (size_t)i] = make_rec(takeA, BA.blen, BA.blit, offA);
   rec[2 * (size_t)i + 1] = make_rec(takeB, BB.blen, BB.blit, offB);
 }
@@ -523,6 +526,90 @@ __global__ __launch_bounds__(64) void lz77_sa_move_kernel(const SaBlockDev* __re
   }
 }
 
+
+// ---- level 2: byte-aligned codes (write_literal / write_match, ZSFX/libzpaq.cpp:6481-6489, 6518-6549) ------------------
+// literals: runs of at most 64, a byte (run length - 1) in front of each; a match: pieces of minMatch .. minMatch+63 bytes,
+// each a byte 64/128/192 + (piece - minMatch) followed by 2/3/4 bytes of (offset - 1), most significant first
+struct Pack2Dev { const u8* in; u32 n; u32 minMatch; const u32* tok_pos; const u32* tok_len; const u32* tok_off; u32* tok_at; u32* result; u8* out; u32 out_cap; };
+__device__ __forceinline__ u32 off_bytes(u32 off) { const u32 o = off - 1; return o < (1u << 16) ? 2u : o < (1u << 24) ? 3u : 4u; }
+__device__ __forceinline__ u32 piece_len(u32 len, u32 mm) { return len > mm * 2 + 63 ? mm + 63 : len > mm + 63 ? len - mm : len; }
+__device__ __forceinline__ u32 match_bytes2(u32 len, u32 off, u32 mm) {
+  u32 np = 0;
+  while (len) { len -= piece_len(len, mm); ++np; }
+  return np * (1u + off_bytes(off));
+}
+__device__ __forceinline__ u32 gap_bytes2(u32 g) { return g + (g + 63) / 64; }
+
+__global__ __launch_bounds__(1024) void lz77_pack2_tokens_kernel(const Pack2Dev* __restrict__ jobs) {
+  const Pack2Dev J = jobs[blockIdx.x];
+  const u32 ntok = J.result[0];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s, over_s;
+  if (tid == 0) { carry_s = 0; over_s = 0; }
+  __syncthreads();
+  for (u32 t0 = 0; t0 <= ntok; t0 += 1024) {              // items 0..ntok-1 = (gap before match t, match t); item ntok = trailing literals
+    const u32 t = t0 + tid;
+    u32 cost = 0, gap = 0, gstart = 0, pos = 0, len = 0, off = 0;
+    if (t <= ntok) {
+      gstart = t ? J.tok_pos[t - 1] + J.tok_len[t - 1] : 0u;
+      if (t < ntok) { pos = J.tok_pos[t]; len = J.tok_len[t]; off = J.tok_off[t]; } else pos = J.n;
+      gap = pos - gstart;
+      cost = gap_bytes2(gap) + (t < ntok ? match_bytes2(len, off, J.minMatch) : 0u);
+    }
+    u32 x = cost;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 y = __shfl_up(x, d); if (lane >= (u32)d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u32 wbase = 0;
+    for (u32 w = 0; w < wave; ++w) wbase += wsum[w];
+    const u32 carry = carry_s;
+    const u32 start = carry + wbase + x - cost;
+    if (t <= ntok) {
+      J.tok_at[t] = start;
+      if ((u64)start + cost > J.out_cap) over_s = 1;
+      else {
+        u8* o = J.out + start;
+        for (u32 r = 0; r < gap; r += 64) o[r + r / 64] = (u8)((gap - r < 64 ? gap - r : 64) - 1);    // run headers; the bytes come from lz77_pack2_literals_kernel
+        o += gap_bytes2(gap);
+        if (t < ntok) {
+          const u32 ov = off - 1, nb = off_bytes(off);
+          while (len) {
+            const u32 l1 = piece_len(len, J.minMatch);
+            *o++ = (u8)((nb - 1) * 64 + l1 - J.minMatch);
+            if (nb == 4) *o++ = (u8)(ov >> 24);
+            if (nb >= 3) *o++ = (u8)(ov >> 16);
+            *o++ = (u8)(ov >> 8); *o++ = (u8)ov;
+            len -= l1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
+  }
+  if (tid == 0) { J.result[1] = carry_s; if (over_s || carry_s > J.out_cap) J.result[2] = 1; }
+}
+
+__global__ __launch_bounds__(256) void lz77_pack2_literals_kernel(const Pack2Dev* __restrict__ jobs) {
+  const Pack2Dev J = jobs[blockIdx.y];
+  const u32 x = blockIdx.x * 256u + threadIdx.x;
+  const u32 ntok = J.result[0];
+  if (J.result[2]) return;
+  const u32 x0 = __builtin_amdgcn_readfirstlane(x);
+  if (x0 >= J.n) return;
+  u32 lo = 0, hi = ntok;                                   // first token with tok_pos > x0
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (J.tok_pos[mid] > x0) hi = mid; else lo = mid + 1; }
+  if (x >= J.n) return;
+  u32 t = lo;
+  while (t < ntok && J.tok_pos[t] <= x) ++t;
+  const u32 gstart = t ? J.tok_pos[t - 1] + J.tok_len[t - 1] : 0u;
+  if (x < gstart) return;                                  // inside match t-1
+  const u32 r = x - gstart;
+  J.out[J.tok_at[t] + r + r / 64 + 1] = J.in[x];
+}
 }  // namespace
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -623,7 +710,7 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
     const size_t nj = hi - lo;
     u8* shared = (u8*)zpq_scratch(ctx, 0, shared_bytes);
     u8* per = (u8*)zpq_scratch(ctx, 24, bytes + 4096);
-    const size_t meta_bytes = nj * (sizeof(zpq_lzjob_dev) + sizeof(SaBlockDev) + 16 + 512) + nseg_total * 16 + 4096;
+    const size_t meta_bytes = nj * (sizeof(zpq_lzjob_dev) + sizeof(SaBlockDev) + sizeof(Pack2Dev) + 16 + 768) + nseg_total * 16 + 4096;
     u8* d_meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
     if (!shared || !per || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 suffix-array scratch (%zu MiB)", (shared_bytes + bytes) >> 20);
     u8* sp = shared;
@@ -639,6 +726,7 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
     u32* d_segblock = carve<u32>(mp, nseg_total);
     u32* d_segfrom = carve<u32>(mp, nseg_total);
     u32* d_segdst = carve<u32>(mp, nseg_total);
+    u8* d_pack2 = (u8*)carve<Pack2Dev>(mp, nj);
     std::vector<zpq_lzjob_dev> hj(nj);
     std::vector<SaBlockDev> hb(nj);
     std::vector<u32> segblock(nseg_total);
@@ -679,7 +767,7 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
         const u32 n = z.n;
         ZPQ_LAUNCH(ctx, "sa_lcp_kernel", st, sa_lcp_kernel, dim3(((n + kLcpChunk - 1) / kLcpChunk + 255) / 256), dim3(256), J.in, n, d_sa, d_isa, d_lcp);
         SaCfg C;
-        C.in = J.in; C.n = n; C.minMatch = (u32)z.args[2]; C.bucket = (1u << z.args[4]) - 1; C.lookahead = (u32)z.args[6]; C.checkbits = 17 + (u32)z.args[0];
+        C.in = J.in; C.n = n; C.minMatch = (u32)z.args[2]; C.bucket = (1u << z.args[4]) - 1; C.lookahead = (u32)z.args[6]; C.checkbits = 17 + (u32)z.args[0]; C.level = (u32)z.args[1] & 3;
         if (C.bucket < kTileR) {         // every neighbour a scan reaches is inside the workgroup's tile
           ZPQ_LAUNCH(ctx, "lz77_sa_cand0_kernel", st, lz77_sa_cand0_kernel<true>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, rec, d_bw);
           ZPQ_LAUNCH(ctx, "lz77_sa_cand1_kernel", st, lz77_sa_cand1_kernel<true>, dim3((n + 255) / 256), dim3(256), C, d_sa, d_lcp, d_bw, rec);
@@ -699,8 +787,33 @@ int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, si
     ZPQ_LAUNCH(ctx, "lz77_sa_count_kernel", st, lz77_sa_count_kernel, dim3((unsigned)nj), dim3(1024), d_blocks, d_segfrom, d_segdst);
     ZPQ_LAUNCH(ctx, "lz77_sa_move_kernel", st, lz77_sa_move_kernel, dim3((unsigned)nseg_total), dim3(64), d_blocks, d_segblock, d_segfrom, d_segdst);
     ZPQ_HIP(ctx, hipGetLastError());
-    int rc = zpq_lz77_pack_launch(ctx, d_jobs, nj, max_n);
-    if (rc) return rc;
+    {   // tokens -> codes: level 1 (bits) for the jobs that ask for it, level 2 (bytes) for the others
+      std::vector<zpq_lzjob_dev> j1; std::vector<Pack2Dev> j2;
+      u32 max1 = 0, max2 = 0;
+      for (size_t i = 0; i < nj; ++i) {
+        const zpq_lz77_job& z = jobs[which[lo + i]];
+        if ((z.args[1] & 3) == 2) {
+          Pack2Dev P; P.in = hj[i].in; P.n = hj[i].n; P.minMatch = (u32)z.args[2]; P.tok_pos = hj[i].tok_pos; P.tok_len = hj[i].tok_len; P.tok_off = hj[i].tok_off;
+          P.tok_at = hj[i].tok_bit; P.result = hj[i].result; P.out = hj[i].out; P.out_cap = hj[i].out_cap;
+          j2.push_back(P); max2 = std::max(max2, z.n);
+        } else { j1.push_back(hj[i]); max1 = std::max(max1, z.n); }
+      }
+      // (the records go behind the ones uploaded above: d_jobs has room for nj, the level-2 ones use the segment map's tail)
+      if (!j1.empty()) {
+        ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, j1.data(), j1.size() * sizeof(zpq_lzjob_dev), hipMemcpyHostToDevice, st));
+        ZPQ_HIP(ctx, hipStreamSynchronize(st));
+        int rc = zpq_lz77_pack_launch(ctx, d_jobs, j1.size(), max1);
+        if (rc) return rc;
+      }
+      if (!j2.empty()) {
+        Pack2Dev* d_p2 = (Pack2Dev*)d_pack2;
+        ZPQ_HIP(ctx, hipMemcpyAsync(d_p2, j2.data(), j2.size() * sizeof(Pack2Dev), hipMemcpyHostToDevice, st));
+        ZPQ_HIP(ctx, hipStreamSynchronize(st));
+        ZPQ_LAUNCH(ctx, "lz77_pack2_tokens_kernel", st, lz77_pack2_tokens_kernel, dim3((unsigned)j2.size()), dim3(1024), d_p2);
+        if (max2) ZPQ_LAUNCH(ctx, "lz77_pack2_literals_kernel", st, lz77_pack2_literals_kernel, dim3((max2 + 255) / 256, (unsigned)j2.size()), dim3(256), d_p2);
+        ZPQ_HIP(ctx, hipGetLastError());
+      }
+    }
     std::vector<u32> res(nj * 4);
     ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
     ZPQ_HIP(ctx, hipStreamSynchronize(st));     // (also keeps hj/hb/segblock alive until their uploads are done)
