@@ -157,3 +157,76 @@ def test_raw_offset_bits():
     want = serial_tokens(s, 2)
     assert replay(s, want) == data
     assert stitched_tokens(s, 2, 1024, 256)[0] == want
+
+
+def replay_in_steps(s, toks, step=64, short=32):
+    """Model of lz77_copy_kernel: `step` tokens at a time, output positions by prefix sum; short tokens are copied in
+    rounds -- a token is ready when it is a literal, when its source ends before the output of the first token still
+    pending, or when it is that first token itself; a long token is copied alone and splits the step.  Every byte a
+    ready token reads must already be written (asserted): that is what makes the rounds equal to the serial replay."""
+    total = sum(ln for _, ln, _ in toks)
+    out = bytearray(total)
+    written = bytearray(total)                               # 1 where out[] holds its final byte
+    rounds = 0
+
+    def put(pos, data):
+        out[pos:pos + len(data)] = data
+        written[pos:pos + len(data)] = b"\x01" * len(data)
+
+    def lit_bytes(x, ln):
+        b0, sh = x >> 3, x & 7
+        return bytes((((s[b0 + j] | ((s[b0 + j + 1] << 8) if sh else 0)) >> sh) & 255) for j in range(ln))
+    op = 0
+    for t0 in range(0, len(toks), step):
+        win = toks[t0:t0 + step]
+        pos = [op]
+        for _, ln, _ in win:
+            pos.append(pos[-1] + ln)
+        cur = 0
+        while cur < len(win):
+            L = next((j for j in range(cur, len(win)) if win[j][1] > short), len(win))
+            pend = list(range(cur, L))
+            while pend:                                      # rounds over the short tokens [cur, L)
+                f = pend[0]
+                ready = [j for j in pend if win[j][0] == "lit" or j == f or pos[j] - win[j][2] + win[j][1] <= pos[f]]
+                for j in ready:                              # all of these run at once on the GPU: only read what is written
+                    kind, ln, x = win[j]
+                    if kind == "lit":
+                        continue
+                    src = pos[j] - x
+                    assert x >= 1 and src >= 0
+                    if j != f or x >= ln:
+                        assert all(written[src:src + ln]), (t0, j)
+                for j in ready:
+                    kind, ln, x = win[j]
+                    if kind == "lit":
+                        put(pos[j], lit_bytes(x, ln))
+                    elif x < ln:                             # self-overlapping: byte by byte, it is the first pending token
+                        assert j == f
+                        for q in range(ln):
+                            put(pos[j] + q, bytes([out[pos[j] + q - x]]))
+                    else:
+                        put(pos[j], bytes(out[pos[j] - x:pos[j] - x + ln]))
+                pend = [j for j in pend if j not in ready]
+                rounds += 1
+            if L < len(win):                                 # one long token, alone
+                kind, ln, x = win[L]
+                if kind == "lit":
+                    put(pos[L], lit_bytes(x, ln))
+                else:
+                    for q in range(ln):
+                        put(pos[L] + q, bytes([out[pos[L] + q - x]]))
+            cur = L + 1
+        op = pos[-1]
+    return bytes(out), rounds
+
+
+@pytest.mark.parametrize("seed,kind", [(11, "mixed"), (12, "text"), (13, "binary")])
+def test_replay_in_rounds_equals_serial_replay(seed, kind):
+    data = {"mixed": datagen.mixed, "text": datagen.text_like, "binary": datagen.binary_like}[kind](30000, seed)
+    data = data + data[100:9000] + bytes(700) + b"ab" * 400 + data[:50]        # long matches, a run (self-overlap), short periods
+    s = orc.lz77_encode(data, [4, 1, 5, 0, 3, 24])
+    toks = serial_tokens(s, 0)
+    got, rounds = replay_in_steps(s, toks)
+    assert got == data == replay(s, toks)
+    assert rounds < len(toks) // 4                           # rounds, not one pass per token (about 9 per step of 64 on this data)
