@@ -54,3 +54,22 @@ def test_page_model_reproduces_the_serial_cuts(proto_pages, tmp_path, name, seg)
     f.write_bytes(CASES[name]())
     r = subprocess.run([proto_pages, str(f), seg], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def proto_dual(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("proto3") / "frag_dual")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "proto", "frag_dual.c")])
+    return exe
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("params", [("262144",), ("65536",), ("344064", "512", "65024", "19"), ("100000", "1024", "8192", "10")])
+def test_dual_table_walker_reproduces_the_serial_cuts(proto_dual, tmp_path, name, params):
+    """Stage 3: the per-file chain as a dual-table walker (tools/proto/frag_dual.c) -- true and global o1[] tables kept
+    current at the walker's position, pages skipped while they hold no context on which the tables differ, no backward
+    scans; also on the inputs stage 2 cannot finish (fully predictable data: the walker simply never leaves exact mode)."""
+    f = tmp_path / "in.bin"
+    f.write_bytes(CASES[name]())
+    r = subprocess.run([proto_dual, str(f), *params], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
