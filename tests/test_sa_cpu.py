@@ -69,3 +69,16 @@ def test_level1_stream_decodes_to_the_input():
 def test_bwt_output_equals_lzbuffer_level3(name, data):
     """LZBuffer with args[1] & 3 == 3 (what methods 3 and 4 put in front of their models) is the BWT of the block."""
     assert orc.bwt_encode(data) == orc.ref_lzbuffer(data, (0, 3, 0, 0, 0, 0, 0))
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_gpu_construction_model_equals_oracle(name, data):
+    """tools/proto/sa_doubling.py: the steps of the GPU construction (8-byte keys, doubling rounds over the still
+    ambiguous suffixes, length as second key for a suffix that ends first, singleton compaction) in numpy."""
+    import os, sys
+    sys.path.insert(0, os.path.join(orc.ROOT, "tools", "proto"))
+    import sa_doubling
+    sa, isa, rounds = sa_doubling.suffix_array(data)
+    assert np.array_equal(sa, orc.suffix_array(data))
+    if len(data):
+        assert np.array_equal(isa[sa], np.arange(len(data), dtype=np.uint32))
