@@ -83,6 +83,42 @@ def test_resident_decode_error_statuses(eng):
     assert r["status"] == 0 and r["sha1"] == orc.sha1(b)
 
 
+def test_resident_decode_failed_pass_block_writes_nothing(eng):
+    """A stored (PASS) block that fails AFTER some of its sub-blocks were accepted -- broken trailer, truncated
+    sub-block, or more payload than the caller's capacity -- must not copy anything: the outputs of one call sit next
+    to each other in one device buffer, so a stray gather would land in the neighbour's bytes."""
+    big = datagen.random_bytes(300000, 31)
+    (st, f), = eng.compress_blocks([big], ["0"], ["n"], ["c"], True)
+    assert st == 0
+    cut_marker = bytearray(f); cut_marker[-22] = 0x77                  # 253 -> garbage: "missing 253/254 marker"
+    cut_end = f[:-1] + b"\x01"                                         # end-of-block byte replaced: another segment
+    trunc = f[: len(f) - 40000]                                        # last sub-block runs past the end
+    n = 3
+    small = 1000
+    # ONE output buffer: [guard | small target | guard] per job, so that an overrun is visible
+    jobs = (UnblockJob * n)()
+    ins = [eng.upload(bytes(b)) for b in (cut_marker, cut_end, trunc)]
+    slab = eng.alloc(n * 400000)
+    try:
+        eng._ck(eng.L.zpq_dev_memset(eng.ctx, slab.ptr, 0xEE, n * 400000))
+        for i in range(n):
+            jobs[i].in_, jobs[i].n = ins[i].ptr, len((cut_marker, cut_end, trunc)[i])
+            jobs[i].out, jobs[i].out_cap = slab.ptr + i * 400000 + 4096, small
+        eng.decompress_blocks_dev(jobs, n, True)
+        assert all(jobs[i].status < 0 for i in range(n))
+        raw = slab.download(n * 400000)
+        assert raw == b"\xEE" * (n * 400000), "a failed block copied data"
+        # and with room for the payload the broken framing is still refused without a copy
+        for i in range(n):
+            jobs[i].out_cap = 390000
+        eng.decompress_blocks_dev(jobs, n, True)
+        assert all(jobs[i].status < 0 for i in range(n))
+        assert slab.download(n * 400000) == b"\xEE" * (n * 400000)
+    finally:
+        for b in ins + [slab]:
+            b.free()
+
+
 def test_resident_decode_fixture_blocks(eng):
     """The c, h and i blocks of the reference's own archive through the device-resident path."""
     arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()

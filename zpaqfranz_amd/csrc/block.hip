@@ -42,20 +42,22 @@ const u8 zpq_pcomp_lz1[302] = {
 // golden 302-byte program; the others are pinned by decode parity (the reference's LZBuffer stream under these
 // programs is restored by the reference's own PostProcessor: tests/test_config_cpu.py).
 const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8) {
-  static std::vector<u8> tab[8][2];
-  static bool built = false;
-  if (!built) {
+  struct Tab { std::vector<u8> t[8][2]; };
+  // function-local static with an initialiser: built once, also when several contexts decode for the first time at
+  // the same moment (calls may come from any host thread)
+  static const Tab tab = [] {
+    Tab T;
     for (u32 r = 0; r < 8; ++r)
       for (int e = 0; e < 2; ++e) {
         char m[64];
         snprintf(m, sizeof m, "x%u,%d,5,0,3,24", 4 + r, e ? 5 : 1);
         std::string xm; int args[9]; std::vector<u8> hdr;
-        if (zpq_build_config(nullptr, m, nullptr, 0, &xm, args, &hdr, &tab[r][e]) != ZPQ_OK) tab[r][e].clear();
+        if (zpq_build_config(nullptr, m, nullptr, 0, &xm, args, &hdr, &T.t[r][e]) != ZPQ_OK) T.t[r][e].clear();
       }
-    built = true;
-  }
+    return T;
+  }();
   static const std::vector<u8> none;
-  return rb < 8 ? tab[rb][e8 ? 1 : 0] : none;
+  return rb < 8 ? tab.t[rb][e8 ? 1 : 0] : none;
 }
 
 namespace {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
         }
       } else {
         for (u32 j = lane; j < len; j += 64) {
-          const u32 two = (u32)in[byte0 + j] | ((u32)in[byte0 + j + 1] << 8);
+          const u32 two = (u32)in[byte0 + j] | (sh ? (u32)in[byte0 + j + 1] << 8 : 0u);   // byte-aligned run: nothing past its end
           const u8 c = (u8)(two >> sh);
           out[op + j] = c;
           ring[(op + j) & (kRing - 1)] = c;

@@ -53,7 +53,13 @@ __global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restr
   memset(&I, 0, sizeof I);
   for (u32 k = 0; k < J.tcap; ++k) t_len[J.tbase + k] = 0;
   const u8* a = J.in; const u32 n = J.n;
-  auto done = [&](i32 st) { I.status = st; info[i] = I; };
+  u32 ns = 0;                                        // extents emitted so far
+  // every exit that is not ZPQ_OK takes its extents back: the gather that follows runs over the whole table, and a
+  // truncated or hostile block must not have it write anything (for PASS blocks the target is the caller's buffer)
+  auto done = [&](i32 st) {
+    if (st != ZPQ_OK) for (u32 q = 0; q < ns; ++q) t_len[J.tbase + q] = 0;
+    I.status = st; info[i] = I;
+  };
   if (n < 13 + 5 + 2 + 7) return done(ZPQ_ERR_FORMAT);
   for (int k = 0; k < 13; ++k) if (a[k] != c_tag[k]) return done(ZPQ_ERR_FORMAT);
   u32 p = 13;
@@ -100,16 +106,17 @@ __global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restr
   } else return done(ZPQ_ERR_FORMAT);
   I.skip = skip;
   u8* dst = I.kind == 0 ? J.out : J.stage;
-  u64 acc = 0; u32 ns = 0;
+  u64 acc = 0;
   for (;;) {
     if ((u64)p + 4 > n) return done(ZPQ_ERR_FORMAT);
     const u32 k = bswap32(*(const u32_u*)(a + p));
     p += 4;
     if (!k) break;
     if ((u64)p + k > n) return done(ZPQ_ERR_FORMAT);
-    if (ns >= J.tcap) { for (u32 q = 0; q < J.tcap; ++q) t_len[J.tbase + q] = 0; return done(1); }
+    if (ns >= J.tcap) return done(1);
     u32 so = 0, ln = k;
     if (ns == 0) { so = skip; ln = k - skip; }
+    if (I.kind == 0 && acc + k - skip > J.out_cap) return done(ZPQ_ERR_CAPACITY);   // before the extent exists
     t_src[J.tbase + ns] = (u64)(uintptr_t)(a + p + so);
     t_dst[J.tbase + ns] = (u64)(uintptr_t)(dst + (acc ? acc - skip : 0));
     t_len[J.tbase + ns] = ln;
@@ -120,9 +127,8 @@ __global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restr
   else if (p < n && a[p] == 254) { I.has_sha = 0; ++p; }
   else return done(ZPQ_ERR_FORMAT);
   if (p >= n) return done(ZPQ_ERR_FORMAT);
-  if (a[p] != 255) { for (u32 q = 0; q < J.tcap; ++q) t_len[J.tbase + q] = 0; return done(ZPQ_ERR_METHOD); }   // another segment follows
+  if (a[p] != 255) return done(ZPQ_ERR_METHOD);      // another segment follows
   I.consumed = p + 1;
-  if (I.kind == 0 && acc - skip > J.out_cap) { for (u32 q = 0; q < J.tcap; ++q) t_len[J.tbase + q] = 0; return done(ZPQ_ERR_CAPACITY); }
   done(ZPQ_OK);
 }
 
@@ -244,19 +250,17 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_wj, wj.data(), njobs * sizeof(WalkJob), hipMemcpyHostToDevice, st));
   {
-    static std::vector<u8> progs;                    // built once per process: table + bytes
-    static bool built = false;
-    if (!built) {
-      progs.assign(128, 0);
+    static const std::vector<u8> progs = [] {        // built once per process (thread-safe initialisation): table + bytes
+      std::vector<u8> g(128, 0);
       for (u32 r = 0; r < 8; ++r)
         for (u32 e = 0; e < 2; ++e) {
           const std::vector<u8>& pc = zpq_known_pcomp(r, e != 0);
-          const u32 off = (u32)progs.size(), len = (u32)pc.size();
-          memcpy(&progs[4 * (2 * r + e)], &off, 4); memcpy(&progs[64 + 4 * (2 * r + e)], &len, 4);
-          progs.insert(progs.end(), pc.begin(), pc.end());
+          const u32 off = (u32)g.size(), len = (u32)pc.size();
+          memcpy(&g[4 * (2 * r + e)], &off, 4); memcpy(&g[64 + 4 * (2 * r + e)], &len, 4);
+          g.insert(g.end(), pc.begin(), pc.end());
         }
-      built = true;
-    }
+      return g;
+    }();
     if (progs.size() > 16384) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "post-processor table");
     ZPQ_HIP(ctx, hipMemcpyAsync(d_lz1, progs.data(), progs.size(), hipMemcpyHostToDevice, st));
   }

@@ -177,7 +177,7 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
         for (uint32_t i = 0; i < nf; ++i) {
           memcpy(ix.ht[num + i].sha1.d, os.data() + 4 + 24 * i, 20);
           ix.ht[num + i].usize = get32(os.data() + 24 + 24 * i);
-          b.usize += ix.ht[num + i].usize + 4u;
+          b.usize += (uint64_t)ix.ht[num + i].usize + 4u;      // 64 bits: a hostile size must not wrap
         }
         ix.blocks.push_back(b);
         data_offset += bsize;
@@ -539,6 +539,8 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     for (uint32_t i = 0; i < ix.blocks[b].nfrag; ++i) {
       const uint32_t f = ix.blocks[b].first_frag + i;
       where[f] = o;
+      // the h table's sizes must stay inside what the d block decoded to (less its own size table)
+      if (o + ix.ht[f].usize > poff[b] + ix.blocks[b].usize - 8 - 4ull * ix.blocks[b].nfrag) return ZPQ_ERR_FORMAT;
       voff.push_back(o); vlen.push_back(ix.ht[f].usize); want.insert(want.end(), ix.ht[f].sha1.d, ix.ht[f].sha1.d + 20);
       o += ix.ht[f].usize;
     }

@@ -164,8 +164,8 @@ void compressBlock(StringBuffer* in, Writer* out, const char* method, const char
   it.job.out = framed.data();
   it.job.out_cap = (uint32_t)framed.size();
   compress_batcher().submit(&it);
-  if (it.job.status != ZPQ_OK) {
-    std::string m = std::string("compressBlock(\"") + method + "\"): " + zpq_strerror(it.job.status);
+  if (it.rc != ZPQ_OK || it.job.status != ZPQ_OK) {      // a batch can fail before it touches its jobs (status stays 0)
+    std::string m = std::string("compressBlock(\"") + method + "\"): " + zpq_strerror(it.job.status ? it.job.status : it.rc);
     error(m.c_str());
   }
   out->write((const char*)framed.data(), (int)it.job.out_len);
@@ -371,8 +371,8 @@ bool Decompresser::decompress(int n) {
       it.job.in = blk.data(); it.job.n = (uint32_t)(blk.size() - 64);
       it.job.out = d.plain.data(); it.job.out_cap = (uint32_t)d.plain.size();
       decompress_batcher().submit(&it);                             // N decompressThreads -> one launch
-      if (it.job.status != ZPQ_OK) {
-        std::string m = std::string("Decompresser: ") + zpq_strerror(it.job.status);
+      if (it.rc != ZPQ_OK || it.job.status != ZPQ_OK) {             // a batch can fail before it touches its jobs
+        std::string m = std::string("Decompresser: ") + zpq_strerror(it.job.status ? it.job.status : it.rc);
         error(m.c_str());
       }
       d.plain.resize(it.job.out_len);
