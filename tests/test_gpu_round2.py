@@ -96,6 +96,7 @@ def test_resident_decode_failed_pass_block_writes_nothing(eng):
     n = 3
     small = 1000
     # ONE output buffer: [guard | small target | guard] per job, so that an overrun is visible
+    from zpaqfranz_amd.engine import UnblockJob
     jobs = (UnblockJob * n)()
     ins = [eng.upload(bytes(b)) for b in (cut_marker, cut_end, trunc)]
     slab = eng.alloc(n * 400000)
