@@ -1,0 +1,105 @@
+"""Rows a11-a14 through the run-time specialised context-mixing coder (cm_jit.hip + cm_spec_src.inc): the kernels hiprtc
+builds for a block header must code exactly like the reference Predictor + ZPAQL interpreter compiled in place
+(oracle/_ref: ZSFX/libzpaq.cpp:1846-2058, :1033-1254) and like the engine's own generic kernels."""
+import json
+import lzma
+import os
+
+import pytest
+
+import cmconfigs
+import datagen
+import orc
+
+pytestmark = pytest.mark.gpu
+G = orc.GOLDEN
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zpaqfranz_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _hdr(name):
+    return orc.ref_compile(cmconfigs.ALL[name], [0] * 9)[0]
+
+
+def _method_header(method, data=b""):
+    from zpaqfranz_amd import engine
+    src, args = engine.make_config(engine.expand_method(method, data))
+    return engine.compile_config(src, args)[0]
+
+
+def test_specialised_kernel_equals_generic_kernel(eng, monkeypatch):
+    """Same inputs through both device paths (ZPQ_CM_GENERIC=1 selects the interpreter-driven wave kernel)."""
+    for name in cmconfigs.ALL:
+        h = _hdr(name)
+        inputs = [b"\0" + datagen.text_like(3000, 11), b"\0" + datagen.binary_like(2500, 12), b"", b"\0"]
+        caps = [len(x) * 2 + 64 for x in inputs]
+        spec = eng.cm_code([h] * len(inputs), inputs, caps, encode=True)
+        monkeypatch.setenv("ZPQ_CM_GENERIC", "1")
+        gen = eng.cm_code([h] * len(inputs), inputs, caps, encode=True)
+        monkeypatch.delenv("ZPQ_CM_GENERIC")
+        assert spec == gen, name
+        assert [s for s, _ in spec] == [0] * len(inputs)
+
+
+def test_many_blocks_several_headers_one_call(eng):
+    """The queue: more blocks than waves in a workgroup, three headers in one call, ragged lengths (incl. empty)."""
+    hs = [_hdr("mid"), _hdr("alltypes"), _hdr("order1_cm")]
+    inputs, headers = [], []
+    for k in range(150):
+        n = [0, 1, 7, 300, 1200, 2500][k % 6] + k
+        gen = datagen.text_like if k % 2 else datagen.mixed
+        inputs.append(b"\0" + gen(n, 100 + k) if n else b"")
+        headers.append(hs[k % 3])
+    got = eng.cm_code(headers, inputs, [len(x) * 2 + 64 for x in inputs], encode=True)
+    assert all(st == 0 for st, _ in got)
+    for k in range(0, 150, 7):
+        assert got[k][1] == orc.ref_cm_encode(headers[k], inputs[k]), k
+    back = eng.cm_code(headers, [g for _, g in got], [len(x) + 16 for x in inputs], encode=False)
+    for k, (st, b) in enumerate(back):
+        assert st == 0 and b == inputs[k], k
+
+
+@pytest.mark.parametrize("method", ["34", "44", "54"])
+def test_methods_3_4_5_models_equal_reference(eng, method):
+    """The models compressBlock's levels 3..5 select (BWT model ci1, the order-1..6 mix of 4, the 22+ component chain
+    of 5 with its 171-byte HCOMP), coded by the specialised kernels."""
+    data = datagen.text_like(40000, 5) + datagen.binary_like(20000, 6)
+    h = _method_header(method, data)
+    x = b"\0" + data
+    (st, got), = eng.cm_code([h], [x], [len(x) + 4096], encode=True)
+    assert st == 0 and got == orc.ref_cm_encode(h, x)
+    (st, back), = eng.cm_code([h], [got], [len(x) + 16], encode=False)
+    assert st == 0 and back == x
+
+
+def _raw_header(hh, hm, comps, hcomp):
+    body = bytes([hh, hm, 0, 0, len(comps)]) + b"".join(bytes(c) for c in comps) + b"\0" + bytes(hcomp) + b"\0"
+    return bytes([len(body) & 255, len(body) >> 8]) + body
+
+
+def test_hcomp_jump_into_an_instruction_and_loops(eng):
+    """ZPAQL lets a jump land inside another instruction's operand; the translation decodes from wherever control can
+    go, like the interpreter.  First program: *d=a ; jmp +1 ; a= 56 -- the jump lands on the operand 56 = halt.
+    Second: a counted loop (a= 3 ; a-- ; a> 0 ; jt -5 ; halt)."""
+    x = b"\0" + datagen.text_like(1500, 3)
+    for prog in ([112, 63, 1, 71, 56], [112, 71, 3, 2, 239, 0, 39, 251, 56]):
+        h = _raw_header(2, 4, [(2, 16, 255)], prog)
+        want = orc.ref_cm_encode(h, x)
+        (st, got), = eng.cm_code([h], [x], [len(x) * 2 + 64], encode=True)
+        assert st == 0 and got == want
+        (st, back), = eng.cm_code([h], [got], [len(x) + 16], encode=False)
+        assert st == 0 and back == x
+
+
+def test_hcomp_endless_loop_is_stopped(eng):
+    """jmp to itself: the reference would spin forever; the generated code counts backward jumps and reports a
+    format error instead of hanging the GPU."""
+    h = _raw_header(2, 4, [(2, 16, 255)], [63, 254])
+    (st, _), = eng.cm_code([h], [b"\0abcdef"], [256], encode=True)
+    assert st == -6

@@ -10,14 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libzpaqhip.so")
-SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "config.hip", "e8e9.hip", "checksum.hip"]
+SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "cm_jit.hip", "config.hip", "e8e9.hip", "checksum.hip"]
 
 
 def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(ROOT, "include", "zpaqhip.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
             os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h"),
             os.path.join(HERE, "shim", "jidac_gpu.cpp")]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-lhiprtc", "-ldl"]
     subprocess.check_call(cmd)
     build_shim()
     if verbose:

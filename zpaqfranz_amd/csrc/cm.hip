@@ -16,6 +16,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <map>
+
 #include "zpq_internal.h"
 
 namespace {
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(256) void cm_init_kernel(const InitJob* jobs) {
     switch (J.kind) {
       case CM: J.cm[j] = 0x80000000u; break;
       case ICM: { const u8* ns = J.T->ns; J.cm[j] = (u32)(((ns[j * 4 + 3] * 2 + 1) << 22) / (ns[j * 4 + 2] + ns[j * 4 + 3] + 1)); } break;
+      case MATCH: ((u8*)J.cm)[j] = 1; break;            // cr.ht(0) = 1
       case MIX2: J.a16[j] = 32768; break;
       case MIX: J.cm[j] = 65536u / J.arg; break;
       case ISSE: {
@@ -914,34 +918,8 @@ __global__ __launch_bounds__(64) void pcomp_run_kernel(Vm* vms, const u8* in, u3
   result[1] = z.err ? (u32)ZPQ_ERR_FORMAT : (z.out_len > z.out_cap ? (u32)ZPQ_ERR_CAPACITY : 0u);
 }
 
-struct ParsedHeader {
-  u32 hh, hm, ph, pm, n;
-  std::vector<std::vector<u8>> comps;   // type + args per component
-  std::vector<u8> hcomp;                // program bytes (without the trailing END 0)
-};
-
-// Block header bytes starting at hsize[2] (ZPAQL::read, ZSFX/libzpaq.cpp:879-921)
-int parse_header(zpq_ctx* ctx, const u8* h, u32 len, ParsedHeader& P) {
-  if (len < 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header too short");
-  const u32 hsize = h[0] | (u32)h[1] << 8;
-  if (hsize + 2 > len) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header truncated");
-  P.hh = h[2]; P.hm = h[3]; P.ph = h[4]; P.pm = h[5]; P.n = h[6];
-  if (P.hh > 24 || P.hm > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "H/M of 2^%u/2^%u too large for this engine", P.hh, P.hm);
-  u32 p = 7;
-  for (u32 i = 0; i < P.n; ++i) {
-    if (p >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
-    const u32 t = h[p];
-    if (t < 1 || t > 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "invalid component type %u", t);
-    if (p + kCompSize[t] > hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
-    P.comps.push_back(std::vector<u8>(h + p, h + p + kCompSize[t]));
-    p += kCompSize[t];
-  }
-  if (p + 1 >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP fills the header: no COMP END / HCOMP END");
-  if (h[p++] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing COMP END");
-  if (hsize + 2 < p + 1 || h[hsize + 1] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing HCOMP END");
-  P.hcomp.assign(h + p, h + hsize + 1);
-  return ZPQ_OK;
-}
+typedef zpq_cm_header ParsedHeader;
+#define parse_header zpq_cm_parse_header
 
 const Tables* device_tables(zpq_ctx* ctx) {
   Tables* d = (Tables*)zpq_scratch(ctx, 9, sizeof(Tables));
@@ -951,153 +929,216 @@ const Tables* device_tables(zpq_ctx* ctx) {
   return d;
 }
 
-int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
-  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
-  if (njobs == 0) return ZPQ_OK;
-  hipStream_t st = ctx->stream;
-  const Tables* dT = device_tables(ctx);
-  if (!dT) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm tables");
-  // sizes
-  std::vector<ParsedHeader> ph(njobs);
-  size_t bytes = 0;
-  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  for (size_t i = 0; i < njobs; ++i) {
-    int rc = parse_header(ctx, jobs[i].header, jobs[i].header_len, ph[i]);
-    if (rc) return rc;
-    if (ph[i].n == 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: block has no components (stored mode)", i);
-    bytes += al(ph[i].n * sizeof(Comp)) + al(256 * 4) * 3 + al((size_t)4 << ph[i].hh) + al((size_t)1 << ph[i].hm) + al(ph[i].hcomp.size() + 8);
-    for (auto& c : ph[i].comps) {
-      const u32 sb = c.size() > 1 ? c[1] : 0;
-      switch (c[0]) {
-        case CM: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "CM 2^%u too large", sb); bytes += al((size_t)4 << sb); break;
-        case ICM: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ICM 2^%u too large", sb); bytes += al(1024) + al((size_t)64 << sb); break;
-        case MATCH: if (sb > 28 || c[2] > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MATCH too large"); bytes += al((size_t)4 << sb) + al((size_t)1 << c[2]); break;
-        case MIX2: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX2 too large"); bytes += al((size_t)2 << sb); break;
-        case MIX: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX too large"); bytes += al(((size_t)4 << sb) * c[3]); break;
-        case ISSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ISSE too large"); bytes += al(2048) + al((size_t)64 << sb); break;
-        case SSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "SSE too large"); bytes += al((size_t)128 << sb); break;
-        default: break;
-      }
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Bytes of model state one block needs: what Predictor::init allocates (ZSFX/libzpaq.cpp:1757-1845) plus the HCOMP
+// machine's H and M.  0 + status when a component is larger than this engine supports.
+int model_bytes(zpq_ctx* ctx, const ParsedHeader& P, size_t* big) {
+  size_t bytes = al256((size_t)4 << P.hh) + al256((size_t)1 << P.hm);
+  for (auto& c : P.comps) {
+    const u32 sb = c.size() > 1 ? c[1] : 0;
+    switch (c[0]) {
+      case CM: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "CM 2^%u too large", sb); bytes += al256((size_t)4 << sb); break;
+      case ICM: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ICM 2^%u too large", sb); bytes += al256(1024) + al256((size_t)64 << sb); break;
+      case MATCH: if (sb > 28 || c[2] > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MATCH too large"); bytes += al256((size_t)4 << sb) + al256((size_t)1 << c[2]); break;
+      case MIX2: if (sb > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX2 too large"); bytes += al256((size_t)2 << sb); break;
+      case MIX: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "MIX too large"); bytes += al256(((size_t)4 << sb) * c[3]); break;
+      case ISSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "ISSE too large"); bytes += al256(2048) + al256((size_t)64 << sb); break;
+      case SSE: if (sb > 24) return zpq_fail(ctx, ZPQ_ERR_METHOD, "SSE too large"); bytes += al256((size_t)128 << sb); break;
+      default: break;
     }
   }
-  bytes += al(njobs * sizeof(CmJobDev)) + al(njobs * 8) + al(njobs * 256 * sizeof(InitJob));
-  u8* arena = (u8*)zpq_scratch(ctx, 0, bytes + 4096);
-  if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm model memory (%zu MiB)", bytes >> 20);
-  ZPQ_HIP(ctx, hipMemsetAsync(arena, 0, bytes, st));
-  u8* ap = arena;
-  auto take = [&](size_t x) { u8* r = ap; ap += al(x); return r; };
-  CmJobDev* d_jobs = (CmJobDev*)take(njobs * sizeof(CmJobDev));
-  u32* d_res = (u32*)take(njobs * 8);
-  InitJob* d_init = (InitJob*)take(njobs * 256 * sizeof(InitJob));
-  std::vector<CmJobDev> hj(njobs);
-  std::vector<InitJob> inits;
-  std::vector<std::pair<void*, std::vector<u8>>> uploads;   // small host->device blobs
-  std::vector<std::vector<Comp>> hcomp(njobs);
-  std::vector<std::vector<int>> hp(njobs);
-  for (size_t i = 0; i < njobs; ++i) {
-    ParsedHeader& P = ph[i];
-    CmJobDev& J = hj[i];
-    memset(&J, 0, sizeof J);
+  *big = bytes;
+  return ZPQ_OK;
+}
+// small per-block records (uploaded in one piece): component descriptors for both kernels, p[], h[], R[], the program
+size_t meta_bytes(const ParsedHeader& P) {
+  return al256(P.n * sizeof(Comp)) + al256(P.n * sizeof(zpq_spec_comp)) + al256(256 * 4) * 3 + al256(P.hcomp.size() + 8);
+}
+
+// One batch: blocks idx[0..nb) of jobs[], all resident at once.
+int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>& ph, const size_t* idx, size_t nb, int encode,
+                 const Tables* dT) {
+  hipStream_t st = ctx->stream;
+  size_t ncomp_all = 0;
+  for (size_t k = 0; k < nb; ++k) ncomp_all += ph[idx[k]].n;
+  size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4);
+  size_t big = 0;
+  for (size_t k = 0; k < nb; ++k) {
+    size_t b = 0;
+    int rc = model_bytes(ctx, ph[idx[k]], &b);
+    if (rc) return rc;
+    big += b; meta += meta_bytes(ph[idx[k]]);
+  }
+  u8* arena = (u8*)zpq_scratch(ctx, 0, meta + big + 4096);
+  if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm model memory (%zu MiB)", (meta + big) >> 20);
+  std::vector<u8> hm(meta, 0);                       // host image of the metadata region
+  ZPQ_HIP(ctx, hipMemsetAsync(arena + meta, 0, big, st));
+  size_t mo = 0;
+  u8* bp = arena + meta;
+  auto take_meta = [&](size_t x) { const size_t r = mo; mo += al256(x); return r; };
+  auto take_big = [&](size_t x) { u8* r = bp; bp += al256(x); return r; };
+  const size_t o_jobs = take_meta(nb * sizeof(CmJobDev)), o_sjobs = take_meta(nb * sizeof(zpq_spec_job)), o_res = take_meta(nb * 8),
+               o_init = take_meta(ncomp_all * sizeof(InitJob)), o_cnt = take_meta(nb * 4);
+  CmJobDev* hj = (CmJobDev*)(hm.data() + o_jobs);
+  zpq_spec_job* hs = (zpq_spec_job*)(hm.data() + o_sjobs);
+  InitJob* hinit = (InitJob*)(hm.data() + o_init);
+  size_t ninit = 0;
+  u32* d_res = (u32*)(arena + o_res);
+  for (size_t k = 0; k < nb; ++k) {
+    const size_t i = idx[k];
+    const ParsedHeader& P = ph[i];
+    CmJobDev& J = hj[k];
+    zpq_spec_job& S = hs[k];
     J.n = P.n; J.T = dT;
-    J.comp = (Comp*)take(P.n * sizeof(Comp));
-    J.p = (int*)take(256 * 4); J.h = (u32*)take(256 * 4);
-    J.vm.R = (u32*)take(256 * 4);
-    J.vm.H = (u32*)take((size_t)4 << P.hh); J.vm.hmask = (1u << P.hh) - 1;
-    J.vm.M = (u8*)take((size_t)1 << P.hm); J.vm.mmask = (1u << P.hm) - 1;
-    u8* prog = take(P.hcomp.size() + 8);
-    J.vm.prog = prog; J.vm.plen = (u32)P.hcomp.size();
-    uploads.push_back({prog, P.hcomp});
-    hcomp[i].resize(P.n);
-    hp[i].assign(256, 0);
-    for (u32 k = 0; k < P.n; ++k) {
-      const std::vector<u8>& c = P.comps[k];
-      Comp& C = hcomp[i][k];
-      memset(&C, 0, sizeof C);
+    const size_t o_comp = take_meta(P.n * sizeof(Comp)), o_scomp = take_meta(P.n * sizeof(zpq_spec_comp)), o_p = take_meta(256 * 4),
+                 o_h = take_meta(256 * 4), o_R = take_meta(256 * 4), o_prog = take_meta(P.hcomp.size() + 8);
+    J.comp = (Comp*)(arena + o_comp); J.p = (int*)(arena + o_p); J.h = (u32*)(arena + o_h);
+    J.vm.R = (u32*)(arena + o_R);
+    J.vm.H = (u32*)take_big((size_t)4 << P.hh); J.vm.hmask = (1u << P.hh) - 1;
+    J.vm.M = take_big((size_t)1 << P.hm); J.vm.mmask = (1u << P.hm) - 1;
+    J.vm.prog = arena + o_prog; J.vm.plen = (u32)P.hcomp.size();
+    if (!P.hcomp.empty()) memcpy(hm.data() + o_prog, P.hcomp.data(), P.hcomp.size());
+    Comp* hc = (Comp*)(hm.data() + o_comp);
+    zpq_spec_comp* sc = (zpq_spec_comp*)(hm.data() + o_scomp);
+    int* hp = (int*)(hm.data() + o_p);
+    for (u32 q = 0; q < P.n; ++q) {
+      const std::vector<u8>& c = P.comps[q];
+      Comp& C = hc[q];
       C.type = c[0];
       C.a1 = c.size() > 1 ? c[1] : 0; C.a2 = c.size() > 2 ? c[2] : 0; C.a3 = c.size() > 3 ? c[3] : 0;
       C.a4 = c.size() > 4 ? c[4] : 0; C.a5 = c.size() > 5 ? c[5] : 0;
+      InitJob in; memset(&in, 0, sizeof in); in.T = dT;
       switch (c[0]) {
-        case CONS: hp[i][k] = ((int)c[1] - 128) * 4; break;
+        case CONS: hp[q] = ((int)c[1] - 128) * 4; break;
         case CM:
-          C.cm = (u32*)take((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1; C.limit = c[2] * 4;
-          inits.push_back({CM, C.cm, 1u << c[1], 0, dT, nullptr});
+          C.cm = (u32*)take_big((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1; C.limit = c[2] * 4;
+          in.kind = CM; in.cm = C.cm; in.count = 1u << c[1];
           break;
         case ICM:
           C.limit = 1023;
-          C.cm = (u32*)take(1024); C.cm_mask = 255;
-          C.ht = take((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
-          inits.push_back({ICM, C.cm, 256, 0, dT, nullptr});
+          C.cm = (u32*)take_big(1024); C.cm_mask = 255;
+          C.ht = take_big((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
+          in.kind = ICM; in.cm = C.cm; in.count = 256;
           break;
         case MATCH:
-          C.cm = (u32*)take((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1;
-          C.ht = take((size_t)1 << c[2]); C.ht_mask = (1u << c[2]) - 1;
-          uploads.push_back({C.ht, std::vector<u8>(1, 1)});     // cr.ht(0)=1
+          C.cm = (u32*)take_big((size_t)4 << c[1]); C.cm_mask = (1u << c[1]) - 1;
+          C.ht = take_big((size_t)1 << c[2]); C.ht_mask = (1u << c[2]) - 1;
+          in.kind = MATCH; in.cm = (u32*)C.ht; in.count = 1;                // cr.ht(0)=1
           break;
         case AVG:
-          if (c[1] >= k || c[2] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "AVG input out of range");
+          if (c[1] >= q || c[2] >= q) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "AVG input out of range");
           break;
         case MIX2:
-          if (c[2] >= k || c[3] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX2 input out of range");
+          if (c[2] >= q || c[3] >= q) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX2 input out of range");
           C.c = 1u << c[1];
-          C.a16 = (u16*)take((size_t)2 << c[1]); C.a16_mask = (1u << c[1]) - 1;
-          inits.push_back({MIX2, nullptr, 1u << c[1], 0, dT, C.a16});
+          C.a16 = (u16*)take_big((size_t)2 << c[1]); C.a16_mask = (1u << c[1]) - 1;
+          in.kind = MIX2; in.count = 1u << c[1]; in.a16 = C.a16;
           break;
         case MIX:
-          if (c[2] >= k || c[3] < 1 || c[3] > k - c[2]) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX inputs out of range");
+          if (c[2] >= q || c[3] < 1 || c[3] > q - c[2]) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "MIX inputs out of range");
           C.c = 1u << c[1];
-          C.cm = (u32*)take(((size_t)4 << c[1]) * c[3]); C.cm_mask = 0xffffffffu;
-          inits.push_back({MIX, C.cm, (1u << c[1]) * c[3], c[3], dT, nullptr});
+          C.cm = (u32*)take_big(((size_t)4 << c[1]) * c[3]); C.cm_mask = 0xffffffffu;
+          in.kind = MIX; in.cm = C.cm; in.count = (1u << c[1]) * c[3]; in.arg = c[3];
           break;
         case ISSE:
-          if (c[2] >= k) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "ISSE input out of range");
-          C.ht = take((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
-          C.cm = (u32*)take(2048); C.cm_mask = 511;
-          inits.push_back({ISSE, C.cm, 512, 0, dT, nullptr});
+          if (c[2] >= q) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "ISSE input out of range");
+          C.ht = take_big((size_t)64 << c[1]); C.ht_mask = (64u << c[1]) - 1;
+          C.cm = (u32*)take_big(2048); C.cm_mask = 511;
+          in.kind = ISSE; in.cm = C.cm; in.count = 512;
           break;
         case SSE:
-          if (c[2] >= k || c[3] > c[4] * 4) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "SSE arguments out of range");
-          C.cm = (u32*)take((size_t)128 << c[1]); C.cm_mask = (32u << c[1]) - 1; C.limit = c[4] * 4;
-          inits.push_back({SSE, C.cm, 32u << c[1], c[3], dT, nullptr});
+          if (c[2] >= q || c[3] > c[4] * 4) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "SSE arguments out of range");
+          C.cm = (u32*)take_big((size_t)128 << c[1]); C.cm_mask = (32u << c[1]) - 1; C.limit = c[4] * 4;
+          in.kind = SSE; in.cm = C.cm; in.count = 32u << c[1]; in.arg = c[3];
           break;
         default: break;
       }
+      if (in.kind) hinit[ninit++] = in;
+      zpq_spec_comp& Z = sc[q];
+      Z.cm = (u64)(uintptr_t)(c[0] == MIX2 ? (void*)C.a16 : (void*)C.cm); Z.ht = (u64)(uintptr_t)C.ht;
+      Z.type = C.type; Z.a1 = C.a1; Z.a2 = C.a2; Z.a3 = C.a3; Z.a4 = C.a4; Z.a5 = C.a5;
+      Z.limit = C.limit; Z.cm_mask = C.cm_mask; Z.ht_mask = C.ht_mask; Z.csize = C.c;
     }
     J.dep = 0;
     if (P.n <= 64)
-      for (u32 k = 0; k < P.n; ++k) {
-        const u32 t = P.comps[k][0];
-        if (t == AVG || t == MIX2 || t == MIX || t == ISSE || t == SSE) J.dep |= 1ull << k;
+      for (u32 q = 0; q < P.n; ++q) {
+        const u32 t = P.comps[q][0];
+        if (t == AVG || t == MIX2 || t == MIX || t == ISSE || t == SSE) J.dep |= 1ull << q;
       }
     J.in = jobs[i].d_in; J.in_len = jobs[i].n;
     J.out = jobs[i].d_out; J.out_cap = jobs[i].out_cap;
-    J.result = d_res + 2 * i;
+    J.result = d_res + 2 * k;
+    S.comp = (u64)(uintptr_t)(arena + o_scomp); S.p0 = (u64)(uintptr_t)J.p; S.H = (u64)(uintptr_t)J.vm.H; S.M = (u64)(uintptr_t)J.vm.M;
+    S.R = (u64)(uintptr_t)J.vm.R; S.in = (u64)(uintptr_t)J.in; S.out = (u64)(uintptr_t)J.out; S.result = (u64)(uintptr_t)J.result;
+    S.in_len = J.in_len; S.out_cap = J.out_cap;
   }
-  for (size_t i = 0; i < njobs; ++i) {
-    ZPQ_HIP(ctx, hipMemcpyAsync(hj[i].comp, hcomp[i].data(), hcomp[i].size() * sizeof(Comp), hipMemcpyHostToDevice, st));
-    ZPQ_HIP(ctx, hipMemcpyAsync(hj[i].p, hp[i].data(), 256 * 4, hipMemcpyHostToDevice, st));
+  // which kernel codes which block: blocks sharing a header share one specialised kernel; the rest take the generic ones
+  std::vector<int> group(nb, -1);
+  std::vector<zpq_cm_spec*> gk;
+  std::vector<std::vector<size_t>> members;
+  const bool want_spec = getenv("ZPQ_CM_GENERIC") == nullptr;
+  {
+    std::map<std::string, int> by_header;
+    for (size_t k = 0; k < nb; ++k) {
+      const size_t i = idx[k];
+      if (!want_spec || ph[i].n > 64) continue;
+      const std::string key((const char*)jobs[i].header, (size_t)(2 + (jobs[i].header[0] | jobs[i].header[1] << 8)));
+      auto it = by_header.find(key);
+      if (it == by_header.end()) {
+        zpq_cm_spec* sk = nullptr;
+        int g = -1;
+        if (zpq_cm_spec_get(ctx, ph[i], &sk) == ZPQ_OK && sk) { g = (int)gk.size(); gk.push_back(sk); members.emplace_back(); }
+        else {
+          static bool warned = false;
+          if (!warned) { warned = true; fprintf(stderr, "[zpaqhip] specialised context-mixing coder unavailable (%s): generic kernel used\n", ctx->err.c_str()); }
+        }
+        it = by_header.insert({key, g}).first;
+      }
+      group[k] = it->second;
+      if (group[k] >= 0) members[group[k]].push_back(k);
+    }
   }
-  for (auto& u : uploads)
-    if (!u.second.empty()) ZPQ_HIP(ctx, hipMemcpyAsync(u.first, u.second.data(), u.second.size(), hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), njobs * sizeof(CmJobDev), hipMemcpyHostToDevice, st));
-  if (!inits.empty()) {
-    if (inits.size() > njobs * 256) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many components");
-    ZPQ_HIP(ctx, hipMemcpyAsync(d_init, inits.data(), inits.size() * sizeof(InitJob), hipMemcpyHostToDevice, st));
-    ZPQ_HIP(ctx, hipStreamSynchronize(st));
-    ZPQ_LAUNCH(ctx, "cm_init_kernel", st, cm_init_kernel, dim3(64, (unsigned)inits.size()), dim3(256), d_init);
+  // the specialised kernels take their blocks from a queue: order each group's records contiguously
+  std::vector<zpq_spec_job> ordered;
+  std::vector<size_t> gstart(gk.size() + 1, 0);
+  for (size_t g = 0; g < gk.size(); ++g) {
+    gstart[g] = ordered.size();
+    // longest first: the last block to finish decides the launch
+    std::stable_sort(members[g].begin(), members[g].end(), [&](size_t x, size_t y) { return hs[x].in_len > hs[y].in_len; });
+    for (size_t k : members[g]) ordered.push_back(hs[k]);
+  }
+  gstart[gk.size()] = ordered.size();
+  if (!ordered.empty()) memcpy(hs, ordered.data(), ordered.size() * sizeof(zpq_spec_job));
+  std::vector<CmJobDev> generic;
+  for (size_t k = 0; k < nb; ++k) if (group[k] < 0) generic.push_back(hj[k]);
+  if (!generic.empty()) memcpy(hj, generic.data(), generic.size() * sizeof(CmJobDev));
+  ZPQ_HIP(ctx, hipMemcpyAsync(arena, hm.data(), meta, hipMemcpyHostToDevice, st));
+  for (size_t q = 0; q < ninit; q += 32768) {
+    const size_t m = ninit - q < 32768 ? ninit - q : 32768;
+    ZPQ_LAUNCH(ctx, "cm_init_kernel", st, cm_init_kernel, dim3(64, (unsigned)m), dim3(256), (const InitJob*)(arena + o_init) + q);
     ZPQ_HIP(ctx, hipGetLastError());
   }
-  ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  bool wave_ok = getenv("ZPQ_CM_ONE_LANE") == nullptr;
-  for (size_t i = 0; i < njobs; ++i) {
-    int nm = 0, nsse = 0;
-    for (auto& c : ph[i].comps) { nm += c[0] == MIX; nsse += c[0] == SSE; }
-    if (ph[i].n > 64 || nm > kMaxMix || nsse > kMaxSse) wave_ok = false;
+  for (size_t g = 0; g < gk.size(); ++g) {
+    int rc = zpq_cm_spec_launch(ctx, gk[g], st, arena + o_sjobs + gstart[g] * sizeof(zpq_spec_job), (u32)(gstart[g + 1] - gstart[g]),
+                                (u32*)(arena + o_cnt) + g, dT, encode);
+    if (rc) return rc;
   }
-  if (wave_ok) ZPQ_LAUNCH(ctx, "cm_wave_kernel", st, cm_wave_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
-  else ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)njobs), dim3(64), d_jobs, encode);
-  ZPQ_HIP(ctx, hipGetLastError());
-  std::vector<u32> res(njobs * 2);
-  ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
+  if (!generic.empty()) {
+    bool wave_ok = getenv("ZPQ_CM_ONE_LANE") == nullptr;
+    for (size_t k = 0; k < nb; ++k) {
+      if (group[k] >= 0) continue;
+      int nm = 0, nsse = 0;
+      for (auto& c : ph[idx[k]].comps) { nm += c[0] == MIX; nsse += c[0] == SSE; }
+      if (ph[idx[k]].n > 64 || nm > kMaxMix || nsse > kMaxSse) wave_ok = false;
+    }
+    CmJobDev* d_jobs = (CmJobDev*)(arena + o_jobs);
+    if (wave_ok) ZPQ_LAUNCH(ctx, "cm_wave_kernel", st, cm_wave_kernel, dim3((unsigned)generic.size()), dim3(64), d_jobs, encode);
+    else ZPQ_LAUNCH(ctx, "cm_code_kernel", st, cm_code_kernel, dim3((unsigned)generic.size()), dim3(64), d_jobs, encode);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
+  std::vector<u32> res(nb * 2);
+  ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nb * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   if (getenv("ZPQ_CM_STATS")) {
     unsigned long long c[8] = {0};
@@ -1105,16 +1146,76 @@ int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
     fprintf(stderr, "[cm stats] cumulative cycles: find=%llu loads=%llu leaves=%llu dependents=%llu update=%llu vm=%llu total=%llu bytes=%llu\n",
             c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
   }
-  int first = ZPQ_OK;
-  for (size_t i = 0; i < njobs; ++i) {
-    jobs[i].out_len = res[2 * i];
-    jobs[i].status = (int32_t)res[2 * i + 1];
-    if (jobs[i].status && !first) first = jobs[i].status;
+  for (size_t k = 0; k < nb; ++k) {
+    jobs[idx[k]].out_len = res[2 * k];
+    jobs[idx[k]].status = (int32_t)res[2 * k + 1];
   }
+  return ZPQ_OK;
+}
+
+int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
+  if (njobs == 0) return ZPQ_OK;
+  const Tables* dT = device_tables(ctx);
+  if (!dT) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm tables");
+  std::vector<ParsedHeader> ph(njobs);
+  std::vector<size_t> need(njobs);
+  for (size_t i = 0; i < njobs; ++i) {
+    int rc = parse_header(ctx, jobs[i].header, jobs[i].header_len, ph[i]);
+    if (rc) return rc;
+    if (ph[i].n == 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: block has no components (stored mode)", i);
+    size_t b = 0;
+    rc = model_bytes(ctx, ph[i], &b);
+    if (rc) return rc;
+    need[i] = b + meta_bytes(ph[i]) + 4096;
+  }
+  // as many blocks side by side as the models fit into what is free now (less a reserve), batch after batch
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  size_t budget = free_b + ctx->scratch_cap[0];
+  budget = budget > total_b / 10 ? budget - total_b / 10 : budget / 2;
+  if (const char* e = getenv("ZPQ_CM_BUDGET_MB")) budget = (size_t)atoll(e) << 20;
+  std::vector<size_t> order(njobs);
+  for (size_t i = 0; i < njobs; ++i) order[i] = i;
+  size_t at = 0;
+  while (at < njobs) {
+    size_t sum = 0, nb = 0;
+    while (at + nb < njobs && nb < 16384 && (nb == 0 || sum + need[order[at + nb]] <= budget)) sum += need[order[at + nb++]];
+    int rc = run_cm_batch(ctx, jobs, ph, order.data() + at, nb, encode, dT);
+    if (rc) return rc;
+    at += nb;
+  }
+  int first = ZPQ_OK;
+  for (size_t i = 0; i < njobs; ++i) if (jobs[i].status && !first) first = jobs[i].status;
   return first;
 }
 
 }  // namespace
+
+// Block header bytes starting at hsize[2] (ZPAQL::read, ZSFX/libzpaq.cpp:879-921)
+int zpq_cm_parse_header(zpq_ctx* ctx, const u8* h, u32 len, zpq_cm_header& P) {
+  static const int kCompSz[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};   // ZSFX/libzpaq.cpp:706
+  if (len < 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header too short");
+  const u32 hsize = h[0] | (u32)h[1] << 8;
+  if (hsize + 2 > len) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "header truncated");
+  P.hh = h[2]; P.hm = h[3]; P.ph = h[4]; P.pm = h[5]; P.n = h[6];
+  P.comps.clear(); P.hcomp.clear();
+  if (P.hh > 24 || P.hm > 28) return zpq_fail(ctx, ZPQ_ERR_METHOD, "H/M of 2^%u/2^%u too large for this engine", P.hh, P.hm);
+  u32 p = 7;
+  for (u32 i = 0; i < P.n; ++i) {
+    if (p >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
+    const u32 t = h[p];
+    if (t < 1 || t > 9) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "invalid component type %u", t);
+    if (p + kCompSz[t] > hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP overflows header");
+    P.comps.push_back(std::vector<u8>(h + p, h + p + kCompSz[t]));
+    p += kCompSz[t];
+  }
+  if (p + 1 >= hsize + 2) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "COMP fills the header: no COMP END / HCOMP END");
+  if (h[p++] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing COMP END");
+  if (hsize + 2 < p + 1 || h[hsize + 1] != 0) return zpq_fail(ctx, ZPQ_ERR_FORMAT, "missing HCOMP END");
+  P.hcomp.assign(h + p, h + hsize + 1);
+  return ZPQ_OK;
+}
 
 extern "C" {
 

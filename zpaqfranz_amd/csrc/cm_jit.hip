@@ -1,0 +1,346 @@
+// Run-time specialisation of the context-mixing coder (rows a12, a14): for one block header -- component list +
+// HCOMP bytecode -- generate HIP source (cm_spec_src.inc with a prelude of lane masks / X-macro lists and the
+// HCOMP program translated to straight-line code), compile it with hiprtc for gfx950 and keep the module.
+// This is the engine's counterpart of libzpaq's two x86 JITs (ZPAQL::assemble ZSFX/libzpaq.cpp:2709-3488,
+// Predictor::assemble_p :3489-4261); like them it changes speed only: the semantics are the interpreters'
+// (ZPAQL::run0 :1033-1254, Predictor::predict0/update0 :1846-2058), and tests compare with those.
+// Code objects are cached per process and, keyed by a hash of the generated source, on disk next to the library
+// (zpaqfranz_amd/jit_cache, or $ZPQ_JIT_CACHE), so that a header is compiled once per installation.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <mutex>
+
+#include "zpq_internal.h"
+
+namespace {
+
+const char* kSpecSrc =
+#include "cm_spec_src.inc"
+    ;
+
+enum { NONE = 0, CONS, CM, ICM, MATCH, AVG, MIX2, MIX, ISSE, SSE };
+
+std::string itos(long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); return b; }
+std::string hex64(u64 v) { char b[32]; snprintf(b, sizeof b, "0x%llxull", (unsigned long long)v); return b; }
+
+// ZPAQL bytecode -> straight-line device code.  Every jump target of ZPAQL is static (JT/JF/JMP are relative to the
+// instruction, LJ is absolute), so each reachable instruction start becomes a label; a jump into the middle of another
+// instruction is decoded from there like the interpreter would (the worklist follows every target).
+std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pcomp) {
+  const u32 n = (u32)code.size();
+  auto at = [&](u32 i) -> u32 { return i < n ? code[i] : 0u; };
+  std::map<u32, std::string> stmt;      // pc -> statement(s), ending in a goto
+  std::vector<u32> work;
+  work.push_back(0);
+  const std::string Mb = "M[b & ZMMASK]", Mc = "M[c & ZMMASK]", Hd = "H[d & ZHMASK]";
+  auto go = [&](u32 from, u32 target) -> std::string {
+    if (target >= n) return "goto Lerr;";
+    work.push_back(target);
+    // a loop needs a jump to a lower (or the same) address: those are counted, so that no program spins forever
+    if (target <= from) return "{ if (++guard > ZGUARD) goto Lerr; goto L" + itos(target) + "; }";
+    return "goto L" + itos(target) + ";";
+  };
+  while (!work.empty()) {
+    const u32 pc = work.back(); work.pop_back();
+    if (pc >= n || stmt.count(pc)) continue;
+    const u32 op = code[pc];
+    const u32 len = op == 255 ? 3 : (op & 7) == 7 ? 2 : 1;
+    const u32 nxt = pc + len;
+    const u32 N = at(pc + 1);
+    std::string s;
+    bool falls = true;
+    if (op == 56) { s = "goto Lend;"; falls = false; }
+    else if (op == 255) { s = go(pc, N + 256 * at(pc + 2)); falls = false; }
+    else if (op == 39 || op == 47 || op == 63) {
+      const u32 tgt = nxt + (((N + 128) & 255) - 128);          // may wrap below 0: then >= n, an error
+      if (op == 63) { s = go(pc, tgt); falls = false; }
+      else s = std::string(op == 39 ? "if (f) " : "if (!f) ") + go(pc, tgt);
+    } else if (op >= 64 && op < 240 && (op < 120 || op >= 128)) {
+      const u32 sel = op & 7, grp = op >> 3;
+      static const char* srcs[7] = {"a", "b", "c", "d", nullptr, nullptr, nullptr};
+      std::string v;
+      if (sel < 4) v = srcs[sel];
+      else if (sel == 4) v = "(u32)" + Mb;
+      else if (sel == 5) v = "(u32)" + Mc;
+      else if (sel == 6) v = Hd;
+      else v = itos(N) + "u";
+      switch (grp) {
+        case 8: s = "a = " + v + ";"; break;
+        case 9: s = "b = " + v + ";"; break;
+        case 10: s = "c = " + v + ";"; break;
+        case 11: s = "d = " + v + ";"; break;
+        case 12: s = Mb + " = (u8)(" + v + ");"; break;
+        case 13: s = Mc + " = (u8)(" + v + ");"; break;
+        case 14: s = Hd + " = " + v + ";"; break;
+        case 16: s = "a += " + v + ";"; break;
+        case 17: s = "a -= " + v + ";"; break;
+        case 18: s = "a *= " + v + ";"; break;
+        case 19: s = "t = " + v + "; a = t ? a / t : 0u;"; break;
+        case 20: s = "t = " + v + "; a = t ? a % t : 0u;"; break;
+        case 21: s = "a &= " + v + ";"; break;
+        case 22: s = "a &= ~(" + v + ");"; break;
+        case 23: s = "a |= " + v + ";"; break;
+        case 24: s = "a ^= " + v + ";"; break;
+        case 25: s = "a <<= ((" + v + ") & 31);"; break;
+        case 26: s = "a >>= ((" + v + ") & 31);"; break;
+        case 27: s = "f = a == " + v + ";"; break;
+        case 28: s = "f = a < " + v + ";"; break;
+        case 29: s = "f = a > " + v + ";"; break;
+        default: s = "goto Lerr;"; falls = false; break;
+      }
+    } else {
+      auto reg = [&](u32 g) -> std::string { static const char* r[4] = {"a", "b", "c", "d"}; return r[g]; };
+      const u32 g = op >> 3, k = op & 7;
+      if (op < 56 && g < 4 && k >= 1 && k <= 4) {                 // X++ X-- X! X=0 on A B C D
+        const std::string x = reg(g);
+        s = k == 1 ? "++" + x + ";" : k == 2 ? "--" + x + ";" : k == 3 ? x + " = ~" + x + ";" : x + " = 0;";
+      } else if (op < 56 && g >= 1 && g < 4 && k == 0) {          // X<>A
+        const std::string x = reg(g);
+        s = "t = a; a = " + x + "; " + x + " = t;";
+      } else if (op < 32 && k == 7) {                             // X=R N
+        s = reg(g) + " = R[" + itos(N) + "];";
+      } else if (op == 32 || op == 40) {                          // *B<>A, *C<>A: the low byte of A only
+        const std::string x = op == 32 ? Mb : Mc;
+        s = "t = " + x + "; " + x + " = (u8)a; a = (a & 0xffffff00u) | t;";
+      } else if ((g == 4 || g == 5) && k >= 1 && k <= 4) {
+        const std::string x = g == 4 ? Mb : Mc;
+        s = k == 1 ? "++" + x + ";" : k == 2 ? "--" + x + ";" : k == 3 ? x + " = (u8)~" + x + ";" : x + " = 0;";
+      } else if (op == 48) s = "t = " + Hd + "; " + Hd + " = a; a = t;";
+      else if (g == 6 && k >= 1 && k <= 4) s = k == 1 ? "++" + Hd + ";" : k == 2 ? "--" + Hd + ";" : k == 3 ? Hd + " = ~" + Hd + ";" : Hd + " = 0;";
+      else if (op == 55) s = "R[" + itos(N) + "] = a;";
+      else if (op == 57) s = is_pcomp ? "ZOUT(a);" : ";";         // OUT: HCOMP has no output stream
+      else if (op == 59) s = "a = (a + (u32)" + Mb + " + 512u) * 773u;";
+      else if (op == 60) s = Hd + " = (" + Hd + " + a + 512u) * 773u;";
+      else { s = "goto Lerr;"; falls = false; }
+    }
+    if (falls) s += " " + go(pc, nxt);
+    stmt[pc] = s;
+  }
+  std::string out = std::string("ZDEV void ") + fname + "(const u32 input, ZVm& z, g_u8* const M, g_u32* const R, const zh_ptr H) {\n";
+  out += "  u32 a = input, b = z.b, c = z.c, d = z.d, f = z.f, t = 0, guard = 0; (void)t; (void)guard;\n";
+  out += n ? "  goto L0;\n" : "  goto Lerr;\n";
+  for (auto& kv : stmt) out += "L" + itos(kv.first) + ": " + kv.second + "\n";
+  out += "Lerr: z.err = 1;\nLend: z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;\n}\n";
+  return out;
+}
+
+u64 fnv64(const std::string& s) {
+  u64 h = 1469598103934665603ull;
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_dir() {
+  const char* e = getenv("ZPQ_JIT_CACHE");
+  if (e && *e) return e;
+  Dl_info di;
+  if (dladdr((const void*)&fnv64, &di) && di.dli_fname) {
+    std::string p = di.dli_fname;
+    const size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
+  }
+  return "/tmp/zpq_jit_cache";
+}
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+void write_file_atomic(const std::string& dir, const std::string& path, const std::vector<char>& data) {
+  (void)mkdir(dir.c_str(), 0755);
+  const std::string tmp = path + ".tmp" + itos((long long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+  fclose(f);
+  if (ok) (void)rename(tmp.c_str(), path.c_str()); else (void)unlink(tmp.c_str());
+}
+
+struct Compiled { std::vector<char> code; std::string log; };
+std::mutex g_mu;
+std::map<u64, Compiled> g_code;                        // source hash -> code object (any device: all gfx950)
+std::map<std::pair<int, u64>, zpq_cm_spec*> g_mods;    // (device, source hash) -> loaded module
+
+}  // namespace
+
+struct zpq_cm_spec {
+  hipModule_t mod;
+  hipFunction_t enc, dec;
+  u32 waves;          // ZW the module was compiled for (workgroup = waves * 64 threads at most)
+  bool h_lds;
+};
+
+// The generated source for one header (also used by the build-time cache warmer and the tests).
+int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* why) {
+  if (P.n < 1 || P.n > 64) { *why = "more than 64 components"; return ZPQ_ERR_METHOD; }
+  u64 mask[10] = {0};
+  std::string mixes, sses, chain;
+  int nmix = 0, nsse = 0;
+  for (u32 i = 0; i < P.n; ++i) {
+    const std::vector<u8>& c = P.comps[i];
+    const u32 t = c[0];
+    if (t < 1 || t > 9) { *why = "invalid component"; return ZPQ_ERR_FORMAT; }
+    mask[t] |= 1ull << i;
+    const std::string I = itos(i);
+    switch (t) {
+      case ISSE: chain += "Z_ISSE(" + I + "," + itos(c[2]) + ") "; break;
+      case AVG: chain += "Z_AVG(" + I + "," + itos(c[1]) + "," + itos(c[2]) + "," + itos(c[3]) + ") "; break;
+      case MIX2: chain += "Z_MIX2(" + I + "," + itos(c[2]) + "," + itos(c[3]) + ") "; break;
+      case MIX:
+        mixes += "X(" + itos(nmix) + "," + I + "," + itos(c[2]) + "," + itos(c[3]) + "," + itos(c[4]) + ") ";
+        chain += "Z_MIX(" + itos(nmix) + "," + I + "," + itos(c[2]) + "," + itos(c[3]) + ") ";
+        ++nmix;
+        break;
+      case SSE:
+        sses += "X(" + itos(nsse) + "," + I + "," + itos(c[2]) + ") ";
+        chain += "Z_SSE(" + itos(nsse) + "," + I + "," + itos(c[2]) + ") ";
+        ++nsse;
+        break;
+      default: break;
+    }
+  }
+  if (nmix > 8 || nsse > 4) { *why = "more mixers / SSE stages than the wave coder keeps in registers"; return ZPQ_ERR_METHOD; }
+  const bool h_lds = P.hh <= 10;
+  // waves per workgroup: the tables (86 KiB) are shared, H[] is per wave; one workgroup per compute unit
+  u32 waves = 16;
+  while (waves > 1 && 88064u + (h_lds ? waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
+  std::string s;
+  s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
+  s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
+  s += "#define ZGUARD (1u << 26)\n";
+  static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
+  for (int t = 1; t <= 9; ++t) s += std::string("#define ZM_") + names[t] + " " + hex64(mask[t]) + "\n";
+  s += "#define Z_FOR_MIX(X) " + mixes + "\n#define Z_FOR_SSE(X) " + sses + "\n#define Z_CHAIN " + chain + "\n";
+  std::string body = kSpecSrc;
+  const std::string marker = "//@@HCOMP@@";
+  const size_t k = body.find(marker);
+  if (k == std::string::npos) { *why = "template marker missing"; return ZPQ_ERR_ARG; }
+  body.replace(k, marker.size(), gen_zpaql(P.hcomp, "z_hcomp", false));
+  *src = s + body;
+  return ZPQ_OK;
+}
+
+// Compiles (or fetches from the caches) the code object for a source text.
+static int compile_source(zpq_ctx* ctx, const std::string& src, u64 key, const Compiled** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_code.find(key);
+  if (it != g_code.end()) { *out = &it->second; return ZPQ_OK; }
+  Compiled c;
+  const std::string dir = cache_dir();
+  char name[64];
+  snprintf(name, sizeof name, "/cm_%016llx.hsaco", (unsigned long long)key);
+  const std::string path = dir + name;
+  if (!getenv("ZPQ_JIT_NOCACHE") && read_file(path, c.code)) {
+    *out = &(g_code[key] = std::move(c));
+    return ZPQ_OK;
+  }
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "cm_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return zpq_fail(ctx, ZPQ_ERR_HIP, "hiprtcCreateProgram failed");
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-Wno-unused-variable"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  size_t ls = 0;
+  (void)hiprtcGetProgramLogSize(prog, &ls);
+  if (ls > 1) { c.log.resize(ls); (void)hiprtcGetProgramLog(prog, &c.log[0]); }
+  if (r != HIPRTC_SUCCESS) {
+    (void)hiprtcDestroyProgram(&prog);
+    if (getenv("ZPQ_JIT_DUMP")) { FILE* f = fopen("/tmp/zpq_cm_failed.hip", "w"); if (f) { fputs(src.c_str(), f); fclose(f); } }
+    fprintf(stderr, "[zpaqhip] hiprtc failed on the generated context-mixing kernel (%s):\n%.4000s\n", hiprtcGetErrorString(r), c.log.c_str());
+    return zpq_fail(ctx, ZPQ_ERR_HIP, "hiprtc: %s: %.400s", hiprtcGetErrorString(r), c.log.c_str());
+  }
+  size_t cs = 0;
+  (void)hiprtcGetCodeSize(prog, &cs);
+  c.code.resize(cs);
+  (void)hiprtcGetCode(prog, c.code.data());
+  (void)hiprtcDestroyProgram(&prog);
+  if (!getenv("ZPQ_JIT_NOCACHE")) write_file_atomic(dir, path, c.code);
+  *out = &(g_code[key] = std::move(c));
+  return ZPQ_OK;
+}
+
+int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out) {
+  *out = nullptr;
+  std::string src, why;
+  int rc = zpq_cm_spec_source(P, &src, &why);
+  if (rc) return zpq_fail(ctx, rc, "specialised coder: %s", why.c_str());
+  const u64 key = fnv64(src);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_mods.find({ctx->device, key});
+    if (it != g_mods.end()) { *out = it->second; return ZPQ_OK; }
+  }
+  const Compiled* c = nullptr;
+  rc = compile_source(ctx, src, key, &c);
+  if (rc) return rc;
+  zpq_cm_spec* k = new zpq_cm_spec();
+  if (hipModuleLoadData(&k->mod, c->code.data()) != hipSuccess) { delete k; return zpq_fail(ctx, ZPQ_ERR_HIP, "hipModuleLoadData failed for the specialised coder"); }
+  if (hipModuleGetFunction(&k->enc, k->mod, "cm_spec_encode") != hipSuccess || hipModuleGetFunction(&k->dec, k->mod, "cm_spec_decode") != hipSuccess) {
+    (void)hipModuleUnload(k->mod); delete k;
+    return zpq_fail(ctx, ZPQ_ERR_HIP, "specialised coder: kernels missing from the module");
+  }
+  k->h_lds = P.hh <= 10;
+  k->waves = 16;
+  while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto ins = g_mods.insert({{ctx->device, key}, k});
+  if (!ins.second) { (void)hipModuleUnload(k->mod); delete k; }
+  *out = ins.first->second;
+  return ZPQ_OK;
+}
+
+u32 zpq_cm_spec_waves(const zpq_cm_spec* k) { return k->waves; }
+
+int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void* d_jobs, u32 njobs, u32* d_counter, const void* d_tables,
+                       int encode) {
+  // one workgroup per compute unit (the tables fill more than half of its LDS); as many waves per workgroup as it
+  // takes to seat every block, at most what the module was compiled for
+  const u32 cus = (u32)ctx->cu_count;
+  u32 w = (njobs + cus - 1) / cus;
+  if (w < 1) w = 1;
+  if (w > k->waves) w = k->waves;
+  u32 grid = (njobs + w - 1) / w;
+  if (grid > cus) grid = cus;
+  void* args[] = {(void*)&d_jobs, (void*)&njobs, (void*)&d_counter, (void*)&d_tables};
+  ZpqProfScope prof(ctx, encode ? "cm_spec_encode" : "cm_spec_decode", st);
+  ZPQ_HIP(ctx, hipModuleLaunchKernel(encode ? k->enc : k->dec, grid, 1, 1, w * 64, 1, 1, 0, st, args, nullptr));
+  return ZPQ_OK;
+}
+
+// Host-only: generates and compiles the kernels for a header into the on-disk cache (no GPU needed: hiprtc
+// cross-compiles).  Used by the build step so that a GPU box starts with the common models ready.
+extern "C" int zpq_cm_precompile(const uint8_t* header, uint32_t header_len) {
+  zpq_cm_header P;
+  int rc = zpq_cm_parse_header(nullptr, header, header_len, P);
+  if (rc) return rc;
+  std::string src, why;
+  rc = zpq_cm_spec_source(P, &src, &why);
+  if (rc) return rc;
+  const Compiled* c = nullptr;
+  return compile_source(nullptr, src, fnv64(src), &c);
+}
+
+// Diagnostic: the generated source text for a header (tests compile and inspect it).
+extern "C" int zpq_cm_spec_source_text(const uint8_t* header, uint32_t header_len, char* out, size_t cap, size_t* len) {
+  zpq_cm_header P;
+  int rc = zpq_cm_parse_header(nullptr, header, header_len, P);
+  if (rc) return rc;
+  std::string src, why;
+  rc = zpq_cm_spec_source(P, &src, &why);
+  if (rc) return rc;
+  if (len) *len = src.size();
+  if (src.size() + 1 > cap) return ZPQ_ERR_CAPACITY;
+  memcpy(out, src.c_str(), src.size() + 1);
+  return ZPQ_OK;
+}

@@ -126,6 +126,25 @@ int zpq_e8e9_forward_launch(zpq_ctx* ctx, hipStream_t st, u8* d_buf, size_t n, u
 // (config.hip; host_data is only read for level 5)
 int zpq_build_config(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, std::string* xmethod, int args[9],
                      std::vector<u8>* header, std::vector<u8>* pcomp);
+// ---- context mixing: parsed block header and the run-time specialised coder (cm.hip, cm_jit.hip) -----------------
+struct zpq_cm_header {
+  u32 hh, hm, ph, pm, n;
+  std::vector<std::vector<u8>> comps;   // type + arguments per component
+  std::vector<u8> hcomp;                // program bytes (without the closing 0)
+};
+// header = hsize[2] hh hm ph pm n COMP 0 HCOMP 0 (ZPAQL::read, ZSFX/libzpaq.cpp:879-921); ctx may be NULL
+int zpq_cm_parse_header(zpq_ctx* ctx, const u8* h, u32 len, zpq_cm_header& P);
+struct zpq_cm_spec;                     // kernels compiled for one header on one device
+int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* why);
+int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out);
+u32 zpq_cm_spec_waves(const zpq_cm_spec* k);
+int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void* d_jobs, u32 njobs, u32* d_counter, const void* d_tables,
+                       int encode);
+// device-side records of the specialised coder (layout shared with cm_spec_src.inc)
+struct zpq_spec_comp { u64 cm, ht; u32 type, a1, a2, a3, a4, a5, limit, cm_mask, ht_mask, csize, pad0, pad1; };
+struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap, pad0, pad1; };
+static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 80, "layout shared with the generated kernels");
+
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests);
