@@ -17,16 +17,17 @@ data = [b"\0" + (datagen.text_like if k % 2 else datagen.mixed)(size, 7 + k % 13
 src, args = engine.make_config(engine.expand_method(method, data[0]))
 h = engine.compile_config(src, args)[0]
 e = Engine(0)
+print('engine up', flush=True)
 e.profile(True)
 t = time.time()
 enc = e.cm_code([h] * nb, data, [len(x) + 4096 for x in data], encode=True)
 t1 = time.time() - t
-print("encode report:", e.profile_report().strip().replace("\n", " | "))
+print("encode report:", e.profile_report())
 assert all(s == 0 for s, _ in enc)
 t = time.time()
 dec = e.cm_code([h] * nb, [g for _, g in enc], [len(x) + 16 for x in data], encode=False)
 t2 = time.time() - t
-print("decode report:", e.profile_report().strip().replace("\n", " | "))
+print("decode report:", e.profile_report())
 assert all(s == 0 and b == x for (s, b), x in zip(dec, data))
 tot = sum(len(x) for x in data)
 print("method %s n=%d components, %d blocks x %d B: encode %.3f s (%.3f MB/s), decode %.3f s (%.3f MB/s), ratio %.3f" %

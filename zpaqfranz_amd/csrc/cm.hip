@@ -15,6 +15,8 @@
 // register slots for.  Measured split and next steps: DESIGN.md section 7-2.
 #include <math.h>
 #include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <map>
@@ -960,6 +962,10 @@ size_t meta_bytes(const ParsedHeader& P) {
 int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>& ph, const size_t* idx, size_t nb, int encode,
                  const Tables* dT) {
   hipStream_t st = ctx->stream;
+  const bool trace = getenv("ZPQ_CM_TRACE") != nullptr;
+  auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+  const double t_begin = now();
+  auto stage = [&](const char* what) { if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[cm trace] %-28s %.3f s\n", what, now() - t_begin); } };
   size_t ncomp_all = 0;
   for (size_t k = 0; k < nb; ++k) ncomp_all += ph[idx[k]].n;
   size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4);
@@ -972,8 +978,10 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   }
   u8* arena = (u8*)zpq_scratch(ctx, 0, meta + big + 4096);
   if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "cm model memory (%zu MiB)", (meta + big) >> 20);
+  stage("arena");
   std::vector<u8> hm(meta, 0);                       // host image of the metadata region
   ZPQ_HIP(ctx, hipMemsetAsync(arena + meta, 0, big, st));
+  stage("memset");
   size_t mo = 0;
   u8* bp = arena + meta;
   auto take_meta = [&](size_t x) { const size_t r = mo; mo += al256(x); return r; };
@@ -1113,12 +1121,14 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   std::vector<CmJobDev> generic;
   for (size_t k = 0; k < nb; ++k) if (group[k] < 0) generic.push_back(hj[k]);
   if (!generic.empty()) memcpy(hj, generic.data(), generic.size() * sizeof(CmJobDev));
+  stage("kernels ready");
   ZPQ_HIP(ctx, hipMemcpyAsync(arena, hm.data(), meta, hipMemcpyHostToDevice, st));
   for (size_t q = 0; q < ninit; q += 32768) {
     const size_t m = ninit - q < 32768 ? ninit - q : 32768;
     ZPQ_LAUNCH(ctx, "cm_init_kernel", st, cm_init_kernel, dim3(64, (unsigned)m), dim3(256), (const InitJob*)(arena + o_init) + q);
     ZPQ_HIP(ctx, hipGetLastError());
   }
+  stage("tables initialised");
   for (size_t g = 0; g < gk.size(); ++g) {
     int rc = zpq_cm_spec_launch(ctx, gk[g], st, arena + o_sjobs + gstart[g] * sizeof(zpq_spec_job), (u32)(gstart[g + 1] - gstart[g]),
                                 (u32*)(arena + o_cnt) + g, dT, encode);
@@ -1138,8 +1148,25 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
     ZPQ_HIP(ctx, hipGetLastError());
   }
   std::vector<u32> res(nb * 2);
+  if (const char* wd = getenv("ZPQ_CM_WATCHDOG")) {
+    // diagnostic: give the coders wd seconds, then report how far each block got (the kernels store their byte
+    // position in result[0] as they go when built with progress marks) and give up on the process
+    const double limit = atof(wd), t0 = now();
+    while (hipStreamQuery(st) == hipErrorNotReady && now() - t0 < limit) usleep(20000);
+    if (hipStreamQuery(st) == hipErrorNotReady) {
+      hipStream_t s2; (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+      (void)hipMemcpyAsync(res.data(), d_res, nb * 8, hipMemcpyDeviceToHost, s2);
+      (void)hipStreamSynchronize(s2);
+      fprintf(stderr, "[cm watchdog] still running after %.1f s; progress words:", limit);
+      for (size_t k = 0; k < nb && k < 16; ++k) fprintf(stderr, " %u/%u", res[2 * k], res[2 * k + 1]);
+      fprintf(stderr, "\n");
+      fflush(stderr);
+      _exit(3);
+    }
+  }
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nb * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  if (trace) fprintf(stderr, "[cm trace] %zu blocks (%zu specialised groups, %zu generic), %zu MiB of models: coded after %.3f s\n", nb, gk.size(), generic.size(), big >> 20, now() - t_begin);
   if (getenv("ZPQ_CM_STATS")) {
     unsigned long long c[8] = {0};
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cm_prof), sizeof c);

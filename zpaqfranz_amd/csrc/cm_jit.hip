@@ -220,6 +220,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
   s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
   s += "#define ZGUARD (1u << 26)\n";
+  if (getenv("ZPQ_CM_PROGRESS")) s += "#define ZPROGRESS 1\n";
   static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
   for (int t = 1; t <= 9; ++t) s += std::string("#define ZM_") + names[t] + " " + hex64(mask[t]) + "\n";
   s += "#define Z_FOR_MIX(X) " + mixes + "\n#define Z_FOR_SSE(X) " + sses + "\n#define Z_CHAIN " + chain + "\n";
