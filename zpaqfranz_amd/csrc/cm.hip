@@ -968,7 +968,8 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   auto stage = [&](const char* what) { if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[cm trace] %-28s %.3f s\n", what, now() - t_begin); } };
   size_t ncomp_all = 0;
   for (size_t k = 0; k < nb; ++k) ncomp_all += ph[idx[k]].n;
-  size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4);
+  const bool want_prof = getenv("ZPQ_CM_PROF") != nullptr;
+  size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4) + al256(nb * 64);
   size_t big = 0;
   for (size_t k = 0; k < nb; ++k) {
     size_t b = 0;
@@ -987,7 +988,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   auto take_meta = [&](size_t x) { const size_t r = mo; mo += al256(x); return r; };
   auto take_big = [&](size_t x) { u8* r = bp; bp += al256(x); return r; };
   const size_t o_jobs = take_meta(nb * sizeof(CmJobDev)), o_sjobs = take_meta(nb * sizeof(zpq_spec_job)), o_res = take_meta(nb * 8),
-               o_init = take_meta(ncomp_all * sizeof(InitJob)), o_cnt = take_meta(nb * 4);
+               o_init = take_meta(ncomp_all * sizeof(InitJob)), o_cnt = take_meta(nb * 4), o_prof = take_meta(nb * 64);
   CmJobDev* hj = (CmJobDev*)(hm.data() + o_jobs);
   zpq_spec_job* hs = (zpq_spec_job*)(hm.data() + o_sjobs);
   InitJob* hinit = (InitJob*)(hm.data() + o_init);
@@ -1080,6 +1081,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
     S.comp = (u64)(uintptr_t)(arena + o_scomp); S.p0 = (u64)(uintptr_t)J.p; S.H = (u64)(uintptr_t)J.vm.H; S.M = (u64)(uintptr_t)J.vm.M;
     S.R = (u64)(uintptr_t)J.vm.R; S.in = (u64)(uintptr_t)J.in; S.out = (u64)(uintptr_t)J.out; S.result = (u64)(uintptr_t)J.result;
     S.in_len = J.in_len; S.out_cap = J.out_cap;
+    S.prof = want_prof ? (u64)(uintptr_t)(arena + o_prof + 64 * k) : 0;
   }
   // which kernel codes which block: blocks sharing a header share one specialised kernel; the rest take the generic ones
   std::vector<int> group(nb, -1);
@@ -1167,6 +1169,14 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nb * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   if (trace) fprintf(stderr, "[cm trace] %zu blocks (%zu specialised groups, %zu generic), %zu MiB of models: coded after %.3f s\n", nb, gk.size(), generic.size(), big >> 20, now() - t_begin);
+  if (want_prof) {
+    std::vector<unsigned long long> pr(nb * 8);
+    ZPQ_HIP(ctx, hipMemcpy(pr.data(), arena + o_prof, nb * 64, hipMemcpyDeviceToHost));
+    unsigned long long t[8] = {0}, bytes = 0;
+    for (size_t k = 0; k < nb; ++k) { for (int q = 0; q < 8; ++q) t[q] += pr[8 * k + q]; bytes += encode ? jobs[idx[k]].n : res[2 * k]; }
+    if (bytes) fprintf(stderr, "[cm prof] cycles per byte: find %.0f | addresses+loads %.0f | leaves %.0f | chain %.0f | update %.0f | byte boundary %.0f | squash+coder %.0f | total %.0f (%llu bytes)\n",
+            (double)t[0] / bytes, (double)t[1] / bytes, (double)t[2] / bytes, (double)t[3] / bytes, (double)t[4] / bytes, (double)t[5] / bytes, (double)t[6] / bytes, (double)t[7] / bytes, bytes);
+  }
   if (getenv("ZPQ_CM_STATS")) {
     unsigned long long c[8] = {0};
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cm_prof), sizeof c);

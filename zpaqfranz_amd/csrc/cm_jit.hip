@@ -186,8 +186,15 @@ struct zpq_cm_spec {
 int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* why) {
   if (P.n < 1 || P.n > 64) { *why = "more than 64 components"; return ZPQ_ERR_METHOD; }
   u64 mask[10] = {0};
-  std::string mixes, sses, chain;
+  std::string mixes, sses, chain, far_inputs, mix2_updates;
   int nmix = 0, nsse = 0;
+  // ISSEs fed by their left neighbour are evaluated as a group (one DPP shift per link); anything else that depends
+  // on earlier components closes the group first
+  u64 group = 0; u32 depth_of[64] = {0}, group_depth = 0;
+  auto flush_group = [&]() {
+    if (group) chain += "Z_ISSE_SYS(" + hex64(group) + "," + itos(group_depth) + ") ";
+    group = 0; group_depth = 0;
+  };
   for (u32 i = 0; i < P.n; ++i) {
     const std::vector<u8>& c = P.comps[i];
     const u32 t = c[0];
@@ -195,15 +202,31 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
     mask[t] |= 1ull << i;
     const std::string I = itos(i);
     switch (t) {
-      case ISSE: chain += "Z_ISSE(" + I + "," + itos(c[2]) + ") "; break;
-      case AVG: chain += "Z_AVG(" + I + "," + itos(c[1]) + "," + itos(c[2]) + "," + itos(c[3]) + ") "; break;
-      case MIX2: chain += "Z_MIX2(" + I + "," + itos(c[2]) + "," + itos(c[3]) + ") "; break;
+      case ISSE:
+        if (i > 0 && c[2] == i - 1) {
+          depth_of[i] = (group >> (i - 1) & 1) ? depth_of[i - 1] + 1 : 1;
+          group |= 1ull << i;
+          if (depth_of[i] > group_depth) group_depth = depth_of[i];
+        } else {
+          flush_group();
+          chain += "Z_ISSE(" + I + "," + itos(c[2]) + ") ";
+          far_inputs += "{ const int q_ = rl(p, " + itos(c[2]) + "); ZWL(q_, " + I + ", pin); } ";
+        }
+        break;
+      case AVG: flush_group(); chain += "Z_AVG(" + I + "," + itos(c[1]) + "," + itos(c[2]) + "," + itos(c[3]) + ") "; break;
+      case MIX2:
+        flush_group();
+        chain += "Z_MIX2(" + I + "," + itos(c[2]) + "," + itos(c[3]) + ") ";
+        mix2_updates += "Z_MIX2_UPD(" + I + "," + itos(c[2]) + "," + itos(c[3]) + "," + itos(c[4]) + ") ";
+        break;
       case MIX:
+        flush_group();
         mixes += "X(" + itos(nmix) + "," + I + "," + itos(c[2]) + "," + itos(c[3]) + "," + itos(c[4]) + ") ";
         chain += "Z_MIX(" + itos(nmix) + "," + I + "," + itos(c[2]) + "," + itos(c[3]) + ") ";
         ++nmix;
         break;
       case SSE:
+        flush_group();
         sses += "X(" + itos(nsse) + "," + I + "," + itos(c[2]) + ") ";
         chain += "Z_SSE(" + itos(nsse) + "," + I + "," + itos(c[2]) + ") ";
         ++nsse;
@@ -211,6 +234,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
       default: break;
     }
   }
+  flush_group();
   if (nmix > 8 || nsse > 4) { *why = "more mixers / SSE stages than the wave coder keeps in registers"; return ZPQ_ERR_METHOD; }
   const bool h_lds = P.hh <= 10;
   // waves per workgroup: the tables (86 KiB) are shared, H[] is per wave; one workgroup per compute unit
@@ -224,6 +248,8 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
   for (int t = 1; t <= 9; ++t) s += std::string("#define ZM_") + names[t] + " " + hex64(mask[t]) + "\n";
   s += "#define Z_FOR_MIX(X) " + mixes + "\n#define Z_FOR_SSE(X) " + sses + "\n#define Z_CHAIN " + chain + "\n";
+  s += "#define Z_ISSE_FAR_INPUTS " + far_inputs + "\n#define Z_MIX2_UPDATES " + mix2_updates + "\n";
+  if (getenv("ZPQ_CM_PROF")) s += "#define ZPROF 1\n";
   std::string body = kSpecSrc;
   const std::string marker = "//@@HCOMP@@";
   const size_t k = body.find(marker);

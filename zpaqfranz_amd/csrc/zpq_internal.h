@@ -142,7 +142,7 @@ int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void*
                        int encode);
 // device-side records of the specialised coder (layout shared with cm_spec_src.inc)
 struct zpq_spec_comp { u64 cm, ht; u32 type, a1, a2, a3, a4, a5, limit, cm_mask, ht_mask, csize, pad0, pad1; };
-struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap, pad0, pad1; };
+struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap; u64 prof; };
 static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 80, "layout shared with the generated kernels");
 
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
