@@ -746,6 +746,156 @@ def main_text_m2(a, rank, world, local, dev):
         e_.close()
 
 
+def main_cm_m5(a, rank, world, local, dev):
+    """Context-mixing stress ("-m3/-m4 runs to stress context mixing"; north_star: one wavefront per
+    ZPAQ block, thousands of blocks in flight): `--cm-blocks` blocks of `--cm-block-bytes` of text per GPU through
+    compressBlock at level 5 -- Predictor (22 components: ICM/ISSE chains, MATCH, three mixers, SSE) + arithmetic coder +
+    HCOMP per byte, one wave per block, all blocks resident at once (90 MB of model state each).  Blocks are independent:
+    no collective on the data path; weak scaling."""
+    from zpaqfranz_amd import Engine, engine as E
+    nb, bs = a.cm_blocks, a.cm_block_bytes
+    eng = Engine(local)
+    blocks = text_blocks_dev(dev, nb * bs, rank, block=bs)
+    assert len(blocks) == nb
+    total = sum(n for _, n in blocks)
+    # what compressBlock's "50" (level 5, blocks up to 1 MiB) expands to for this data (level 5 looks at the data to add
+    # models for periodic structure: text has none, checked for every block outside the timed region); passing the
+    # expansion itself keeps that host-side analysis out of the measured step
+    first = bytes(blocks[0][0][: blocks[0][1]].cpu().numpy())
+    xm = E.expand_method("50", first)
+    src, args = E.make_config(xm)
+    header = E.compile_config(src, args)[0]
+    method = xm.encode()
+    caps = [(eng.block_bound(n, b"", b"") + 63) & ~63 for _, n in blocks]
+    outs = torch.zeros(sum(caps), dtype=torch.uint8, device=dev)
+    jobs = (E.BlockJob * nb)()
+    p_out, offs = 0, []
+    for k, (t, n) in enumerate(blocks):
+        jobs[k].in_ = t.data_ptr(); jobs[k].n = n; jobs[k].method = method
+        jobs[k].filename = b""; jobs[k].comment = b""; jobs[k].dosha1 = 1
+        jobs[k].out = outs.data_ptr() + p_out; jobs[k].out_cap = caps[k]
+        offs.append(p_out); p_out += caps[k]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def step():
+        eng.compress_blocks_dev(jobs, nb)
+        bad = [k for k in range(nb) if jobs[k].status != 0]
+        if bad:
+            raise RuntimeError("compressBlock failed for block %d: status %d" % (bad[0], jobs[bad[0]].status))
+        return sum(jobs[k].out_len for k in range(nb))
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+    steps = a.steps if a.steps is not None else 2
+    warm = a.warmup if a.warmup is not None else 1
+    for _ in range(warm):
+        step()
+    eng.profile(not a.no_kernel_timing)
+    barrier()
+    t0 = time.perf_counter()
+    out_bytes = 0
+    for _ in range(steps):
+        out_bytes = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = eng.profile_report()
+    eng.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
+        tsum = torch.tensor([float(out_bytes)], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax.item()); out_bytes = int(tsum.item())
+    if rank == 0:
+        sec = dt / steps
+        k_ms = kern.get("cm_spec_encode", kern.get("cm_wave_kernel", (1, 0.0)))
+        per = k_ms[1] / max(1, k_ms[0])
+        ach = (total + out_bytes / world) / 1e9 / (per / 1e3) if per else 0.0
+        res = {"metric": "MB/s compressed output at -m5 (context mixing: 22-component Predictor + arithmetic coder), %d blocks of %d KiB of text per GPU" % (nb, bs >> 10),
+               "value": round(out_bytes / 1e6 / sec, 3), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm,
+               "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": "synthetic",
+               "config": {"workload": "cm_m5", "input_bytes": total * world, "blocks": nb * world, "block_bytes": bs,
+                          "method": "50 -> " + xm, "components": header[6], "ratio": round(out_bytes / (total * world), 4)},
+               "input_MBps": round(total * world / 1e6 / sec, 3),
+               "blocks_in_flight_per_gpu": nb, "waves_per_simd": round(nb / 1024.0, 2),
+               "input_KBps_per_block": round(total / nb / 1e3 / (per / 1e3), 1) if per else None,
+               "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               "roofline": {"bound": "hbm", "kernel": "cm_spec_encode", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(per, 3),
+                            "launches_per_step": round(k_ms[0] / steps, 2), "algorithmic_bytes_per_step": int(total + out_bytes / world),
+                            "note": "one serial chain of bit decisions per block (a wave each): bounded by instruction issue and dependent "
+                                    "table lookups, not by HBM bytes (1 B read + r B written per input byte)"}}
+        if world == 1 and not a.no_verify:
+            # (1) every framed block back through the device decoder (context-model decode + stored SHA-1), bytes compared
+            uj = (E.UnblockJob * nb)()
+            back = torch.zeros(nb * (bs + 64), dtype=torch.uint8, device=dev)
+            for k in range(nb):
+                uj[k].in_ = outs.data_ptr() + offs[k]; uj[k].n = jobs[k].out_len
+                uj[k].out = back.data_ptr() + k * (bs + 64); uj[k].out_cap = blocks[k][1] + 64
+            t1 = time.perf_counter()
+            eng.decompress_blocks_dev(uj, nb, True)
+            torch.cuda.synchronize()
+            res["decode_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+            bad = [(k, int(uj[k].status)) for k in range(nb)
+                   if not (uj[k].status == 0 and uj[k].out_len == blocks[k][1] and
+                           bool(torch.equal(back[k * (bs + 64): k * (bs + 64) + blocks[k][1]], blocks[k][0][: blocks[k][1]])))]
+            res["verified_roundtrip_all_blocks"] = not bad
+            if bad:
+                res["roundtrip_failures"] = bad[:8]
+            del back
+            # (2) the expansion of "50" is the same for every block (no periodic models found anywhere)
+            same = all(E.expand_method("50", bytes(t[:n].cpu().numpy())) == xm for t, n in blocks[:: max(1, nb // 64)])
+            res["method_expansion_checked"] = bool(same)
+        if world == 1 and not a.no_cpu_baseline:
+            # the reference Predictor (x86 JIT) + mirrored Encoder on every host core over a bounded sample of the same
+            # blocks; every sampled code stream is compared with the one inside the GPU's framed block
+            sample = min(nb, a.cm_cpu_sample)
+            blob = b"".join(bytes(t[:n].cpu().numpy()) for t, n in blocks[:sample])
+            fr = b"".join(bytes(outs[offs[k]: offs[k] + jobs[k].out_len].cpu().numpy()) for k in range(sample))
+            cb = cpu_baseline("cm", [bs, json.dumps([jobs[k].out_len for k in range(sample)]), header.hex(), nb], [blob, fr])
+            if "identical_blocks" in cb:
+                res["verified_blocks_vs_reference_coder"] = cb.pop("identical_blocks")
+                res["verified_all_sampled_blocks"] = res["verified_blocks_vs_reference_coder"] == "%d of %d" % (sample, sample)
+            res["cpu_baseline"] = cb
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    eng.close()
+
+
+def run_other_workloads(a):
+    """dup8_m1 (config 4 at 1-GPU size), extract_m1 (config 5), text_m2 (config 3) and cm_m5 (context-mixing stress), each
+    as `bench.py --workload X` in a fresh process with its default size; returns {workload: its JSON line or an error}."""
+    import subprocess
+    out = {}
+    budget = float(os.environ.get("ZPQ_BENCH_OTHERS_S", "1200"))
+    t_all = time.time()
+    for w in ("extract_m1", "text_m2", "cm_m5", "dup8_m1"):
+        left = budget - (time.time() - t_all)
+        if left < 60:
+            out[w] = {"skipped": "time budget for the nested workloads used up"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--gpus", "1"]
+        if a.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                out[w] = json.loads(lines[-1])
+                out[w]["wall_s"] = round(time.time() - t0, 1)
+            else:
+                out[w] = {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
+        except subprocess.TimeoutExpired:
+            out[w] = {"error": "timed out after %.0f s" % left}
+    return out
+
+
 def cpu_baseline(mode, argv, blobs):
     """Runs tests/cpu_baseline.py (the reference's own code on all host cores) in a fresh process and returns its JSON."""
     import subprocess
@@ -772,7 +922,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="silesia_x256_m1", choices=["silesia_x256_m1", "dup8_m1", "extract_m1", "text_m2"])
+    ap.add_argument("--workload", default=None, choices=["all", "silesia_x256_m1", "dup8_m1", "extract_m1", "text_m2", "cm_m5"],
+                    help="default: silesia_x256_m1 (BASELINE config 2) as the headline, then -- single GPU only -- every other workload "
+                         "in its own process, nested under 'workloads' in the one JSON line")
+    ap.add_argument("--cm-blocks", type=int, default=2048, help="cm_m5: blocks per GPU (one wave each, all resident at once)")
+    ap.add_argument("--cm-block-bytes", type=int, default=256 << 10, help="cm_m5: bytes per block")
+    ap.add_argument("--cm-cpu-sample", type=int, default=192, help="cm_m5: blocks the CPU baseline codes (and compares)")
     ap.add_argument("--text-bytes", type=int, default=10 ** 9, help="text_m2: bytes of text per GPU (enwik9 is 10^9)")
     ap.add_argument("--copies", type=int, default=256, help="corpus replication factor (256 = BASELINE config)")
     ap.add_argument("--units", type=int, default=1024, help="dup8_m1: unique 16 MiB units per GPU")
@@ -788,6 +943,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
     a = ap.parse_args()
+    run_all = a.workload in (None, "all")
+    if run_all:
+        a.workload = "silesia_x256_m1"
     if os.environ.get("ZPQ_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack and exit if the run takes too long
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ZPQ_BENCH_WATCHDOG"]), exit=True)
@@ -811,6 +969,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     if a.workload == "text_m2":
         return main_text_m2(a, rank, world, local, dev)
+    if a.workload == "cm_m5":
+        return main_cm_m5(a, rank, world, local, dev)
     steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
@@ -937,7 +1097,7 @@ def main():
             alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": pipe.total - chain_bytes, "gather_kernel": pipe.total + ub,
                    "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
             waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": pipe.nfiles}
-            alg_step = pipe.arc_bytes + 3 * pipe.total  # r bytes read + 1 byte written + 1 byte read back for SHA-256, + the copy's read
+            alg_step = pipe.arc_bytes + 2 * pipe.total  # r bytes read + 1 byte written per restored byte + 1 byte read back for SHA-256
             metric = "MB/s compressed archive input extracted + verified (SHA-1 per fragment, SHA-256 per file), Silesia x%d -m1" % a.copies
         else:
             in_bytes = pipe.total * world
@@ -947,7 +1107,7 @@ def main():
             alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
                    "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
             waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)), "lz77_direct_kernel": st["blocks"]}
-            alg_step = 2 * pipe.total + 2 * (ub // max(1, world)) + out_bytes // max(1, world)   # per rank: fragment pass + hash pass + gather/LZ/checksum of unique bytes + output
+            alg_step = pipe.total + ub // max(1, world) + out_bytes // max(1, world)   # SURVEY 8(d), per rank: every input byte read once + the unique bytes into the compressor + the output
             metric = ("MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x%d" % a.copies) if a.workload == "silesia_x256_m1" else \
                      ("MB/s compressed output (bit-identical .zpaq) at -m1, %d unique 16 MiB units x%d duplication per GPU" % (a.units, a.dup))
         traffic = {}
@@ -990,7 +1150,7 @@ def main():
                "roofline": roof_dom, "roofline_all": roof_all,
                "roofline_end_to_end": {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 5),
                                        "algorithmic_bytes_per_step": int(alg_step),
-                                       "note": "whole step (algorithmic bytes / ms_per_step); the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
+                                       "note": "whole step: SURVEY 8(d) algorithmic bytes (input once + unique + output; extract: r + 1 + 1) / ms_per_step; the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
         if extract:
             res["sha256_mismatches"] = pipe.sha256_mismatches
         threads = min(32, len(os.sched_getaffinity(0)))
@@ -1030,6 +1190,18 @@ def main():
                 index = dict(block_off=boff, block_usize=ex.usize, frag_block=ublk.tolist(),
                              frag_off=(upos - np.array(ex.plain_off)[ublk]).tolist(), frag_len=ulen.tolist(), members=members, copies=a.copies)
                 res["cpu_baseline"] = cpu_baseline("extract", [], [blocks_blob, json.dumps(index).encode()])
+        if run_all and world == 1 and not a.force_collectives:
+            # the other BASELINE configs, each in its own process (its own HIP context and memory), after this one has
+            # given the device back; their JSON lines nest under "workloads" (the headline stays config 2)
+            for e_ in engines:
+                e_.close()
+            engines.clear()
+            pipes.clear(); runners.clear(); last_pipe.clear()
+            pipe = layout = ex_pipe = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            res["workloads"] = run_other_workloads(a)
         print(json.dumps(res))
     if a.dump_archive and rank == 0 and a.workload != "extract_m1":
         if world > 1:

@@ -12,6 +12,10 @@ the oracle.  One worker thread per usable core -- `zpaqfranz -tN` -- the C calls
                                                              method 2 ("x6,1,4,0,7,27,1"): divsufsort + LZBuffer + SHA1 of
                                                              every block; the code streams are compared with the ones
                                                              inside the GPU's framed blocks (outside the timed part)
+  cpu_baseline.py cm <text file> <framed file> <block bytes> <framed lengths json> <header hex> <blocks of the full job>
+                                                             context mixing: the reference Predictor (x86 JIT) + mirrored
+                                                             Encoder + SHA1 over a bounded sample of the job's blocks; code
+                                                             streams compared with the GPU's (outside the timed part)
   cpu_baseline.py extract <blocks file> <index file>         d blocks decoded, fragments verified (SHA-1), files
                                                              assembled and hashed (SHA-256)
 Prints one JSON object."""
@@ -121,6 +125,37 @@ def main():
                "sample": "bounded sample = %d of the workload's %d unique 16 MiB units, same x%d duplication, %d threads: fragment loop + "
                          "libzpaq::SHA1 over %.1f GB in %.1f s, LZBuffer + SHA1 of %d blocks in %.1f s (rates scale with the unit count)"
                          % (units, full_units, dup, cores, total_in / 1e9, t_fh, len(blocks), t_c)}
+    elif mode == "cm":
+        text = open(sys.argv[2], "rb").read()
+        framed = open(sys.argv[3], "rb").read()
+        bs = int(sys.argv[4]); flens = json.loads(sys.argv[5]); header = bytes.fromhex(sys.argv[6]); full = int(sys.argv[7])
+        nb = len(flens)
+        if kind != "reference":
+            raise SystemExit("cm baseline needs oracle/_ref (the real Predictor)")
+
+        def one(k):
+            x = text[k * bs: (k + 1) * bs]
+            orc.ref_sha1(x)
+            return orc.ref_cm_encode(header, b"\0" + x)
+        with ThreadPoolExecutor(cores) as ex:
+            one(0)                                                   # tables built, JIT emitted
+            t0 = time.time()
+            streams = list(ex.map(one, range(nb)))
+            tot = time.time() - t0
+        same, o = 0, 0
+        for k in range(nb):
+            fr = framed[o: o + flens[k]]; o += flens[k]
+            kz = fr.index(b"zPQ"); p = kz + 5
+            p += 2 + (fr[p] | fr[p + 1] << 8)                       # header
+            p += 1                                                   # segment marker
+            p = fr.index(b"\0", p) + 1; p = fr.index(b"\0", p) + 1; p += 1   # filename, comment, reserved
+            same += fr[p: len(fr) - 22] == streams[k]
+        out = sum(len(x) for x in streams)
+        res = {"value": round(out / 1e6 / tot, 3), "unit": "MB/s compressed output", "cores": cores, "kind": kind,
+               "input_MBps": round(len(text) / 1e6 / tot, 3), "seconds": round(tot, 2), "identical_blocks": "%d of %d" % (same, nb),
+               "sample": "bounded sample = the first %d of the job's %d blocks (%d KiB each), %d threads: reference Predictor (x86 JIT build of "
+                         "ZSFX/libzpaq.cpp) + mirrored Encoder + libzpaq::SHA1 per block, %.1f MB in %.1f s"
+                         % (nb, full, bs >> 10, cores, len(text) / 1e6, tot)}
     elif mode == "m2":
         text = open(sys.argv[2], "rb").read()
         framed = open(sys.argv[3], "rb").read()

@@ -103,3 +103,61 @@ def test_hcomp_endless_loop_is_stopped(eng):
     h = _raw_header(2, 4, [(2, 16, 255)], [63, 254])
     (st, _), = eng.cm_code([h], [b"\0abcdef"], [256], encode=True)
     assert st == -6
+
+
+def _fixture_dblock():
+    arc = open(os.path.join(G, "sha256.zpaq"), "rb").read()
+    blk = json.load(open(os.path.join(G, "blocks.json")))[1]
+    raw = arc[blk["offset"]: blk["offset"] + blk["size"]]
+    hs = 13 + 5
+    hsize = raw[hs] | raw[hs + 1] << 8
+    header = raw[hs: hs + 2 + hsize]
+    p = hs + 2 + hsize + 1
+    p = raw.index(b"\0", p) + 1      # filename
+    p = raw.index(b"\0", p) + 1      # comment
+    p += 1                           # reserved
+    return arc, header, raw[p: len(raw) - 22]     # ... 00 00 00 00 | fd sha1[20] ff
+
+
+def test_reference_archive_in_full_both_directions():
+    """The reference's own interoperability fixture (AUTOTEST/README.txt:1-40): AUTOTEST/sha256.zpaq, written by
+    zpaqfranz -m5 on Windows.  (a) Jidac extract on the GPU returns 256 files whose SHA-256 are their names -- the
+    reference's autotest criterion -- and `t` verifies every stored XXHASH64 / CRC-32; (b) the d block's 9 473 560
+    bytes of plaintext code to exactly the archive's 121 236 bytes (23 components, 171-byte HCOMP).  The two
+    directions run side by side on two contexts."""
+    import hashlib
+    import threading
+    from zpaqfranz_amd import Engine, engine as E
+    arc, header, coded = _fixture_dblock()
+    plain = lzma.decompress(open(os.path.join(G, "dblock_plain.xz"), "rb").read())
+    assert header[6] == 23 and len(coded) == 121236 and len(plain) == 9473560
+    res = {}
+
+    def encode():
+        e = Engine(0)
+        try:
+            res["enc"] = e.cm_code([header], [b"\0" + plain], [len(coded) + 4096], encode=True)[0]
+        finally:
+            e.close()
+
+    def extract():
+        e = Engine(0)
+        try:
+            res["files"] = E.jidac_extract(e, arc)
+            res["verify"] = E.jidac_verify(e, arc)
+        finally:
+            e.close()
+
+    ts = [threading.Thread(target=encode), threading.Thread(target=extract)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    st, got = res["enc"]
+    assert st == 0 and got == coded
+    files = res["files"]
+    assert len(files) == 256
+    for name, data in files.items():
+        assert len(data) == 37000
+        assert hashlib.sha256(data).hexdigest().upper() == os.path.basename(name).upper()[:64], name
+    rc, stats = res["verify"]
+    assert rc == 0 and stats["files"] == 256 and stats["xxh64_mismatches"] == 0 and stats["crc32_mismatches"] == 0
+    assert stats["files_with_checksums"] == 256

@@ -505,31 +505,60 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
       if (dj[k].status != ZPQ_OK) { jobs[dj_job[k]].status = dj[k].status; jobs[dj_job[k]].out_len = 0; if (!first_err) first_err = dj[k].status; }
     }
   }
-  // generic blocks: [context-model decode] -> post-processor preamble -> PASS / LZ77 fast path / ZPAQL VM
+  // generic blocks: [context-model decode] -> post-processor preamble -> PASS / LZ77 fast path / ZPAQL VM.
+  // Every arithmetic-coded block of the call is decoded by ONE zpq_cm_decode_dev call: blocks sharing a header share
+  // one specialised kernel and run side by side, a wave each (cm.hip).
+  std::vector<u8*> dec_at(njobs, nullptr);
+  std::vector<u32> dec_len_of(njobs, 0);
+  {
+    size_t total = 0;
+    std::vector<size_t> off(njobs, 0);
+    for (size_t i = 0; i < njobs; ++i) {
+      if (jobs[i].status != ZPQ_OK || ps[i].kind != 3) continue;
+      const size_t dcap = (size_t)jobs[i].out_cap + 65536 + 64;
+      off[i] = total;
+      total += ((dcap + 255) & ~(size_t)255) + ((ps[i].payload.size() + 128 + 255) & ~(size_t)255);
+    }
+    u8* d_all = total ? (u8*)zpq_scratch(ctx, 10, total + 256) : nullptr;
+    if (total && !d_all) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+    std::vector<zpq_cm_job> cj; std::vector<size_t> cj_job;
+    for (size_t i = 0; i < njobs; ++i) {
+      if (jobs[i].status != ZPQ_OK || ps[i].kind != 3) continue;
+      Parsed& P = ps[i];
+      const size_t dcap = (size_t)jobs[i].out_cap + 65536 + 64;
+      dec_at[i] = d_all + off[i];
+      if (P.ncomp) {
+        u8* d_coded = dec_at[i] + ((dcap + 255) & ~(size_t)255);
+        ZPQ_HIP(ctx, hipMemcpyAsync(d_coded, P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
+        zpq_cm_job c;
+        memset(&c, 0, sizeof c);
+        c.header = P.header.data(); c.header_len = (u32)P.header.size();
+        c.d_in = d_coded; c.n = (u32)P.payload.size(); c.d_out = dec_at[i]; c.out_cap = (u32)dcap;
+        cj.push_back(c); cj_job.push_back(i);
+      } else if (P.payload.size() > dcap) {
+        jobs[i].status = ZPQ_ERR_CAPACITY; jobs[i].out_len = 0; if (!first_err) first_err = ZPQ_ERR_CAPACITY;
+      } else {
+        ZPQ_HIP(ctx, hipMemcpyAsync(dec_at[i], P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
+        dec_len_of[i] = (u32)P.payload.size();
+      }
+    }
+    if (!cj.empty()) {
+      ZPQ_HIP(ctx, hipStreamSynchronize(st));
+      const int rc = zpq_cm_decode_dev(ctx, cj.data(), cj.size());
+      for (size_t k = 0; k < cj.size(); ++k) {
+        const size_t i = cj_job[k];
+        if (cj[k].status || (rc && rc != ZPQ_ERR_FORMAT && rc != ZPQ_ERR_CAPACITY)) {
+          jobs[i].status = cj[k].status ? cj[k].status : rc; jobs[i].out_len = 0; if (!first_err) first_err = jobs[i].status;
+        } else dec_len_of[i] = cj[k].out_len;
+      }
+    }
+  }
   for (size_t i = 0; i < njobs; ++i) {
     if (jobs[i].status != ZPQ_OK || ps[i].kind != 3) continue;
     Parsed& P = ps[i];
     auto fail_job = [&](int code) { jobs[i].status = code; jobs[i].out_len = 0; if (!first_err) first_err = code; };
-    const size_t dcap = (size_t)jobs[i].out_cap + 65536 + 64;
-    u8* d_dec = (u8*)zpq_scratch(ctx, 10, dcap + (P.ncomp ? P.payload.size() + 128 : 0) + 256);
-    if (!d_dec) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
-    u32 dec_len = 0;
-    if (P.ncomp) {
-      u8* d_coded = d_dec + ((dcap + 255) & ~(size_t)255);
-      ZPQ_HIP(ctx, hipMemcpyAsync(d_coded, P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
-      ZPQ_HIP(ctx, hipStreamSynchronize(st));
-      zpq_cm_job cj;
-      memset(&cj, 0, sizeof cj);
-      cj.header = P.header.data(); cj.header_len = (u32)P.header.size();
-      cj.d_in = d_coded; cj.n = (u32)P.payload.size(); cj.d_out = d_dec; cj.out_cap = (u32)dcap;
-      int rc = zpq_cm_decode_dev(ctx, &cj, 1);
-      if (rc || cj.status) { fail_job(cj.status ? cj.status : rc); continue; }
-      dec_len = cj.out_len;
-    } else {
-      if (P.payload.size() > dcap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
-      ZPQ_HIP(ctx, hipMemcpyAsync(d_dec, P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
-      dec_len = (u32)P.payload.size();
-    }
+    u8* d_dec = dec_at[i];
+    const u32 dec_len = dec_len_of[i];
     if (dec_len < 1) { fail_job(ZPQ_ERR_FORMAT); continue; }
     u8 pre[3] = {0, 0, 0};
     ZPQ_HIP(ctx, hipMemcpyAsync(pre, d_dec, dec_len < 3 ? dec_len : 3, hipMemcpyDeviceToHost, st));
