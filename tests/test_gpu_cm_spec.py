@@ -130,7 +130,7 @@ def test_reference_archive_in_full_both_directions():
     from zpaqfranz_amd import Engine, engine as E
     arc, header, coded = _fixture_dblock()
     plain = lzma.decompress(open(os.path.join(G, "dblock_plain.xz"), "rb").read())
-    assert header[6] == 23 and len(coded) == 121236 and len(plain) == 9473560
+    assert header[6] == 23 and len(coded) == 121236 + 4 and coded[-4:] == b"\0\0\0\0" and len(plain) == 9473560   # + the four 0 bytes after the end-of-segment symbol
     res = {}
 
     def encode():
