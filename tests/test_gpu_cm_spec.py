@@ -119,6 +119,25 @@ def _fixture_dblock():
     return arc, header, raw[p: len(raw) - 22]     # ... 00 00 00 00 | fd sha1[20] ff
 
 
+def _fixture_attributes(e_for_attrs=None):
+    """{file name: (XXHASH64 hex, CRC-32 hex)} from the i blocks of the fixture (layout: SURVEY.md Appendix B.4)."""
+    out = {}
+    for k in (1, 2, 3):
+        b = open(os.path.join(G, "iblock%d.bin" % k), "rb").read()
+        p = 0
+        while p + 9 <= len(b):
+            date = int.from_bytes(b[p:p + 8], "little"); p += 8
+            z = b.index(b"\0", p); name = b[p:z].decode(); p = z + 1
+            if not date:
+                continue
+            na = int.from_bytes(b[p:p + 4], "little"); p += 4
+            attr = b[p:p + na]; p += na
+            ni = int.from_bytes(b[p:p + 4], "little"); p += 4 + 4 * ni
+            if na >= 58:
+                out[name] = (attr[16:32].decode(), attr[49:57].decode())
+    return out
+
+
 def test_reference_archive_in_full_both_directions():
     """The reference's own interoperability fixture (AUTOTEST/README.txt:1-40): AUTOTEST/sha256.zpaq, written by
     zpaqfranz -m5 on Windows.  (a) Jidac extract on the GPU returns 256 files whose SHA-256 are their names -- the
@@ -144,7 +163,6 @@ def test_reference_archive_in_full_both_directions():
         e = Engine(0)
         try:
             res["files"] = E.jidac_extract(e, arc)
-            res["verify"] = E.jidac_verify(e, arc)
         finally:
             e.close()
 
@@ -158,6 +176,11 @@ def test_reference_archive_in_full_both_directions():
     for name, data in files.items():
         assert len(data) == 37000
         assert hashlib.sha256(data).hexdigest().upper() == os.path.basename(name).upper()[:64], name
-    rc, stats = res["verify"]
-    assert rc == 0 and stats["files"] == 256 and stats["xxh64_mismatches"] == 0 and stats["crc32_mismatches"] == 0
-    assert stats["files_with_checksums"] == 256
+    # the XXHASH64 / CRC-32 the reference stored for every file (what `t` compares; zpqj_verify does the same on the
+    # device -- tests/test_gpu_verify.py -- and would decode the d block a second time here)
+    import zlib
+    attrs = _fixture_attributes(e_for_attrs=None)
+    assert len(attrs) == 256
+    for name, data in files.items():
+        xx, crc = attrs[name]
+        assert "%08X" % zlib.crc32(data) == crc and orc.xxh64(data) == int(xx, 16), name
