@@ -148,7 +148,9 @@ typedef struct zpq_lz77_job {
 } zpq_lz77_job;
 size_t zpq_lz77_bound(size_t n);
 int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs);
-/* Inverse (what the level-1 PCOMP does): d_in/n = code stream, rb = max(args[0]-4,0). */
+/* Inverse (what the level-1 PCOMP does): d_in/n = code stream, rb = max(args[0]-4,0).  With bit 31 of rb set the stream
+ * holds LZBuffer's byte-aligned codes (level 2, ZSFX/libzpaq.cpp:6221-6224) and the low byte of rb is the minimum match
+ * length (args[2]): what the level-2 post-processor of methods 3 and 4 undoes. */
 typedef struct zpq_lz77_dec_job {
   const uint8_t* d_in;
   uint32_t n;

@@ -104,9 +104,20 @@ def test_level5_without_data_is_an_error_not_a_crash(cfg):
 
 
 def test_unpinned_preprocessors_are_refused(cfg):
-    for m in ("x4,2,4,0,3,24", "x4,3ci1", "x4,4ci1", "x4,6,12,0,7,25,1c0,0,511i2", "q1"):
+    # BWT + E8E9 above 16 MiB blocks (post-processor not restated) and strings that are no method at all
+    for m in ("x5,7ci1", "q1"):
         with pytest.raises(cfg.ConfigRefused):
             cfg.make_config(m)
+
+
+@needs_ref
+@pytest.mark.parametrize("method", ["x4,2,12,0,7,25,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,7ci1", "x6,3ci1", "x4,4ci1,1,1,1,2a",
+                                    "x0,2,4,0,7,21,1c0,0,511,1256i2"])
+def test_level2_level3_configs_compile_like_the_reference_compiler(cfg, method):
+    """Levels 2 / 3 / E8E9-only (served since round 3): the generated config source -- HCOMP with the LZ77 parse-state
+    prelude, the post-processor programs -- goes through the REAL reference Compiler and must give our bytes."""
+    src, args = cfg.make_config(method)
+    assert cfg.compile_config(src, args) == ref_compiled(src, args)
 
 
 METHODS = [LEVEL5, "x4,1,5,0,3,24", "x6,1,4,0,2,26", "x7,5,6,0,3,27", "x2,0ci1,1,1,1,2am", "x2,0ci1,1,1,1,2awm", "x0,0w2c0,1010,255i1c256ci1,1,1,1,1,1,2ac0,0,1009,255i1c0,10i1c0,2,0,255i1mm16ts19t0",

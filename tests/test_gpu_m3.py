@@ -1,0 +1,102 @@
+"""Rows a5 / f4: compressBlock at level 3 and the explicit x,2 / x,3 / x,4 methods -- byte-aligned LZ77 over the suffix
+array, the Burrows-Wheeler transform and E8E9 in front of a context model.  Their post-processor programs have no byte
+fixture in the reference tree; they are pinned by DECODE parity: the REAL reference Decompresser (oracle/_ref,
+ZSFX/libzpaq.cpp:2239-2366 with its PostProcessor / ZPAQL machine) restores every block this engine writes, stored SHA-1
+verified; the pre-processed stream inside equals the REAL LZBuffer's (:6140-6552); and the engine's own decode side
+(native level-2 decoder, inverse BWT by list ranking, E8E9 inverse, or the translated program) gives the input back."""
+import numpy as np
+import pytest
+
+import datagen
+import orc
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from zpaqfranz_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def exe_like(n, seed):
+    a = bytearray(datagen.binary_like(n, seed))
+    rng = np.random.default_rng(seed)
+    for p in rng.integers(0, n - 8, n // 40):
+        a[p] = 0xE8 if p & 2 else 0xE9
+        a[p + 4] = 0 if p & 1 else 0xFF
+    return bytes(a)
+
+
+METHODS = ["34", "34,200,1", "34,170,2", "34,30,0", "x4,2,12,0,7,25,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,7ci1",
+           "x4,4ci1,1,1,1,2a", "44,160,2", "x0,3ci1", "x6,3ci1"]
+
+
+def _coded_payload(framed):
+    k = framed.index(b"zPQ"); p = k + 5
+    header = framed[p: p + 2 + (framed[p] | framed[p + 1] << 8)]
+    p += len(header) + 1
+    p = framed.index(b"\0", p) + 1; p = framed.index(b"\0", p) + 1; p += 1
+    return header, framed[p: len(framed) - 22]
+
+
+@needs_ref
+@pytest.mark.parametrize("method", METHODS)
+def test_reference_decompresser_restores_and_stream_equals_lzbuffer(eng, method):
+    from zpaqfranz_amd import engine as E
+    n = 120000
+    exe = ",2" in method[2:] and method[0] in "34" or method.startswith(("x4,6", "x4,7", "x4,4"))
+    blocks = [exe_like(n, 3) if exe else datagen.text_like(n, 4), datagen.mixed(n // 2, 5), b"", b"q"]
+    res = eng.compress_blocks(blocks, [method] * len(blocks), ["f%d" % i for i in range(len(blocks))], ["c"] * len(blocks), True)
+    for b, (st, framed) in zip(blocks, res):
+        assert st == 0
+        r = orc.ref_decompress_block(framed, len(b) + 64)                 # the REAL Decompresser + PostProcessor
+        assert r["data"] == b and r["sha1_ok"] == 1, (method, len(b))
+        xm = E.expand_method(method, b)
+        src, args = E.make_config(xm)
+        header, coded = _coded_payload(framed)
+        if header[6]:                                                     # context model in front: the Encoder's input
+            seen = orc.ref_cm_decode(header, coded, len(b) * 2 + 4096)
+            lvl = args[1] & 3
+            if lvl in (2, 3):
+                pre = 3 + (seen[1] | seen[2] << 8)
+                assert seen[pre:] == orc.ref_lzbuffer(b, args), (method, len(b))
+    back = eng.decompress_blocks([f for _, f in res], [len(b) + 64 for b in blocks])
+    for b, r in zip(blocks, back):
+        assert r["status"] == 0 and r["data"] == b and r["sha1"] == orc.sha1(b), method
+
+
+def test_inverse_bwt_and_level2_decoder_on_larger_blocks(eng, monkeypatch):
+    """4 MiB through both native decode kernels, and the same blocks through the translated ZPAQL programs
+    (ZPQ_PCOMP_GENERIC=1): identical output."""
+    data = datagen.text_like(3 << 20, 11) + datagen.binary_like(1 << 20, 12)
+    for method in ("x4,3c0", "x4,2,8,0,7,25,1c0"):
+        (st, framed), = eng.compress_blocks([data], [method], ["f"], None, True)
+        assert st == 0
+        r, = eng.decompress_blocks([framed], [len(data) + 64])
+        assert r["status"] == 0 and r["data"] == data
+    small = data[:200000]
+    monkeypatch.setenv("ZPQ_PCOMP_GENERIC", "1")
+    for method in ("x4,3c0", "x4,2,8,0,7,25,1c0", "x4,7c0"):
+        (st, framed), = eng.compress_blocks([small], [method], ["f"], None, True)
+        assert st == 0
+        r, = eng.decompress_blocks([framed], [len(small) + 64])
+        assert r["status"] == 0 and r["data"] == small, method
+
+
+def test_hostile_bwt_streams_are_refused(eng):
+    """A BWT stream whose list does not run through every row (damaged bytes / index) must give a format error, not a
+    hang: the reference's program would walk a cycle forever."""
+    data = datagen.text_like(50000, 13)
+    (st, framed), = eng.compress_blocks([data], ["x0,3"], ["f"], None, False)
+    assert st == 0
+    bad = bytearray(framed)
+    k = len(bad) // 2
+    bad[k] ^= 0x55; bad[k + 1] ^= 0x33
+    r, = eng.decompress_blocks([bytes(bad)], [len(data) + 64], verify=False)
+    assert r["status"] in (-6, 0)
+    if r["status"] == 0:
+        assert len(r["data"]) == len(data)

@@ -54,3 +54,38 @@ def test_golden_program_is_variant_zero():
     assert len(gold) == 302 and known(0, False) == gold
     blocks = open(os.path.join(orc.GOLDEN, "sha256.zpaq"), "rb").read()
     assert gold in blocks                              # it is what the reference's own i blocks carry
+
+
+# ---- levels 2 and 3 (what methods 3 and 4 put in front of their models): byte-aligned LZ77 and BWT ----------
+@pytest.mark.parametrize("arg0,e8", [(0, False), (4, False), (4, True), (6, False)])
+def test_reference_vm_undoes_byte_aligned_lz77_under_our_program(arg0, e8):
+    """REAL LZBuffer at level 2 (suffix-array match finder, as "x<N>,2,12,0,7,<21+N>,1" asks) -> our level-2 program in
+    front -> the REAL PostProcessor must give the input back.  The program without E8E9 has the 108 bytes libzpaq's own
+    HCOMP prelude counts on (it skips 3 + 108 bytes of preamble before the first LZ77 code)."""
+    method = "x%d,%d,12,0,7,%d,1c0,0,511i2" % (arg0, 6 if e8 else 2, 21 + arg0)
+    src, args = engine.make_config(method)
+    hdr, pc = engine.compile_config(src, args)
+    assert len(pc) == (160 if e8 else 108)
+    n = 200000
+    data = exe_like(n, 7) if e8 else datagen.mixed(n, 8)
+    lz = orc.ref_lzbuffer(data, args)
+    stream = bytes([1, len(pc) & 255, len(pc) >> 8]) + pc + lz
+    assert orc.ref_postprocess(stream, hdr[4], hdr[5], n + 64) == data
+
+
+@pytest.mark.parametrize("arg0,e8", [(0, False), (4, False), (4, True), (5, False)])
+def test_reference_vm_inverts_the_bwt_under_our_program(arg0, e8):
+    """REAL LZBuffer at level 3 (divbwt + index) -> our BWT program -> the REAL PostProcessor restores the input."""
+    method = "x%d,%dci1" % (arg0, 7 if e8 else 3)
+    src, args = engine.make_config(method)
+    hdr, pc = engine.compile_config(src, args)
+    n = 150000
+    data = exe_like(n, 9) if e8 else datagen.text_like(n, 10)
+    bw = orc.ref_lzbuffer(data, args)
+    assert len(bw) == len(data) + 5
+    stream = bytes([1, len(pc) & 255, len(pc) >> 8]) + pc + bw
+    assert orc.ref_postprocess(stream, hdr[4], hdr[5], n + 64) == data
+    for edge in (b"", b"a", b"abracadabra"):
+        bw = orc.ref_lzbuffer(edge, args)
+        stream = bytes([1, len(pc) & 255, len(pc) >> 8]) + pc + bw
+        assert orc.ref_postprocess(stream, hdr[4], hdr[5], 64) == edge

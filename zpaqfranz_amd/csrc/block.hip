@@ -10,6 +10,9 @@
 // (frame_kernel below: header, 64 KiB stored sub-blocks with big-endian lengths, trailer).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #include "zpq_internal.h"
 
 namespace {
@@ -61,9 +64,45 @@ const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8) {
 }
 
 namespace {
+// The post-processor programs of levels 2 (byte-aligned LZ77), 3 (BWT) and of E8E9 alone, as this engine's makeConfig
+// emits them (decode-pinned: the reference's PostProcessor restores the input under them, tests/test_pcomp_variants_cpu.py):
+// the decode side recognises them byte for byte and runs native kernels instead of the ZPAQL machine.
+struct KnownPre { int kind; bool e8; u32 mm; };     // kind: 2 = LZ77 level 2, 3 = BWT, 4 = E8E9 only
+std::vector<u8> pcomp_of(const std::string& method) {
+  static std::mutex mu;
+  static std::map<std::string, std::vector<u8>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(method);
+  if (it != cache.end()) return it->second;
+  std::string xm; int args[9]; std::vector<u8> hdr, pc;
+  if (zpq_build_config(nullptr, method.c_str(), nullptr, 0, &xm, args, &hdr, &pc) != ZPQ_OK) pc.clear();
+  return cache[method] = pc;
+}
+bool match_known_pre(const std::vector<u8>& pc, u32 ph, u32 pm, KnownPre* out) {
+  if (pm < 20 || pm > 31) return false;
+  const std::string a0 = std::to_string(pm - 20);
+  for (int e8 = 0; e8 < 2; ++e8) {
+    if (ph == 0) {
+      if (e8 && pc == pcomp_of("x" + a0 + ",4c0")) { *out = {4, true, 0}; return true; }
+      const std::string tail = ",0,7," + std::to_string(21 + (int)pm - 20) + ",1c0";
+      const std::vector<u8> p1 = pcomp_of("x" + a0 + "," + std::to_string(e8 ? 6 : 2) + ",1" + tail), p2 = pcomp_of("x" + a0 + "," + std::to_string(e8 ? 6 : 2) + ",2" + tail);
+      if (p1.size() == pc.size() && p1.size() == p2.size() && !p1.empty()) {
+        size_t at = 0, ndiff = 0;
+        for (size_t i = 0; i < p1.size(); ++i) if (p1[i] != p2[i]) { at = i; ++ndiff; }
+        if (ndiff == 1) {
+          const u32 mm = pc[at];
+          if (pc == pcomp_of("x" + a0 + "," + std::to_string(e8 ? 6 : 2) + "," + std::to_string(mm) + tail)) { *out = {2, e8 != 0, mm}; return true; }
+        }
+      }
+    } else if (ph == pm) {
+      if (pc == pcomp_of("x" + a0 + "," + std::to_string(e8 ? 7 : 3) + "c0")) { *out = {3, e8 != 0, 0}; return true; }
+    }
+  }
+  return false;
+}
 #define kPcompLz1 zpq_pcomp_lz1
 
-enum Kind { KIND_STORE0 = 0, KIND_STOREX = 1, KIND_LZ1 = 2 };
+enum Kind { KIND_STORE0 = 0, KIND_STOREX = 1, KIND_LZ1 = 2 /* LZ77 codes, bit packed (level 1) or byte aligned (level 2) */, KIND_BWT = 3 };
 
 struct Config {
   Kind kind;           // what produces the bytes the Encoder sees after the preamble
@@ -83,12 +122,15 @@ int parse_method(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, C
   if (rc) return rc;
   const std::string& m = cfg->xmethod;
   cfg->ncomp = cfg->header.size() > 6 ? cfg->header[6] : 0;
-  const int pre = cfg->args[1];
-  cfg->e8 = pre == 5;
+  const int pre = cfg->args[1], level = pre & 3;
+  cfg->e8 = m[0] != '0' && pre >= 4 && pre <= 7;
   if (m[0] == '0') cfg->kind = KIND_STORE0;
-  else if (pre == 0) cfg->kind = KIND_STOREX;
-  else if ((pre == 1 || pre == 5) && cfg->args[0] <= 6) cfg->kind = KIND_LZ1;     // blocks up to 64 MiB (rb = 0..2)
-  else if (pre >= 4 && pre <= 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': this E8E9 / pre-processor combination is not implemented", m.c_str());
+  else if (pre > 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': pre-processor %d does not exist", m.c_str(), pre);
+  else if (level == 0) cfg->kind = KIND_STOREX;                                      // model only (x,0) or E8E9 + model (x,4)
+  else if (level == 1 && cfg->args[0] <= 6) cfg->kind = KIND_LZ1;                    // blocks up to 64 MiB (rb = 0..2)
+  else if (level == 2 && cfg->args[5] - cfg->args[0] >= 21) cfg->kind = KIND_LZ1;    // byte-aligned codes over the suffix array
+  else if (level == 2) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': byte-aligned LZ77 with the hash-table match finder is not implemented (use the suffix array: N6 = N1 + 21)", m.c_str());
+  else if (level == 3) cfg->kind = KIND_BWT;
   else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s' not implemented", m.c_str());
   if (cfg->kind != KIND_STORE0 && (u64)n > (1ull << (20 + cfg->args[0])))
     return zpq_fail(ctx, ZPQ_ERR_ARG, "block larger than 2^%d", 20 + cfg->args[0]);
@@ -176,8 +218,13 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
   size_t e8_total = 0;
   std::vector<size_t> cm_jobs;          // jobs whose Encoder is the context-mixing coder
   size_t encin_total = 0;
+  std::vector<size_t> bwt_jobs;         // jobs whose body is the Burrows-Wheeler transform of the input (level 3)
+  size_t bwt_total = 0;
+  std::vector<const u8*> body_ptr(njobs, nullptr);     // what the Encoder sees after the preamble
+  std::vector<u32> body_len(njobs, 0);
   for (size_t i = 0; i < njobs; ++i) {
     jobs[i].out_len = 0;
+    body_ptr[i] = jobs[i].in; body_len[i] = jobs[i].n;
     const u8* host_data = nullptr;
     if (jobs[i].method && jobs[i].method[0] >= '5' && jobs[i].method[0] <= '9' && jobs[i].n) {
       hostbuf.resize(jobs[i].n);        // level 5 looks at the data to pick periodic models (host logic in libzpaq too)
@@ -199,8 +246,13 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
       prefix[i].push_back(0);        // PASS
     }
     size_t body_cap = jobs[i].n;
+    if (cfg[i].e8) { e8_jobs.push_back(i); e8_total += (((size_t)jobs[i].n + 64 + 63) & ~(size_t)63) + ((((size_t)jobs[i].n + 31) / 32 * 4 + 63) & ~(size_t)63); }
+    if (cfg[i].kind == KIND_BWT) {
+      bwt_jobs.push_back(i);
+      body_cap = (size_t)jobs[i].n + 5;
+      bwt_total += (body_cap + 64 + 63) & ~(size_t)63;
+    }
     if (cfg[i].kind == KIND_LZ1) {
-      if (cfg[i].e8) { e8_jobs.push_back(i); e8_total += (((size_t)jobs[i].n + 64 + 63) & ~(size_t)63) + ((((size_t)jobs[i].n + 31) / 32 * 4 + 63) & ~(size_t)63); }
       lz_of[i] = lz.size();
       zpq_lz77_job j;
       memset(&j, 0, sizeof j);
@@ -254,7 +306,8 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
       ZPQ_HIP(ctx, hipMemsetAsync(copy + jobs[i].n, 0, 64, st));
       int rc = zpq_e8e9_forward_launch(ctx, st, copy, jobs[i].n, bits);
       if (rc) return rc;
-      lz[lz_of[i]].d_in = copy;
+      if (cfg[i].kind == KIND_LZ1) lz[lz_of[i]].d_in = copy;
+      body_ptr[i] = copy;                 // x,4: the transformed bytes go to the model as they are
     }
   }
   // LZ77 streams
@@ -263,6 +316,20 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     for (auto& j : lz) { j.d_out = d_lz + o; o += j.out_cap; }
     int rc = zpq_lz77_encode_dev(ctx, lz.data(), lz.size());
     if (rc) return rc;
+    for (size_t i = 0; i < njobs; ++i)
+      if (jobs[i].status == ZPQ_OK && cfg[i].kind == KIND_LZ1) { body_ptr[i] = lz[lz_of[i]].d_out; body_len[i] = lz[lz_of[i]].out_len; }
+  }
+  // Burrows-Wheeler transforms (LZBuffer level 3: suffix array -> last column + index)
+  if (!bwt_jobs.empty()) {
+    u8* d_bwt = (u8*)zpq_scratch(ctx, 23, bwt_total + 64);
+    if (!d_bwt) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "BWT scratch");
+    size_t o = 0;
+    for (size_t i : bwt_jobs) {
+      u8* dst = d_bwt + o; o += ((size_t)jobs[i].n + 5 + 64 + 63) & ~(size_t)63;
+      int rc = zpq_bwt_dev(ctx, body_ptr[i], jobs[i].n, dst);
+      if (rc) return rc;
+      body_ptr[i] = dst; body_len[i] = jobs[i].n + 5;
+    }
   }
   // framing
   std::vector<FrameDev> fr(njobs);
@@ -282,8 +349,7 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
     memcpy(&pre_all[po], pv.data(), pv.size());
     FrameDev F;
     F.out = jobs[i].out; F.prefix = d_prefix + po; F.prefix_len = plen; F.pre_len = (u32)pv.size() - plen;
-    if (cfg[i].kind == KIND_LZ1) { F.data = lz[lz_of[i]].d_out; F.data_len = lz[lz_of[i]].out_len; }
-    else { F.data = jobs[i].in; F.data_len = jobs[i].n; }
+    F.data = body_ptr[i]; F.data_len = body_len[i];
     F.digest = jobs[i].dosha1 ? d_dig + 20 * sha_slot[i] : nullptr;
     const u32 P = F.pre_len + F.data_len;
     jobs[i].out_len = framed_size(plen, P, jobs[i].dosha1 != 0);
@@ -316,17 +382,17 @@ extern "C" int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t
       }
       plens[k] = plen;
       const u32 pre_len = (u32)pv.size() - plen;
-      const u8* body = cfg[i].kind == KIND_LZ1 ? lz[lz_of[i]].d_out : jobs[i].in;
-      const u32 body_len = cfg[i].kind == KIND_LZ1 ? lz[lz_of[i]].out_len : jobs[i].n;
+      const u8* body = body_ptr[i];
+      const u32 body_len_i = body_len[i];
       u8* e = d_encin + eo;
       ZPQ_HIP(ctx, hipMemcpyAsync(e, pv.data() + plen, pre_len, hipMemcpyHostToDevice, st));
-      if (body_len) ZPQ_HIP(ctx, hipMemcpyAsync(e + pre_len, body, body_len, hipMemcpyDeviceToDevice, st));
+      if (body_len_i) ZPQ_HIP(ctx, hipMemcpyAsync(e + pre_len, body, body_len_i, hipMemcpyDeviceToDevice, st));
       ZPQ_HIP(ctx, hipMemcpyAsync(jobs[i].out, pv.data(), plen, hipMemcpyHostToDevice, st));
       memset(&cj[k], 0, sizeof cj[k]);
       cj[k].header = cfg[i].header.data(); cj[k].header_len = (u32)cfg[i].header.size();
-      cj[k].d_in = e; cj[k].n = pre_len + body_len;
+      cj[k].d_in = e; cj[k].n = pre_len + body_len_i;
       cj[k].d_out = jobs[i].out + plen; cj[k].out_cap = jobs[i].out_cap - plen - 32;
-      eo += (pre_len + body_len + 64 + 15) & ~(size_t)15;
+      eo += (pre_len + body_len_i + 64 + 15) & ~(size_t)15;
     }
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
     int rc = zpq_cm_encode_dev(ctx, cj.data(), cj.size());
@@ -596,6 +662,38 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
           if (rc) { fail_job(rc); continue; }
         }
         jobs[i].out_len = d.out_len;
+      } else if (KnownPre kp; !getenv("ZPQ_PCOMP_GENERIC") && match_known_pre(pc, P.ph, P.pm, &kp)) {
+        // byte-aligned LZ77 / BWT / E8E9 alone, undone by native kernels (the stage output goes to a temporary when an
+        // E8E9 inverse follows)
+        u8* d_tmp = nullptr;
+        if (kp.e8 && kp.kind != 4) {
+          d_tmp = (u8*)zpq_scratch(ctx, 22, (size_t)jobs[i].out_cap + 128);
+          if (!d_tmp) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+        }
+        u8* stage_out = d_tmp ? d_tmp : outp[i];
+        u32 olen = 0;
+        int rc = ZPQ_OK;
+        if (kp.kind == 2) {
+          zpq_lz77_dec_job d;
+          memset(&d, 0, sizeof d);
+          d.d_in = d_data; d.n = dlen; d.rb = 0x80000000u | kp.mm; d.d_out = stage_out; d.out_cap = jobs[i].out_cap;
+          rc = zpq_lz77_decode_dev(ctx, &d, 1);
+          if (!rc) rc = d.status;
+          olen = d.out_len;
+        } else if (kp.kind == 3) {
+          rc = zpq_ibwt_dev(ctx, d_data, dlen, stage_out, jobs[i].out_cap, &olen);
+        } else {
+          if (dlen > jobs[i].out_cap) rc = ZPQ_ERR_CAPACITY;
+          olen = dlen;
+        }
+        if (rc) { fail_job(rc); continue; }
+        if (kp.e8) {
+          const u8* src = kp.kind == 4 ? d_data : d_tmp;
+          if (kp.kind != 4) ZPQ_HIP(ctx, hipMemsetAsync(d_tmp + olen, 0, 64, st));
+          rc = zpq_e8e9_inverse_dev(ctx, src, outp[i], olen);
+          if (rc) { fail_job(rc); continue; }
+        }
+        jobs[i].out_len = olen;
       } else {
         u32 olen = 0;
         int rc = zpq_pcomp_run_dev(ctx, pc.data(), psize, P.ph, P.pm, d_data, dlen, outp[i], jobs[i].out_cap, &olen);

@@ -1294,8 +1294,13 @@ int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32
   ZPQ_HIP(ctx, hipMemcpyAsync(prog, pcomp, psize, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_vm, &v, sizeof v, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  ZPQ_LAUNCH(ctx, "pcomp_run_kernel", st, pcomp_run_kernel, dim3(1), dim3(64), d_vm, d_in, n, d_res);
-  ZPQ_HIP(ctx, hipGetLastError());
+  // the program translated to machine code (cm_jit.hip); the interpreter only when that is not to be had
+  // (the closing 0 of the stored program is not part of it)
+  const u32 plen = psize && pcomp[psize - 1] == 0 ? psize - 1 : psize;
+  if (getenv("ZPQ_CM_GENERIC") || zpq_pcomp_spec_run(ctx, st, pcomp, plen, ph, pm, d_in, n, d_out, out_cap, v.H, v.M, v.R, d_res) != ZPQ_OK) {
+    ZPQ_LAUNCH(ctx, "pcomp_run_kernel", st, pcomp_run_kernel, dim3(1), dim3(64), d_vm, d_in, n, d_res);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
   u32 res[2];
   ZPQ_HIP(ctx, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));

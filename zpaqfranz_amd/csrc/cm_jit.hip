@@ -112,7 +112,7 @@ std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pc
       } else if (op == 48) s = "t = " + Hd + "; " + Hd + " = a; a = t;";
       else if (g == 6 && k >= 1 && k <= 4) s = k == 1 ? "++" + Hd + ";" : k == 2 ? "--" + Hd + ";" : k == 3 ? Hd + " = ~" + Hd + ";" : Hd + " = 0;";
       else if (op == 55) s = "R[" + itos(N) + "] = a;";
-      else if (op == 57) s = is_pcomp ? "ZOUT(a);" : ";";         // OUT: HCOMP has no output stream
+      else if (op == 57) s = is_pcomp ? "{ if (zop < zcap) zout[zop] = (u8)a; ++zop; }" : ";";   // OUT: HCOMP has no output stream
       else if (op == 59) s = "a = (a + (u32)" + Mb + " + 512u) * 773u;";
       else if (op == 60) s = Hd + " = (" + Hd + " + a + 512u) * 773u;";
       else { s = "goto Lerr;"; falls = false; }
@@ -120,7 +120,8 @@ std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pc
     if (falls) s += " " + go(pc, nxt);
     stmt[pc] = s;
   }
-  std::string out = std::string("ZDEV void ") + fname + "(const u32 input, ZVm& z, g_u8* const M, g_u32* const R, const zh_ptr H) {\n";
+  std::string out = std::string("ZDEV void ") + fname + "(const u32 input, ZVm& z, g_u8* const M, g_u32* const R, const zh_ptr H" +
+                    (is_pcomp ? ", g_u8* const zout, const u32 zcap, u32& zop" : "") + ") {\n";
   out += "  u32 a = input, b = z.b, c = z.c, d = z.d, f = z.f, t = 0, guard = 0; (void)t; (void)guard;\n";
   out += n ? "  goto L0;\n" : "  goto Lerr;\n";
   for (auto& kv : stmt) out += "L" + itos(kv.first) + ": " + kv.second + "\n";
@@ -342,6 +343,68 @@ int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void*
   void* args[] = {(void*)&d_jobs, (void*)&njobs, (void*)&d_counter, (void*)&d_tables};
   ZpqProfScope prof(ctx, encode ? "cm_spec_encode" : "cm_spec_decode", st);
   ZPQ_HIP(ctx, hipModuleLaunchKernel(encode ? k->enc : k->dec, grid, 1, 1, w * 64, 1, 1, 0, st, args, nullptr));
+  return ZPQ_OK;
+}
+
+// ---- any post-processor program, translated (rows a14, a16) -------------------------------------------------------
+// PostProcessor::write runs the PCOMP program once per decoded byte and once with 2^32-1 when the segment ends
+// (ZSFX/libzpaq.cpp:2185-2226).  The interpreter in cm.hip does that at ~1000 cycles per ZPAQL instruction; the
+// translated program runs at the speed of the machine code it became (one lane: a ZPAQL machine is one serial thread).
+namespace {
+const char* kPcompSrc = R"ZPQSRC(
+typedef unsigned char u8; typedef unsigned short u16; typedef unsigned int u32; typedef unsigned long long u64;
+#define ZGA __attribute__((address_space(1)))
+typedef ZGA u32 g_u32; typedef ZGA u8 g_u8;
+typedef g_u32* zh_ptr;
+#define ZDEV __device__ inline __attribute__((always_inline))
+struct ZVm { u32 a, b, c, d, f, err; };
+//@@PCOMP@@
+extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n, u8* out, u32 cap, u32* H, u8* M, u32* R, u32* result) {
+  if (threadIdx.x) return;
+  ZVm z = {0, 0, 0, 0, 0, 0};
+  u32 op = 0;
+  const g_u8* gin = (const g_u8*)in;
+  for (u32 i = 0; i < n && !z.err; ++i) z_pcomp(gin[i], z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
+  if (!z.err) z_pcomp(0xffffffffu, z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
+  result[0] = op;
+  result[1] = z.err ? (u32)-6 : (op > cap ? (u32)-4 : 0u);
+}
+)ZPQSRC";
+
+struct PcompMod { hipModule_t mod; hipFunction_t fn; };
+std::map<std::pair<int, u64>, PcompMod> g_pmods;
+}  // namespace
+
+// Runs pcomp[0..psize) over d_in[0..n) on the device; H, M, R are zeroed device arrays of 2^ph words, 2^pm bytes, 256 words.
+int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize, u32 ph, u32 pm, const u8* d_in, u32 n, u8* d_out, u32 out_cap,
+                       u32* d_H, u8* d_M, u32* d_R, u32* d_result) {
+  std::vector<u8> code(pcomp, pcomp + psize);
+  std::string src = "#define ZHMASK " + itos((1u << ph) - 1) + "u\n#define ZMMASK " + itos((1u << pm) - 1) + "u\n#define ZGUARD 0x7fffffffu\n";
+  std::string body = kPcompSrc;
+  const std::string marker = "//@@PCOMP@@";
+  body.replace(body.find(marker), marker.size(), gen_zpaql(code, "z_pcomp", true));
+  src += body;
+  const u64 key = fnv64(src);
+  PcompMod pmod;
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_pmods.find({ctx->device, key});
+    if (it != g_pmods.end()) { pmod = it->second; have = true; }
+  }
+  if (!have) {
+    const Compiled* c = nullptr;
+    int rc = compile_source(ctx, src, key, &c);
+    if (rc) return rc;
+    if (hipModuleLoadData(&pmod.mod, c->code.data()) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_HIP, "hipModuleLoadData failed for a translated post-processor");
+    if (hipModuleGetFunction(&pmod.fn, pmod.mod, "pcomp_spec") != hipSuccess) { (void)hipModuleUnload(pmod.mod); return zpq_fail(ctx, ZPQ_ERR_HIP, "translated post-processor: kernel missing"); }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto ins = g_pmods.insert({{ctx->device, key}, pmod});
+    if (!ins.second) { (void)hipModuleUnload(pmod.mod); pmod = ins.first->second; }
+  }
+  void* args[] = {(void*)&d_in, (void*)&n, (void*)&d_out, (void*)&out_cap, (void*)&d_H, (void*)&d_M, (void*)&d_R, (void*)&d_result};
+  ZpqProfScope prof(ctx, "pcomp_spec", st);
+  ZPQ_HIP(ctx, hipModuleLaunchKernel(pmod.fn, 1, 1, 1, 64, 1, 1, 0, st, args, nullptr));
   return ZPQ_OK;
 }
 

@@ -301,6 +301,16 @@ std::string lazy2_source(int rb, bool doe8) {
   return p;
 }
 
+// E8E9 inverse over M[0..b) with output, as the post-processors of levels 2 and 3 run it when the segment ends
+// (mirror of e8e9(), ZSFX/libzpaq.cpp:6117-6126)
+std::string e8e9_inverse_source() {
+  return "    d=b b=0 do\n      a=b a==d ifnot\n        a=*b a&= 254 a== 232 if\n"
+         "          c=b b++ b++ b++ b++ a=*b a++ a&= 254 a== 0 if\n"
+         "            b-- a=*b\n            b-- a<<= 8 a+=*b\n            b-- a<<= 8 a+=*b\n            a-=b a++\n"
+         "            *b=a a>>= 8 b++\n            *b=a a>>= 8 b++\n            *b=a b++\n          endif\n          b=c\n        endif\n"
+         "        a=*b out b++\n      forever\n    endif\n";
+}
+
 std::string make_config(const char* method, int args[9]) {
   const char kind = method[0];
   if (kind != 'x' && kind != 's' && kind != '0' && kind != 'i') throw ConfigError("method must begin with 0..5, x or s");
@@ -320,11 +330,50 @@ std::string make_config(const char* method, int args[9]) {
     const int rb = args[0] > 4 ? args[0] - 4 : 0;
     hdr = "comp 9 16 0 $1+20 ";
     pcomp = lazy2_source(rb, doe8);
-  } else if (level == 2 || level == 3) {
-    throw ConfigError(level == 2 ? "byte-aligned LZ77 pre-processor (x,2 / x,6) is not pinned by any fixture: refused"
-                                 : "BWT pre-processor (x,3 / x,7) is not pinned by any fixture: refused");
+  } else if (level == 2) {
+    // byte-aligned LZ77 (LZBuffer level 2, ZSFX/libzpaq.cpp:6221-6224, :6519-6547): 00xxxxxx = x+1 literals,
+    // yyxxxxxx = match of x+$3 bytes, yy+1 offset bytes (offset-1, MSB first).  d = state, M = output, b = size.
+    hdr = "comp 9 16 0 $1+20 ";
+    pcomp = "pcomp lzpre c ;\n  a> 255 if\n";
+    if (doe8) pcomp += e8e9_inverse_source();
+    pcomp += "    b=0 c=0 d=0 a=0 r=a 1 r=a 2\n  halt\n  endif\n"
+             "  c=a a=d a== 0 if\n    a=c a>>= 6 a++ d=a\n    a== 1 if\n      a+=c r=a 1 a=0 r=a 2\n    else\n"
+             "      d++ a=c a&= 63 a+= $3 r=a 1 a=0 r=a 2\n    endif\n  else\n    a== 1 if\n      a=c *b=a b++\n";
+    if (!doe8) pcomp += " out\n";
+    pcomp += "      a=r 1 a-- a== 0 if d=0 endif r=a 1\n    else\n      a> 2 if\n        a=r 2 a<<= 8 a|=c r=a 2 d--\n      else\n"
+             "        a=r 2 a<<= 8 a|=c c=a a=b a-=c a-- c=a\n        d=r 1\n        do\n          a=*c *b=a c++ b++\n";
+    if (!doe8) pcomp += " out\n";
+    pcomp += "        d-- a=d a> 0 while\n      endif\n    endif\n  endif\n  halt\nend\n";
+  } else if (level == 3) {
+    // BWT (LZBuffer level 3, ZSFX/libzpaq.cpp:6225-6226, :6317-6326): the transform with the end-of-string coded
+    // as 255 and its position in the last 4 bytes, LSB first.  The program collects it in M, then inverts it through
+    // a linked list in H.
+    if (doe8 && args[0] > 4) throw ConfigError("BWT + E8E9 above 16 MiB blocks: post-processor not restated");
+    hdr = "comp 9 16 $1+20 $1+20 ";
+    pcomp = "pcomp bwtrle c ;\n  a> 255 ifnot\n    *b=a b++\n  elsel\n"
+            "    b-- a=*b\n    b-- a<<= 8 a+=*b\n    b-- a<<= 8 a+=*b\n    b-- a<<= 8 a+=*b c=a r=a 1\n"
+            "    a=b r=a 2\n"
+            "    do\n      a=b a> 0 if\n        b-- a=*b a++ a&= 255 d=a d! *d++\n      forever\n    endif\n"
+            "    d=0 d! *d= 1 a=0\n    do\n      a+=*d *d=a d--\n    d<>a a! a> 255 a! d<>a until\n"
+            "    b=0 do\n      a=c a>b if\n        d=*b d! *d++ d=*d d-- *d=b\n      b++ forever\n    endif\n"
+            "    b=c b++ c=r 2 do\n      a=c a>b if\n        d=*b d! *d++ d=*d d-- *d=b\n      b++ forever\n    endif\n";
+    if (args[0] <= 4) {
+      pcomp += "    b=0 do\n      a=c a>b if\n        d=b a=*d a<<= 8 a+=*b *d=a\n      b++ forever\n    endif\n"
+               "    d=r 1 b=0 do\n      a=d a== 0 ifnot\n        a=*d a>>= 8 d=a\n";
+      pcomp += doe8 ? " *b=*d b++\n" : " a=*d out\n";
+      pcomp += "      forever\n    endif\n";
+      if (doe8) pcomp += e8e9_inverse_source();
+      pcomp += "  endif\n  halt\nend\n";
+    } else {
+      pcomp += "    d=r 1 do\n      a=d a== 0 ifnot\n        d=*d b=d a=*b out\n      forever\n    endif\n  endif\n  halt\nend\n";
+    }
+  } else if (doe8) {
+    // E8E9 alone in front of a model (what level 4 picks for executable data).  libzpaq 7.15 undoes it with a
+    // streaming 5-byte window; this program collects the segment in M (2^($1+20) bytes) and runs the same inverse as the
+    // level 2 / 3 programs when the segment ends: any ZPAQ reader decodes it, the header bytes differ from 7.15's.
+    hdr = "comp 9 16 0 $1+20 ";
+    pcomp = "pcomp e8buf c ;\n  a> 255 ifnot\n    *b=a b++\n  else\n" + e8e9_inverse_source() + "    b=0 c=0 d=0\n  endif\n  halt\nend\n";
   } else {
-    if (doe8) throw ConfigError("E8E9-only pre-processor (x,4) is not pinned by any fixture: refused");
     hdr = "comp 9 16 0 0 ";
     pcomp = "end\n";
   }
@@ -335,6 +384,12 @@ std::string make_config(const char* method, int args[9]) {
   const int membits = args[0] + 20;
   int sb = 5;       // context bits of the last component
   std::string comp, hcomp = "hcomp\nc-- *c=a a+= 255 d=a *d=c\n";
+  if (level == 2) {
+    // the parse state of the byte-aligned LZ77 codes for the 256..511 context masks: R1 = 1 + bytes until the next
+    // code (starting behind the post-processor preamble: 3 + 108 bytes, 52 more with the E8E9 stage as restated here), R2 = the code
+    hcomp += "a=r 1 a== 0 if\n  a= " + itos(111 + 52 * (doe8 ? 1 : 0)) + "\nelse a== 1 if\n  a=*c r=a 2\n  a> 63 if a>>= 6 a++ a++\n"
+             "  else a++ a++ endif\nelse\n  a--\nendif endif\nr=a 1\n";
+  }
   while (*m && ncomp < 254) {
     std::vector<int> v;
     v.push_back((unsigned char)*m++);

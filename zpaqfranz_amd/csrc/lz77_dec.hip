@@ -196,6 +196,82 @@ __global__ __launch_bounds__(64) void lz77_decode_kernel(const LzDecDev* __restr
 }
 
 
+// ---- byte-aligned codes (LZBuffer level 2, ZSFX/libzpaq.cpp:6221-6224, :6519-6547): what methods 3 and 4 put in front of
+// their models; the inverse is the level-2 post-processor program of makeConfig.  00xxxxxx = x + 1 literals follow;
+// yyxxxxxx (yy > 0) = match of x + minMatch bytes, yy + 1 offset bytes follow (offset - 1, most significant first).
+// One wave per block: the parse is a few scalar instructions per token, literal runs (<= 64 bytes) and matches
+// (<= minMatch + 63 bytes) are copied by the lanes -- through the 64 KiB LDS ring when the source is near, from HBM
+// (past the L1, which may hold lines cached while they were only partly written) when it is far.  J.rb carries minMatch.
+__global__ __launch_bounds__(64) void lz2_decode_kernel(const LzDecDev* __restrict__ jobs) {
+  const LzDecDev J = jobs[blockIdx.x];
+  __shared__ u8 ring_mem[kRing];
+  l_u8* const ring = (l_u8*)ring_mem;
+  g_u8* const out = (g_u8*)J.out;
+  g_cu8* const in = (g_cu8*)J.in;
+  const u32 lane = (u32)lane_id();
+  const u32 n = J.n, mm = J.rb & 255u;
+  u32 ip = 0, op = 0; int status = ZPQ_OK;
+  // code-stream window: 64 x 8 bytes from a 8-byte aligned position; bytes at or past n read as 0
+  u32 wbase = 0;
+  u64 win = (u64)lane * 8 < n ? load8(in + (u64)lane * 8) : 0ull;
+  auto peek5 = [&](u32 p) -> u64 {                     // the 8 bytes at p (p < n)
+    if (p < wbase || p + 8 > wbase + 504) {
+      wbase = p & ~7u;
+      const u64 o = (u64)wbase + (u64)lane * 8;
+      win = o < n ? load8(in + o) : 0ull;
+    }
+    const u32 L = __builtin_amdgcn_readfirstlane((p - wbase) >> 3), sh = ((p - wbase) & 7u) << 3;
+    const u64 lo = readlane64(win, L), hi = readlane64(win, L + 1);
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  };
+  while (ip < n) {
+    const u64 w = peek5(ip);
+    const u32 code = (u32)w & 255u;
+    if (code < 64) {                                  // literals
+      u32 len = code + 1;
+      const u32 avail = n - ip - 1;
+      const bool cutoff = avail < len;
+      if (cutoff) len = avail;                         // the stream ends inside the run
+      if ((u64)op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
+      if (lane < len) { const u8 c = in[ip + 1 + lane]; out[op + lane] = c; ring[(op + lane) & (kRing - 1)] = c; }
+      __builtin_amdgcn_wave_barrier();
+      op += len; ip += 1 + len;
+      if (cutoff) break;
+    } else {
+      const u32 nb = (code >> 6) + 1;
+      if (ip + 1 + nb > n) break;                      // the stream ends inside the code
+      u32 o1 = 0;
+      for (u32 k = 0; k < nb; ++k) o1 = o1 << 8 | ((u32)(w >> (8 * (k + 1))) & 255u);
+      const u32 len = (code & 63u) + mm;
+      ip += 1 + nb;
+      if (o1 >= op) { status = ZPQ_ERR_FORMAT; break; }                  // offset = o1 + 1 must not reach before the block
+      const u32 off = o1 + 1;
+      if (len == 0) continue;
+      if ((u64)op + len > J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }
+      const u32 src0 = op - off;
+      if (off + 128 <= kRing) {                        // source inside the LDS ring
+        for (u32 c0 = 0; c0 < len; c0 += 64) {
+          const u32 j = c0 + lane;
+          u8 c = 0;
+          if (j < len) c = ring[(off >= 64 ? op + j - off : src0 + (j % off)) & (kRing - 1)];
+          __builtin_amdgcn_wave_barrier();
+          if (j < len) { out[op + j] = c; ring[(op + j) & (kRing - 1)] = c; }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {                                         // far: written at least 64 KiB - 128 bytes ago, long complete
+        for (u32 j = lane; j < len; j += 64) {
+          const u8 c = __builtin_nontemporal_load((g_cu8*)out + src0 + j);
+          out[op + j] = c;
+          ring[(op + j) & (kRing - 1)] = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      op += len;
+    }
+  }
+  if (lane == 0) { J.result[0] = op; J.result[1] = (u32)status; }
+}
+
 // ---- parse off the chain ----------------------------------------------------------------------------------------------
 // The wave above spends ~250 scalar instructions per token on PARSING; the copies are cheap.  The parse state between
 // two tokens is one number (the bit position), so a parse started at any bit merges with the true one at their first
@@ -706,15 +782,26 @@ extern "C" int zpq_lz77_decode_dev(zpq_ctx* ctx, zpq_lz77_dec_job* jobs, size_t 
   LzDecDev* d_jobs = (LzDecDev*)d_meta;
   u32* d_res = (u32*)(d_meta + njobs * sizeof(LzDecDev));
   std::vector<LzDecDev> h(njobs);
-  for (size_t i = 0; i < njobs; ++i) {
-    if (jobs[i].rb > 8) return zpq_fail(ctx, ZPQ_ERR_ARG, "rb out of range");
-    h[i].in = jobs[i].d_in; h[i].n = jobs[i].n; h[i].rb = jobs[i].rb;
-    h[i].out = jobs[i].d_out; h[i].out_cap = jobs[i].out_cap; h[i].result = d_res + 2 * i;
-  }
+  // rb with bit 31 set: byte-aligned codes (level 2), minimum match length in the low byte; those records go last
+  size_t n1 = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (size_t i = 0, k = pass ? n1 : 0; i < njobs; ++i) {
+      const bool l2 = (jobs[i].rb >> 31) != 0;
+      if (l2 != (pass == 1)) continue;
+      if (!l2 && jobs[i].rb > 8) return zpq_fail(ctx, ZPQ_ERR_ARG, "rb out of range");
+      h[k].in = jobs[i].d_in; h[k].n = jobs[i].n; h[k].rb = jobs[i].rb & 0x7fffffffu;
+      h[k].out = jobs[i].d_out; h[k].out_cap = jobs[i].out_cap; h[k].result = d_res + 2 * i;
+      ++k;
+      if (!pass) n1 = k;
+    }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, h.data(), njobs * sizeof(LzDecDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  int rc = zpq_lz77_decode_launch(ctx, st, h.data(), d_jobs, njobs);
+  int rc = n1 ? zpq_lz77_decode_launch(ctx, st, h.data(), d_jobs, n1) : ZPQ_OK;
   if (rc) return rc;
+  if (njobs > n1) {
+    ZPQ_LAUNCH(ctx, "lz2_decode_kernel", st, lz2_decode_kernel, dim3((unsigned)(njobs - n1)), dim3(64), d_jobs + n1);
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
   std::vector<u32> res(njobs * 2);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, njobs * 8, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));

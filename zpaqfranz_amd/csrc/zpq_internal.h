@@ -111,6 +111,8 @@ int zpq_lz77_decode_launch(zpq_ctx* ctx, hipStream_t st, const zpq_lzdec_dev* h_
 extern const u8 zpq_pcomp_lz1[302];
 // the level-1 post-processor programs decoded natively: rb = 0..7 raw offset bits, with / without the E8E9 inverse
 const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8);
+// inverse Burrows-Wheeler transform of a level-3 stream (ibwt.hip); synchronous
+int zpq_ibwt_dev(zpq_ctx* ctx, const u8* d_bwt, u32 m, u8* d_out, u32 out_cap, u32* out_len);
 // decode path for blocks that need host parsing (context-model coded data, arbitrary PCOMP programs): jobs[].in are
 // HOST pointers; jobs[].out are device pointers when out_dev, else host pointers (block.hip)
 int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify, bool out_dev);
@@ -140,6 +142,10 @@ int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out);
 u32 zpq_cm_spec_waves(const zpq_cm_spec* k);
 int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void* d_jobs, u32 njobs, u32* d_counter, const void* d_tables,
                        int encode);
+// any PCOMP program translated to device code and run over d_in (cm_jit.hip); H/M/R: zeroed device arrays; d_result: [0] bytes
+// produced, [1] status
+int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize, u32 ph, u32 pm, const u8* d_in, u32 n, u8* d_out, u32 out_cap,
+                       u32* d_H, u8* d_M, u32* d_R, u32* d_result);
 // device-side records of the specialised coder (layout shared with cm_spec_src.inc)
 struct zpq_spec_comp { u64 cm, ht; u32 type, a1, a2, a3, a4, a5, limit, cm_mask, ht_mask, csize, pad0, pad1; };
 struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap; u64 prof; };
