@@ -70,9 +70,9 @@ def test_reference_decompresser_restores_and_stream_equals_lzbuffer(eng, method)
 
 
 def test_inverse_bwt_and_level2_decoder_on_larger_blocks(eng, monkeypatch):
-    """4 MiB through both native decode kernels, and the same blocks through the translated ZPAQL programs
+    """1.25 MiB through both native decode kernels, and the same blocks through the translated ZPAQL programs
     (ZPQ_PCOMP_GENERIC=1): identical output."""
-    data = datagen.text_like(3 << 20, 11) + datagen.binary_like(1 << 20, 12)
+    data = datagen.text_like(1 << 20, 11) + datagen.binary_like(1 << 18, 12)
     for method in ("x4,3c0", "x4,2,8,0,7,25,1c0"):
         (st, framed), = eng.compress_blocks([data], [method], ["f"], None, True)
         assert st == 0
