@@ -362,20 +362,32 @@ class Pipeline:
     def _exchange_seams(self, P, lens, my_lo, nf, layout, blocks_buf):
         """Fragments of a block that live on another rank (only at rank seams) travel peer to peer:
         both sides derive the same ordered lists from the plan, so one send/recv per rank pair suffices."""
-        dev = self.dev
+        dev, eng = self.dev, self.eng
+        i64, i32 = torch.int64, torch.int32
         sends, recvs = {}, {}
         for dst, idx in P["send"].items():
+            # one gather kernel packs the outgoing fragments back to back (no per-fragment host work)
             loc = torch.from_numpy((idx - my_lo).astype(np.int64)).to(dev)
-            offs = self.frag_off[:nf][loc].tolist()
-            sends[int(dst)] = torch.cat([self.data[o:o + int(l)] for o, l in zip(offs, lens[idx].tolist())])
+            ln = torch.from_numpy(lens[idx].astype(np.int32)).to(dev)
+            src = self.frag_off[:nf][loc].contiguous()
+            dst_off = (torch.cumsum(ln.to(i64), 0) - ln.to(i64)).contiguous()
+            buf = torch.empty(int(lens[idx].sum()) + 64, dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream().synchronize()
+            eng.gather_dev(self.data.data_ptr(), src.data_ptr(), ln.data_ptr(), dst_off.data_ptr(), len(idx), buf.data_ptr())
+            eng.sync()
+            sends[int(dst)] = buf[: int(lens[idx].sum())]
         for src, idx in P["recv"].items():
             recvs[int(src)] = int(lens[idx].sum())
         got = _exchange(sends, recvs, dev)
         for src, idx in P["recv"].items():
-            buf, q = got[int(src)], 0
-            for g, ll in zip(idx.tolist(), lens[idx].tolist()):
-                d = layout[int(g)]
-                blocks_buf[d:d + ll] = buf[q:q + ll]; q += ll
+            buf = got[int(src)]
+            ln = torch.from_numpy(lens[idx].astype(np.int32)).to(dev)
+            src_off = (torch.cumsum(ln.to(i64), 0) - ln.to(i64)).contiguous()
+            dst_off = torch.tensor([int(layout[int(g)]) for g in idx.tolist()], dtype=i64, device=dev)
+            pad = torch.cat([buf, torch.zeros(64, dtype=torch.uint8, device=dev)])      # the library reads up to 64 bytes past an extent
+            torch.cuda.current_stream().synchronize()
+            eng.gather_dev(pad.data_ptr(), src_off.data_ptr(), ln.data_ptr(), dst_off.data_ptr(), len(idx), blocks_buf.data_ptr())
+            eng.sync()
 
 
 def verify_add(pipe, layout, corpus, threads):
@@ -528,6 +540,24 @@ class ExtractPipeline:
                           archive_bytes=int(self.arc_bytes), restored_bytes=int(self.total))
         torch.cuda.synchronize()
 
+    def clone_for(self, eng):
+        """A second extract job in flight on another engine context: shares the archive and the index (read-only), owns
+        its decoded blocks, its restored files and its digests."""
+        import copy
+        c = copy.copy(self)
+        c.eng = eng
+        dev = self.dev
+        c.plain = torch.empty_like(self.plain)
+        c.out = torch.empty(self.total + 64, dtype=torch.uint8, device=dev)
+        c.d_got = torch.empty_like(self.d_got)
+        c.d_sha_got = torch.empty_like(self.d_sha_got)
+        c.jobs = (self.E.UnblockJob * self.nb)()
+        for k in range(self.nb):
+            c.jobs[k].in_ = self.arc.data_ptr() + self.arc_off[k]; c.jobs[k].n = self.blk_len[k]
+            c.jobs[k].out = c.plain.data_ptr() + self.plain_off[k]; c.jobs[k].out_cap = self.usize[k] + 64
+        torch.cuda.synchronize()
+        return c
+
     def step(self, order=None, idx=0):
         eng = self.eng
         self.out.zero_() if getattr(self, "scrub", False) else None
@@ -542,6 +572,11 @@ class ExtractPipeline:
             raise RuntimeError("extract: %d fragment checksums differ" % mism)
         # every file fragment to its place (the writes of ZSFX/zsfx.cpp:1880-1960, into HBM instead of the file system)
         eng.gather_dev(self.plain.data_ptr(), self.d_src.data_ptr(), self.d_len.data_ptr(), self.d_dst.data_ptr(), self.n_ext, self.out.data_ptr())
+        if getattr(self, "verify_hash", "sha256") == "blake3":
+            # the file-level hash zpaqfranz itself offers for this (README.md:95-105): a tree, so one long file is chip-wide work
+            _, _, got = eng.file_checksums_dev(self.out.data_ptr(), self.file_off, crc32=False, xxh64=False, blake3=True)
+            self.blake3_mismatches = sum(1 for g_, w_ in zip(got, self.blake3_want) if g_ != w_)
+            return self.arc_bytes
         # SHA-256 of every restored file against the original's
         eng.sha256_extents_dev(self.out.data_ptr(), self.d_foff.data_ptr(), self.d_flen.data_ptr(), self.nfiles, self.d_sha_got.data_ptr())
         mism, first = eng.digest_compare_dev(self.d_sha_got.data_ptr(), self.d_sha_want.data_ptr(), self.nfiles, 32)
@@ -934,6 +969,10 @@ def main():
     ap.add_argument("--dup", type=int, default=8, help="dup8_m1: copies of every unit")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
     ap.add_argument("--pipeline", type=int, default=None, help="steps in flight (each on its own engine context); 1 = strictly serial")
+    ap.add_argument("--shared-corpus", action="store_true",
+                    help="multi-GPU, strong scaling: ONE Silesia x copies corpus split by file range across the ranks (rank r holds copies "
+                         "[r*copies/N, (r+1)*copies/N)): every fragment of ranks > 0 duplicates one of rank 0, the global first-occurrence "
+                         "exchange carries the whole dedup; the stitched archive equals the single-GPU one")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo runs the collectives through the host: functional test only")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses GPU 0 (with --dist-backend gloo)")
     ap.add_argument("--force-collectives", action="store_true", help="single rank: run the multi-rank code path (RCCL all-gathers with world size 1)")
@@ -995,20 +1034,25 @@ def main():
         return main_text_m2(a, rank, world, local, dev)
     if a.workload == "cm_m5":
         return main_cm_m5(a, rank, world, local, dev)
-    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 4}[a.workload]
+    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 6}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
     # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6: six by default
     # (multi-rank runs keep three: every step in flight adds three collective sections to the fixed order, and that depth
     # is the one exercised over RCCL)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 1}[a.workload])
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 3}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
-    corpus = datagen.silesia_like(seed=rank, scale=a.scale)
+    shared = a.shared_corpus and a.workload == "silesia_x256_m1"
+    corpus = datagen.silesia_like(seed=0 if shared else rank, scale=a.scale)
     if a.workload == "dup8_m1":
         layout = dup8_layout(dev, corpus, a.units, a.dup, rank)
+    elif shared:
+        if a.copies % world:
+            raise SystemExit("--shared-corpus: --copies must be a multiple of the number of ranks")
+        layout = silesia_layout(dev, corpus, a.copies // world)        # this rank's file range of the one corpus
     else:
         layout = silesia_layout(dev, corpus, a.copies)
     torch.cuda.empty_cache()       # what the generators left in torch's cache is HBM the engine cannot see (its LZ77 batches are sized by free memory)
@@ -1032,9 +1076,13 @@ def main():
         pipes[0].step()                                     # the archive to extract (untimed)
         sha = [hashlib.sha256(b).digest() for _, b in corpus]
         ex_pipe = ExtractPipeline(eng, dev, pipes[0], layout, sha * a.copies)
-        layout["data"] = None; pipes[0].data = None; del pipes[0].verify_blocks  # the originals are not needed any more
+        layout["data"] = None; del pipes[0].verify_blocks  # the originals are not needed any more
+        for p_ in pipes:
+            p_.data = None
         torch.cuda.empty_cache()
-        runners = [ex_pipe]
+        # several extract jobs in flight (own context, own output): a job is as long as its longest serial chain -- the
+        # SHA-256 of the 51 MB member on one wave, the SHA-1 of a 16 MiB block -- and leaves most of the chip idle
+        runners = [ex_pipe] + [ex_pipe.clone_for(e_) for e_ in engines[1:]]
     else:
         runners = pipes
 
@@ -1164,8 +1212,9 @@ def main():
         e2e = alg_step / 1e9 / sec
         res = {"metric": metric, "value": round(out_bytes / 1e6 / sec, 3),
                "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(sec * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if shared else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": a.workload if a.workload != "silesia_x256_m1" else "silesia_x%d_m1" % a.copies,
+                          **({"corpus": "one Silesia x%d split by file range over %d ranks" % (a.copies, world)} if shared else {}),
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
@@ -1177,6 +1226,23 @@ def main():
                                        "note": "whole step: SURVEY 8(d) algorithmic bytes (input once + unique + output; extract: r + 1 + 1) / ms_per_step; the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
         if extract:
             res["sha256_mismatches"] = pipe.sha256_mismatches
+            if world == 1 and not a.no_verify:
+                # the same extract with BLAKE3 as the per-file check (what zpaqfranz offers beside SHA-256 / XXHASH64)
+                import orc
+                want12 = [orc.blake3(b) for _, b in corpus]
+                for r_ in runners:
+                    r_.verify_hash = "blake3"; r_.blake3_want = want12 * a.copies
+                run_steps(len(runners))                      # warm
+                barrier(); tb = time.perf_counter()
+                nb3 = 2 * len(runners)
+                run_steps(nb3)
+                barrier(); secb = (time.perf_counter() - tb) / nb3
+                res["blake3_verify"] = {"ms_per_step": round(secb * 1e3, 3), "value": round(pipe.arc_bytes / 1e6 / secb, 3), "unit": "MB/s",
+                                        "output_GBps": round(pipe.total / 1e9 / secb, 3),
+                                        "mismatches": int(sum(getattr(r_, "blake3_mismatches", 0) for r_ in runners)),
+                                        "note": "same job, BLAKE3 (tree hash, checked against the oracle's digests of the 12 members) instead of SHA-256 per file"}
+                for r_ in runners:
+                    r_.verify_hash = "sha256"
         threads = min(32, len(os.sched_getaffinity(0)))
         if world == 1 and not a.no_verify and not a.force_collectives:
             if extract:

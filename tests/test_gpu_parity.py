@@ -655,3 +655,23 @@ def test_two_rank_add_is_bit_identical_to_serial(tmp_path):
         want += fb
     assert len(got) == len(want)
     assert got == want
+
+
+def test_two_rank_shared_corpus_equals_the_single_gpu_archive(tmp_path):
+    """Strong scaling (BASELINE metric: one Silesia x N corpus on 1/2/4/8 GPUs): --shared-corpus splits ONE corpus by file
+    range over the ranks, so every fragment of rank 1 is a duplicate of one on rank 0 and only the all-gathered fragment
+    tables find that out.  The stitched d blocks must equal, byte for byte, what one GPU writes for the whole corpus."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one, two = str(tmp_path / "one.bin"), str(tmp_path / "two.bin")
+    common = ["--steps", "1", "--warmup", "1", "--copies", "4", "--scale", "0.05", "--no-cpu-baseline", "--no-verify", "--workload", "silesia_x256_m1"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-archive", one] + common, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--shared-corpus", "--dump-archive", two] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    a, b = open(one, "rb").read(), open(two, "rb").read()
+    assert len(a) > 100000 and a == b
