@@ -125,6 +125,16 @@ int zpq_file_checksums_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
  * iff first[i] == i.  Deterministic regardless of scheduling. */
 int zpq_dedup_dev(zpq_ctx* ctx, const uint8_t* d_digests, size_t n, uint32_t* d_first);
 
+/* ---- block method hint (row a4) ------------------------------------------------------------- */
+/* What zpaq's add() appends to the method it hands to compressBlock, "method,R,t" (ZSFX/libzpaq.h:86-135), comes from
+ * per-fragment statistics: d_stats[4*i+0] = order-1 prediction hits of fragment i (c == o1[c1] with the table reset at
+ * the fragment start: the count the fragment loop keeps), [1] = 1 if the fragment looks like
+ * text, [2] = 1 if it looks like x86 code, [3] = its length.  R = 256 * hits / bytes over a block's fragments (capped
+ * at 255), t = (exe fragments > 1/8) * 2 + (text fragments > 1/4).  The text / exe detectors are this engine's own
+ * (zpaqfranz.cpp is not in the snapshot): parity unpinned.  Extents as for zpq_sha1_extents_dev. */
+int zpq_fragment_stats_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off, const uint32_t* d_len, size_t n,
+                           uint32_t* d_stats);
+
 /* ---- block packer data movement (row a4) ---------------------------------------------------- */
 /* Copies n extents: d_dst_base[dst_off[i] .. +len[i]) = d_src_base[src_off[i] .. +len[i]).
  * The host-side packer (which fragments go to which block, in which order) stays host logic as in

@@ -100,3 +100,50 @@ def test_hostile_bwt_streams_are_refused(eng):
     assert r["status"] in (-6, 0)
     if r["status"] == 0:
         assert len(r["data"]) == len(data)
+
+
+def _o1_hits(b):
+    o1 = [0] * 256; c1 = 0; hits = 0
+    for c in b:
+        hits += o1[c1] == c
+        o1[c1] = c; c1 = c
+    return hits
+
+
+def test_fragment_statistics_and_method_hint(eng):
+    """Row a4: the order-1 hit count of a fragment is the one the fragment loop defines (table
+    reset per fragment) -- checked against the plain loop; with ZPQJ_METHOD_HINT every d block is compressed with
+    "1B,R,t" derived from it, so text, x86-like and incompressible blocks get different LZ77 variants (E8E9, stored),
+    and the archive still extracts (the REAL reference decoder walks it too)."""
+    import ctypes as C
+    import numpy as np
+    from zpaqfranz_amd import engine as E
+    frs = [datagen.text_like(30000, 1), exe_like(40000, 2), datagen.random_bytes(20000, 3), b"", b"a" * 5000, datagen.mixed(70001, 4)]
+    blob = b"".join(frs)
+    off = np.cumsum([0] + [len(f) for f in frs[:-1]]).astype(np.uint64)
+    ln = np.array([len(f) for f in frs], dtype=np.uint32)
+    d = eng.upload(blob); d_off = eng.upload(off.tobytes()); d_len = eng.upload(ln.tobytes()); d_st = eng.alloc(16 * len(frs))
+    try:
+        eng._ck(eng.L.zpq_fragment_stats_dev(eng.ctx, d.ptr, d_off.ptr, d_len.ptr, len(frs), d_st.ptr))
+        eng.sync()
+        st = np.frombuffer(d_st.download(16 * len(frs)), dtype=np.uint32).reshape(-1, 4)
+    finally:
+        for b in (d, d_off, d_len, d_st):
+            b.free()
+    assert st[:, 0].tolist() == [_o1_hits(f) for f in frs]
+    assert st[:, 3].tolist() == [len(f) for f in frs]
+    assert st[0, 1] == 1 and st[0, 2] == 0 and st[1, 2] == 1 and st[2, 1] == 0 and st[2, 2] == 0
+    # an archive whose blocks differ in kind: 1 MiB blocks ("10"), hint on
+    files = [("text.txt", datagen.text_like(900000, 5)), ("prog.exe", exe_like(900000, 6)), ("noise.bin", datagen.random_bytes(900000, 7))]
+    arc, stats = E.jidac_add(eng, b"", files, 20240101000000, method="10", hint=True)
+    assert E.jidac_extract(eng, arc) == dict(files)
+    methods = set()
+    pos = 0
+    while pos < len(arc):
+        r = orc.ref_decompress_block(arc[pos:], 1 << 21)
+        if r["filename"][17:18] == b"d":
+            k = arc.index(b"zPQ", pos) + 5
+            methods.add(bytes(arc[k: k + 2 + (arc[k] | arc[k + 1] << 8)]))
+        assert r["sha1_ok"] == 1
+        pos += r["consumed"]
+    assert len(methods) >= 2          # not one header for everything: the hint chose per block

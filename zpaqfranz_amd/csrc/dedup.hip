@@ -112,3 +112,59 @@ extern "C" int zpq_gather_dev(zpq_ctx* ctx, const uint8_t* d_src_base, const uin
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
+
+// ---- per-fragment statistics for the block method hint (row a4) -----------------------------------------------------------
+// zpaq's add() passes "method,R,t" to compressBlock (ZSFX/libzpaq.h:86-135): R = 0..255 redundancy of the block, t bit 0
+// = text, bit 1 = x86.  R comes from the order-1 prediction hits the fragment loop counts anyway (c == o1[c1], table reset
+// per fragment -- SURVEY.md Appendix C.4); the text / exe detectors live in the missing zpaqfranz.cpp, so the ones here are
+// this engine's own (PARITY UNPINNED): a fragment votes "text" when at least 15/16 of its bytes are
+// letters, digits, blanks or common punctuation and none is a control byte below 9, and "exe" when at least one byte in
+// 48 is 0x8B (mov reg, r/m) or an E8/E9 followed four bytes later by 00/FF.
+// One lane per fragment (unique fragments only: a few hundred MB at most per job), o1[] in LDS, 16 bytes per load.
+namespace {
+__global__ __launch_bounds__(64) void fragment_stats_kernel(const u8* __restrict__ base, const u64* __restrict__ off, const u32* __restrict__ len,
+                                                            u32 n, u32* __restrict__ stats) {
+  __shared__ u8 tab[256 * 64];
+  const u32 lane = (u32)lane_id();
+  const u32 f = blockIdx.x * 64u + lane;
+  for (u32 v = 0; v < 256; ++v) tab[v * 64 + lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (f >= n) return;
+  const u8* p = base + off[f];
+  const u32 L = len[f];
+  u32 hits = 0, text = 0, ctrl = 0, x86 = 0, c1 = 0, w4 = 0;     // w4: the last four bytes (oldest in the high byte)
+  for (u32 i = 0; i < L; i += 16) {
+    const u32x4 d = *(const u32x4_u*)(p + i);                    // (readable 64 bytes past the end: include/zpaqhip.h)
+    const u32 wv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (i + j >= L) break;
+      const u32 c = (wv[j >> 2] >> (8 * (j & 3))) & 255u;
+      const u32 a = c1 * 64 + lane;
+      hits += tab[a] == c;
+      tab[a] = (u8)c;
+      c1 = c;
+      const bool alnum = (c - 'a' < 26u) || (c - 'A' < 26u) || (c - '0' < 10u);
+      text += alnum || c == ' ' || c == '.' || c == ',' || c == '\n' || c == '\r' || c == '\t' || c == ';' || c == ':' || c == '\'' || c == '"' || c == '-' || c >= 128;
+      ctrl += c < 9;
+      const u32 old = w4 >> 24;                                  // the byte four positions back
+      x86 += c == 0x8b || ((old & 0xfe) == 0xe8 && (c == 0 || c == 255));
+      w4 = w4 << 8 | c;
+    }
+  }
+  stats[4 * f + 0] = hits;
+  stats[4 * f + 1] = (L >= 16 && text * 16 >= L * 15 && ctrl == 0) ? 1u : 0u;
+  stats[4 * f + 2] = (L >= 48 && x86 * 48 >= L) ? 1u : 0u;
+  stats[4 * f + 3] = L;
+}
+}  // namespace
+
+extern "C" int zpq_fragment_stats_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* d_off, const uint32_t* d_len, size_t n, uint32_t* d_stats) {
+  if (!ctx) return ZPQ_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  if (n == 0) return ZPQ_OK;
+  if (n > 0xffffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many fragments");
+  ZPQ_LAUNCH(ctx, "fragment_stats_kernel", ctx->stream, fragment_stats_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), d_base, d_off, d_len, (u32)n, d_stats);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}

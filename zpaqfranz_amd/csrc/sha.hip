@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "zpq_internal.h"
 
 namespace {
@@ -312,12 +314,21 @@ __device__ __forceinline__ void sha256_rounds_lane(const u32 (&wk)[64], int blk,
 // else runs beside them (the lane-wise kernel) instead of one SIMD here and there.
 __global__ __launch_bounds__(256) void sha256_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                            const u64* __restrict__ len, u32 n, u64 min_len,
-                                                           u8* __restrict__ digests, const u32* __restrict__ list, u32* __restrict__ queue) {
+                                                           u8* __restrict__ digests, const u32* __restrict__ list, u32* __restrict__ queue,
+                                                           u32 rot) {
   const int lane = lane_id();
   const u32 waves = gridDim.x * 4u;
-  // with a queue the waves take the (longest-first) list entries as they get free; without, in strides
+  // with a queue the waves take the (longest-first) list entries as they get free; without, in strides.  The first
+  // entry of every wave is fixed, rotated by `rot`: several jobs in flight (each with its own launch of this kernel)
+  // then put their longest chains on different compute units instead of all on the first ones to start.
+  bool first = true;
   for (u32 k = blockIdx.x * 4u + (threadIdx.x >> 6);; k += waves) {
-    if (queue) { u32 q = 0; if (lane == 0) q = atomicAdd(queue, 1u); k = __builtin_amdgcn_readfirstlane(q); }
+    if (queue) {
+      if (first) k = (k + rot) % waves;
+      else { u32 q = 0; if (lane == 0) q = atomicAdd(queue, 1u); k = __builtin_amdgcn_readfirstlane(q) + waves; }
+      first = false;
+      if (k >= n) { if (k < waves) continue; break; }
+    }
     if (k >= n) break;
     const u32 idx = list ? list[k] : k;
     const u64 total = len[idx];
@@ -552,8 +563,11 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
       ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
       const size_t cw = std::min(kc, max_chains);         // persistent waves, one per SIMD at most
+      static std::atomic<u32> calls{0};
+      const u32 nw = (u32)((cw + 3) / 4) * 4u;
+      const u32 rot = (calls.fetch_add(1) * 341u) % nw;
       ZPQ_LAUNCH(ctx, "sha256_chain_kernel", ctx->stream2, sha256_chain_kernel, dim3((unsigned)((cw + 3) / 4)), dim3(256), d_base, d_off, d_len, (u32)kc, (u64)0,
-                 d_digests, (const u32*)d_ord, counter + 1);
+                 d_digests, (const u32*)d_ord, counter + 1, rot);
       ZPQ_HIP(ctx, hipGetLastError());
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
     }
@@ -575,7 +589,7 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
   {
     const unsigned waves = (unsigned)std::min<size_t>(n, max_chains);
     ZPQ_LAUNCH(ctx, "sha256_chain_kernel", st, sha256_chain_kernel, dim3((waves + 3) / 4), dim3(256), d_base, d_off, d_len, (u32)n, chain_min,
-               d_digests, (const u32*)nullptr, (u32*)nullptr);
+               d_digests, (const u32*)nullptr, (u32*)nullptr, 0u);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   return ZPQ_OK;

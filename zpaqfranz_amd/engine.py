@@ -76,6 +76,7 @@ def load():
     L.zpq_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.zpq_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.zpq_dev_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
+    L.zpq_fragment_stats_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_device_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
     L.zpq_sha1_extents_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_sha256_extents_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -537,7 +538,7 @@ def load_shim():
     return _shim
 
 
-def jidac_add(eng, archive, files, version_date, method="14", dates=None, checksums=False):
+def jidac_add(eng, archive, files, version_date, method="14", dates=None, checksums=False, hint=False):
     """files: list of (name, bytes).  Returns (bytes to append to the archive, stats dict).  `eng` may be a list of
     engines (one per GPU): the files are then sharded across them (zpqj_add_multi), with identical output."""
     S = load_shim()
@@ -552,11 +553,11 @@ def jidac_add(eng, archive, files, version_date, method="14", dates=None, checks
     dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
     out, out_len = C.c_void_p(), C.c_size_t(0)
     stats = (C.c_uint64 * 6)()
-    if checksums:
+    if checksums or hint:
         es = engs or [eng]
         ctxs = (C.c_void_p * len(es))(*[e.ctx.value for e in es])
         rc = S.zpqj_add_opts(ctxs, len(es), bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,
-                             version_date, method.encode(), 1, C.byref(out), C.byref(out_len), stats)
+                             version_date, method.encode(), (1 if checksums else 0) | (2 if hint else 0), C.byref(out), C.byref(out_len), stats)
     elif engs:
         ctxs = (C.c_void_p * len(engs))(*[e.ctx.value for e in engs])
         rc = S.zpqj_add_multi(ctxs, len(engs), bytes(archive) if archive else None, len(archive) if archive else 0, names, datas, sizes, dts, n,

@@ -271,6 +271,8 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   *out = nullptr; *out_len = 0;
   if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
   const bool checksums = (flags & ZPQJ_FILE_CHECKSUMS) != 0;
+  bool hint = (flags & ZPQJ_METHOD_HINT) != 0;
+  for (const char* q = method; hint && q && *q; ++q) if (*q < '0' || *q > '9') hint = false;     // only for "LB" methods
   zpq_ctx* ctx = ctxs[0];
   Index ix;
   if (archive && archive_len) { int rc = read_index(ctx, archive, archive_len, ix); if (rc) return rc; }
@@ -392,10 +394,36 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     }
     void* d_out;
     if ((rc = zpq_dev_alloc(c, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
+    // "method,R,t" per block (zpaq's add(); ZSFX/libzpaq.h:86-135): R from the order-1 hits of its fragments, t from the
+    // text / exe votes -- one lane per fragment over the assembled blocks
+    std::vector<std::string> mth(mine.size(), std::string(method));
+    if (hint) {
+      std::vector<uint64_t> fo; std::vector<uint32_t> fl; std::vector<size_t> fb;
+      for (size_t m = 0; m < mine.size(); ++m) {
+        uint64_t q = boff[m];
+        for (size_t k = blocks[mine[m]].first; k < blocks[mine[m]].second; ++k) { fo.push_back(q); fl.push_back(flen[newfrags[k]]); fb.push_back(m); q += flen[newfrags[k]]; }
+      }
+      void *d_fo, *d_fl, *d_st;
+      if ((rc = zpq_dev_alloc(c, fo.size() * 8 + 64, &d_fo))) return rc; dev.p.push_back(d_fo);
+      if ((rc = zpq_dev_alloc(c, fo.size() * 4 + 64, &d_fl))) return rc; dev.p.push_back(d_fl);
+      if ((rc = zpq_dev_alloc(c, fo.size() * 16 + 64, &d_st))) return rc; dev.p.push_back(d_st);
+      if ((rc = zpq_h2d(c, d_fo, fo.data(), fo.size() * 8)) || (rc = zpq_h2d(c, d_fl, fl.data(), fl.size() * 4))) return rc;
+      if ((rc = zpq_fragment_stats_dev(c, (const uint8_t*)d_blk, (const uint64_t*)d_fo, (const uint32_t*)d_fl, fo.size(), (uint32_t*)d_st))) return rc;
+      std::vector<uint32_t> st(fo.size() * 4);
+      if ((rc = zpq_d2h(c, st.data(), d_st, st.size() * 4))) return rc;
+      std::vector<uint64_t> hits(mine.size(), 0), bytes(mine.size(), 0); std::vector<uint32_t> nf(mine.size(), 0), tx(mine.size(), 0), ex(mine.size(), 0);
+      for (size_t i = 0; i < fo.size(); ++i) { const size_t m = fb[i]; hits[m] += st[4 * i]; tx[m] += st[4 * i + 1]; ex[m] += st[4 * i + 2]; bytes[m] += st[4 * i + 3]; ++nf[m]; }
+      for (size_t m = 0; m < mine.size(); ++m) {
+        uint64_t R = hits[m] * 256 / (bytes[m] + 1);
+        if (R > 255) R = 255;
+        const unsigned t = (ex[m] * 8 > nf[m] ? 2u : 0u) + (tx[m] * 4 > nf[m] ? 1u : 0u);
+        mth[m] += "," + std::to_string(R) + "," + std::to_string(t);
+      }
+    }
     for (size_t m = 0; m < mine.size(); ++m) {
       zpq_block_job& j = jobs[m];
       memset(&j, 0, sizeof j);
-      j.in = (uint8_t*)d_blk + boff[m]; j.n = bn[m]; j.method = method; j.filename = nm[m].c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
+      j.in = (uint8_t*)d_blk + boff[m]; j.n = bn[m]; j.method = mth[m].c_str(); j.filename = nm[m].c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
       j.out = (uint8_t*)d_out + ooff[m]; j.out_cap = (uint32_t)zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01");
     }
     if ((rc = zpq_sync(c))) return rc;

@@ -20,6 +20,8 @@ int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, si
                    int64_t version_date, const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]);
 /* zpqj_add_multi with options */
 #define ZPQJ_FILE_CHECKSUMS 1u   /* store XXHASH64 + CRC-32 of every file in its i-block attribute (zpaqfranz's default) */
+#define ZPQJ_METHOD_HINT 2u      /* method "LB" (digits only): every d block gets "LB,R,t" from its fragments' statistics
+                                  * (zpq_fragment_stats_dev), as zpaq's add() does; the detectors are unpinned */
 int zpqj_add_opts(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
                   const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
                   int64_t version_date, const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]);
