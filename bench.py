@@ -849,6 +849,12 @@ def main_cm_m5(a, rank, world, local, dev):
         k_ms = kern.get("cm_spec_encode", kern.get("cm_wave_kernel", (1, 0.0)))
         per = k_ms[1] / max(1, k_ms[0])
         ach = (total + out_bytes / world) / 1e9 / (per / 1e3) if per else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_cm_m5.json")       # PMC bytes per launch of the 2048 x 64 KiB profile run, scaled by input size
+        if os.path.exists(tf):
+            t_ = json.load(open(tf)).get("bytes_per_launch", {}).get("cm_spec_encode")
+            if t_:
+                traffic = int(t_ * total / (2048.0 * 65536))
         res = {"metric": "MB/s compressed output at -m5 (context mixing: 22-component Predictor + arithmetic coder), %d blocks of %d KiB of text per GPU" % (nb, bs >> 10),
                "value": round(out_bytes / 1e6 / sec, 3), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
@@ -860,7 +866,7 @@ def main_cm_m5(a, rank, world, local, dev):
                "input_KBps_per_block": round(total / nb / 1e3 / (per / 1e3), 1) if per else None,
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                "roofline": {"bound": "hbm", "kernel": "cm_spec_encode", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(per, 3),
+                            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(per, 3),
                             "launches_per_step": round(k_ms[0] / steps, 2), "algorithmic_bytes_per_step": int(total + out_bytes / world),
                             "note": "one serial chain of bit decisions per block (a wave each): bounded by instruction issue and dependent "
                                     "table lookups, not by HBM bytes (1 B read + r B written per input byte)"}}
@@ -1217,6 +1223,8 @@ def main():
                           **({"corpus": "one Silesia x%d split by file range over %d ranks" % (a.copies, world)} if shared else {}),
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
+               "identity": "per d block and per table: every block, fragment boundary, SHA-1 and the dedup map equal the reference-derived oracle; "
+                           "whole-archive identity is not provable here (block cut rule, R,t hint and file order of the missing zpaqfranz.cpp are unpinned)",
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
                "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
