@@ -203,7 +203,7 @@ int main(int argc, char** argv) {
     // an unsupported method must surface through libzpaq::error, not be approximated
     try {
       libzpaq::StringBuffer sb, o; sb.write("hello", 5);
-      libzpaq::compressBlock(&sb, &o, "3", 0, 0, true);   // level 3: byte-aligned LZ77 or BWT front end
+      libzpaq::compressBlock(&sb, &o, "x4,6,4,0,3,24c0", 0, 0, true);   // byte-aligned LZ77 codes with the hash-table match finder: not implemented
       printf("unsupported: NOT refused\n");
     } catch (std::exception& e) { printf("unsupported: refused (%s)\n", e.what()); }
   } catch (std::exception& e) {
