@@ -239,7 +239,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   if (nmix > 8 || nsse > 4) { *why = "more mixers / SSE stages than the wave coder keeps in registers"; return ZPQ_ERR_METHOD; }
   const bool h_lds = P.hh <= 10;
   // waves per workgroup: the tables (86 KiB) are shared, H[] is per wave; one workgroup per compute unit
-  u32 waves = 16;
+  u32 waves = getenv("ZPQ_CM_SPEC") ? 8 : 16;      // (the one-bit-ahead values need the registers of a 512-thread bound)
   while (waves > 1 && 88064u + (h_lds ? waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
   std::string s;
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
@@ -251,6 +251,11 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   s += "#define Z_FOR_MIX(X) " + mixes + "\n#define Z_FOR_SSE(X) " + sses + "\n#define Z_CHAIN " + chain + "\n";
   s += "#define Z_ISSE_FAR_INPUTS " + far_inputs + "\n#define Z_MIX2_UPDATES " + mix2_updates + "\n";
   if (getenv("ZPQ_CM_PROF")) s += "#define ZPROF 1\n";
+  // requesting the next bit's entries one bit early (both outcomes): bit-exact, measured SLOWER (1.25 s against 1.03 s
+  // for a 100 KB block, 448 against 400 ms for 2048 blocks): the ~80 instructions it adds per bit cost more than the
+  // waits it removes -- most of a bit's waiting is LDS latency on the dependent chain, not the round of loads.  Kept
+  // behind ZPQ_CM_SPEC=1 for tuning.
+  s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") ? "1" : "0") + "\n";
   std::string body = kSpecSrc;
   const std::string marker = "//@@HCOMP@@";
   const size_t k = body.find(marker);
@@ -319,7 +324,7 @@ int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out) {
     return zpq_fail(ctx, ZPQ_ERR_HIP, "specialised coder: kernels missing from the module");
   }
   k->h_lds = P.hh <= 10;
-  k->waves = 16;
+  k->waves = getenv("ZPQ_CM_SPEC") ? 8 : 16;
   while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
   std::lock_guard<std::mutex> lk(g_mu);
   auto ins = g_mods.insert({{ctx->device, key}, k});
