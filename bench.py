@@ -426,9 +426,9 @@ def verify_add(pipe, layout, corpus, threads):
                 ok_dig = False; break
         res["verified_fragments"] = bool(ok_len and ok_dig)
     else:
-        # dup8: every file is 4 units; the oracle fragments and hashes a sample of files (all of them would be 128 GiB of CPU work)
+        # dup8: every file is 4 units; the oracle fragments and hashes a sample of files (all of them would be 128 GiB of CPU work; blocks and the dedup map below ARE checked completely)
         rng = np.random.default_rng(1)
-        sample = sorted(set(rng.integers(0, pipe.nfiles, 24).tolist()))
+        sample = sorted(set(rng.integers(0, pipe.nfiles, 256).tolist()))    # ~11 % of the files (17 GB through the oracle)
         pool = np.frombuffer(layout["pool_bytes"], dtype=np.uint8)
         bounds = np.searchsorted(ffile, np.arange(pipe.nfiles + 1))
 
