@@ -80,3 +80,14 @@ def test_libzpaq_shim_builds_and_links(tmp_path, lib):
     syms = subprocess.run(["nm", "-DC", so], capture_output=True, text=True).stdout
     for name in ("libzpaq::compressBlock", "libzpaq::compress(", "libzpaq::decompress", "libzpaq::SHA1::result", "libzpaq::SHA256::result"):
         assert name in syms, name
+
+
+def test_journaling_library_exports_every_symbol_of_its_header(lib):
+    """zpaqfranz_amd/shim/jidac_gpu.h (the journaling C ABI, incl. the process-sharded add) vs libzpaq_jidac.so."""
+    import ctypes, re
+    hdr = open(os.path.join(ROOT, "zpaqfranz_amd", "shim", "jidac_gpu.h")).read()
+    names = set(re.findall(r"\b(zpqj_\w+)\s*\(", hdr)) - {"zpqj_allgatherv_fn"}
+    assert {"zpqj_add", "zpqj_add_multi", "zpqj_add_opts", "zpqj_add_sharded", "zpqj_shard_files", "zpqj_extract", "zpqj_verify", "zpqj_free"} <= names
+    S = ctypes.CDLL(os.path.join(ROOT, "zpaqfranz_amd", "libzpaq_jidac.so"))
+    for n in sorted(names):
+        assert hasattr(S, n), n

@@ -1,0 +1,139 @@
+"""zpqj_add_sharded: the journaling add across PROCESSES, one GPU each, with ONE caller-supplied
+collective (an all-gather of byte strings).  CPU part: the file plan and the torch.distributed all-gather helper
+(gloo, world 2).  GPU part: two processes on the same device produce, each, exactly the archive one GPU writes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _corpus(seed=11, nfiles=40):
+    """Files of 0..700 KB with repeats inside and across files (so dedup pointers cross the range edge) and one file
+    made of pieces of the others."""
+    rng = np.random.default_rng(seed)
+    pool = [rng.integers(0, 64, size=int(rng.integers(20000, 300000)), dtype=np.uint8).tobytes() for _ in range(12)]
+    files = []
+    for i in range(nfiles):
+        k = int(rng.integers(0, 4))
+        body = b"".join(pool[int(rng.integers(0, 12))] for _ in range(k))
+        if i % 7 == 3:
+            body += rng.integers(0, 256, size=int(rng.integers(1, 90000)), dtype=np.uint8).tobytes()
+        files.append(("dir%d/f%03d.bin" % (i % 3, (i * 17) % 101), body))
+    return files
+
+
+def test_shard_files_is_a_partition_into_contiguous_name_ranges():
+    from zpaqfranz_amd import build, engine
+    build.build(verbose=False)
+    files = _corpus()
+    names, sizes = [f[0] for f in files], [len(f[1]) for f in files]
+    order = sorted(range(len(files)), key=lambda i: names[i].encode())
+    for world in (1, 2, 3, 8, 64):
+        marks = [engine.jidac_shard_files(names, sizes, world, r) for r in range(world)]
+        owner = [[r for r in range(world) if marks[r][i]] for i in range(len(files))]
+        assert all(len(o) == 1 for o in owner)                                  # every file exactly once
+        seq = [owner[i][0] for i in order]
+        assert seq == sorted(seq)                                               # contiguous ranges in name order
+        if world == 2:
+            half = sum(sizes[i] for i in order if owner[i][0] == 0)
+            assert abs(half - sum(sizes) / 2) <= max(sizes)
+    with pytest.raises(engine.ZpqError):
+        engine.jidac_shard_files(names, sizes, 2, 2)
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zpaqfranz_amd import engine
+    ag = engine.dist_allgather_bytes()
+    got = [ag(b"" if rank else b"x" * 70001), ag(bytes([rank]) * (3 + rank)), ag(b"")]
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_of_byte_strings_over_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    want = [[b"x" * 70001, b""], [b"\0" * 3, b"\1" * 4], [b"", b""]]
+    assert res[0] == want and res[1] == want
+
+
+def _add_worker(rank, world, port, q, method, flags):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zpaqfranz_amd import engine
+    files = _corpus()
+    names, sizes = [f[0] for f in files], [len(f[1]) for f in files]
+    mine = engine.jidac_shard_files(names, sizes, world, rank)
+    part = [(n, b if m else None, len(b)) for (n, b), m in zip(files, mine)]      # other ranks' data is never passed in
+    eng = engine.Engine(0)
+    arc, st = engine.jidac_add_sharded(eng, rank, world, engine.dist_allgather_bytes(), None, part, 20260925120000, method, **flags)
+    # a second version on top: half of the files changed, the old fragments are known from the archive
+    files2 = [(n, (b[:len(b) // 2] + b"new" + b[len(b) // 2:]) if i % 2 else b) for i, (n, b) in enumerate(files)]
+    sizes2 = [len(f[1]) for f in files2]
+    mine2 = engine.jidac_shard_files(names, sizes2, world, rank)
+    part2 = [(n, b if m else None, len(b)) for (n, b), m in zip(files2, mine2)]
+    arc2, st2 = engine.jidac_add_sharded(eng, rank, world, engine.dist_allgather_bytes(), arc, part2, 20260925130000, method, **flags)
+    q.put((rank, arc, st, arc2, st2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,flags", [("14", {}), ("1", {"checksums": True}), ("24", {"hint": True})])
+def test_two_processes_write_the_single_gpu_archive(method, flags):
+    from zpaqfranz_amd import engine
+    files = _corpus()
+    eng = engine.Engine(0)
+    want, wst = engine.jidac_add(eng, None, files, 20260925120000, method, **flags)
+    files2 = [(n, (b[:len(b) // 2] + b"new" + b[len(b) // 2:]) if i % 2 else b) for i, (n, b) in enumerate(files)]
+    want2, wst2 = engine.jidac_add(eng, want, files2, 20260925130000, method, **flags)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_add_worker, args=(r, 2, port, q, method, flags)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+    for r in range(2):
+        arc, st, arc2, st2 = res[r]
+        assert arc == want and st == wst, r
+        assert arc2 == want2 and st2 == wst2, r
+    assert wst["d_blocks"] >= 1 and wst2["new_fragments"] > 0
+    got = engine.jidac_extract(eng, want + want2)
+    assert got == dict(files2)
+
+
+@pytest.mark.gpu
+def test_a_failing_collective_fails_the_add():
+    from zpaqfranz_amd import engine
+    files = _corpus(nfiles=6)
+    part = [(n, b, len(b)) for n, b in files]
+    eng = engine.Engine(0)
+
+    def broken(_):
+        raise RuntimeError("link down")
+    with pytest.raises(RuntimeError, match="link down"):
+        engine.jidac_add_sharded(eng, 0, 1, broken, None, part, 20260925120000, "14")
+    arc, _ = engine.jidac_add_sharded(eng, 0, 1, lambda b: [b], None, part, 20260925120000, "14")     # world 1: the plain add
+    assert arc == engine.jidac_add(eng, None, files, 20260925120000, "14")[0]

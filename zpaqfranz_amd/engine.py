@@ -534,8 +534,92 @@ def load_shim():
         S.zpqj_verify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
         S.zpqj_add_opts.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        S.zpqj_add_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLGATHERV, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t), C.c_void_p]
+        S.zpqj_shard_files.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _shim = S
     return _shim
+
+
+ALLGATHERV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+
+
+def dist_allgather_bytes(group=None):
+    """An all-gather of byte strings over torch.distributed (RCCL on the GPU box, gloo on CPU): lengths first, then the
+    strings padded to the longest.  Returns f(bytes) -> [bytes per rank]."""
+    import torch
+    import torch.distributed as dist
+
+    def f(b):
+        world = dist.get_world_size(group)
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        n = torch.tensor([len(b)], dtype=torch.int64, device=dev)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n, group=group)
+        ns = [int(x.item()) for x in ns]
+        m = max(1, max(ns))
+        t = torch.zeros(m, dtype=torch.uint8, device=dev)
+        if b:
+            t[:len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t, group=group)
+        return [bytes(ts[r][:ns[r]].cpu().numpy().tobytes()) for r in range(world)]
+    return f
+
+
+def jidac_shard_files(names, sizes, world, rank):
+    """Which files rank `rank` of `world` supplies to jidac_add_sharded: a list of bools in the order given."""
+    S = load_shim()
+    n = len(names)
+    nm = (C.c_char_p * max(1, n))(*[x.encode() for x in names])
+    sz = (C.c_uint64 * max(1, n))(*sizes)
+    mine = (C.c_uint8 * max(1, n))()
+    rc = S.zpqj_shard_files(nm, sz, n, world, rank, mine)
+    if rc != 0:
+        raise ZpqError(rc, "zpqj_shard_files")
+    return [bool(mine[i]) for i in range(n)]
+
+
+def jidac_add_sharded(eng, rank, world, allgather, archive, files, version_date, method="14", dates=None, checksums=False, hint=False):
+    """zpqj_add_sharded: one PROCESS per GPU.  files: list of (name, bytes-or-None, size) -- bytes only for the files
+    jidac_shard_files marks for this rank.  allgather: f(bytes) -> [bytes of every rank] (e.g. dist_allgather_bytes()).
+    Every rank returns the same (archive bytes, stats)."""
+    S = load_shim()
+    n = len(files)
+    names = (C.c_char_p * max(1, n))(*[f[0].encode() for f in files])
+    keep = [C.create_string_buffer(bytes(f[1]), max(1, len(f[1]))) if f[1] is not None else None for f in files]
+    datas = (C.c_void_p * max(1, n))(*[C.cast(k, C.c_void_p).value if k is not None else None for k in keep])
+    sizes = (C.c_uint64 * max(1, n))(*[f[2] for f in files])
+    dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
+    out, out_len = C.c_void_p(), C.c_size_t(0)
+    stats = (C.c_uint64 * 6)()
+    held, err = [], []
+
+    def cb(user, send, send_len, recv, recv_len):
+        try:
+            got = allgather(C.string_at(send, send_len) if send_len else b"")
+            del held[:]
+            for r in range(world):
+                buf = C.create_string_buffer(got[r], max(1, len(got[r])))
+                held.append(buf)
+                recv[r] = C.cast(buf, C.c_void_p).value
+                recv_len[r] = len(got[r])
+            return 0
+        except Exception as e:          # an exception cannot cross the C frames: report it after the call
+            err.append(e)
+            return 1
+    rc = S.zpqj_add_sharded(eng.ctx, rank, world, ALLGATHERV(cb), None, bytes(archive) if archive else None, len(archive) if archive else 0,
+                            names, datas, sizes, dts, n, version_date, method.encode(), (1 if checksums else 0) | (2 if hint else 0),
+                            C.byref(out), C.byref(out_len), stats)
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    data = C.string_at(out.value, out_len.value)
+    S.zpqj_free(out)
+    keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
+    return data, dict(zip(keys, [int(x) for x in stats]))
 
 
 def jidac_add(eng, archive, files, version_date, method="14", dates=None, checksums=False, hint=False):

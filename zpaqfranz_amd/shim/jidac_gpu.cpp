@@ -265,11 +265,41 @@ int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes,
   return ZPQ_OK;
 }
 
+// Contiguous ranges (in name order) of about equal bytes: range r is order[edge[r] .. edge[r+1]).
+void shard_plan(const std::vector<size_t>& order, const uint64_t* sizes, size_t nctx, std::vector<size_t>& edge) {
+  const size_t nfiles = order.size();
+  uint64_t total = 0;
+  for (size_t i = 0; i < nfiles; ++i) total += sizes[i];
+  edge.assign(nctx + 1, 0);
+  size_t f = 0; uint64_t acc = 0;
+  for (size_t r = 0; r < nctx; ++r) {
+    edge[r] = f;
+    const uint64_t goal = total / nctx * (r + 1) + (r + 1 == nctx ? total : 0);
+    while (f < nfiles && (r + 1 == nctx || acc + sizes[order[f]] / 2 <= goal)) acc += sizes[order[f++]];
+    edge[r + 1] = f;
+  }
+}
+
+// Process-sharded runs: the ranges of the plan above live in `world` processes (one GPU each); what the in-process form
+// reads from its neighbours' Shard objects travels through ONE caller-supplied primitive, an all-gather of byte strings
+// (RCCL / MPI / anything): fragment tables, the few fragments a block needs from another rank, the compressed blocks.
+struct Xchg { int rank, world; zpqj_allgatherv_fn fn; void* user; };
+int xchg_all(const Xchg& X, const Bytes& send, std::vector<Bytes>& got) {
+  std::vector<void*> rp(X.world, nullptr); std::vector<size_t> rl(X.world, 0);
+  const int rc = X.fn(X.user, send.data(), send.size(), rp.data(), rl.data());
+  if (rc) return ZPQ_ERR_ARG;
+  got.assign(X.world, Bytes());
+  for (int r = 0; r < X.world; ++r) if (rl[r]) got[r].assign((const uint8_t*)rp[r], (const uint8_t*)rp[r] + rl[r]);
+  return ZPQ_OK;
+}
+
 int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
              const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
-             uint8_t** out, size_t* out_len, uint64_t stats[6], uint32_t flags = 0) {
+             uint8_t** out, size_t* out_len, uint64_t stats[6], uint32_t flags = 0, const Xchg* X = nullptr) {
   *out = nullptr; *out_len = 0;
   if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
+  const size_t me = X ? (size_t)X->rank : 0;
+  if (X) { if (X->world < 1 || X->rank < 0 || X->rank >= X->world || !X->fn) return ZPQ_ERR_ARG; nctx = (size_t)X->world; }
   const bool checksums = (flags & ZPQJ_FILE_CHECKSUMS) != 0;
   bool hint = (flags & ZPQJ_METHOD_HINT) != 0;
   for (const char* q = method; hint && q && *q; ++q) if (*q < '0' || *q > '9') hint = false;     // only for "LB" methods
@@ -283,23 +313,46 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   for (size_t i = 0; i < nfiles; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
   // 1. contiguous file ranges of about equal bytes, one per context; fragment + hash per range (one host thread each)
-  uint64_t total = 0;
-  for (size_t i = 0; i < nfiles; ++i) total += sizes[i];
   std::vector<Shard> sh(nctx);
   {
-    size_t f = 0; uint64_t acc = 0;
-    for (size_t r = 0; r < nctx; ++r) {
-      sh[r].ctx = ctxs[r]; sh[r].f0 = f;
-      const uint64_t goal = total / nctx * (r + 1) + (r + 1 == nctx ? total : 0);
-      while (f < nfiles && (r + 1 == nctx || acc + sizes[order[f]] / 2 <= goal)) acc += sizes[order[f++]];
-      sh[r].f1 = f;
-    }
+    std::vector<size_t> edge;
+    shard_plan(order, sizes, nctx, edge);
+    for (size_t r = 0; r < nctx; ++r) { sh[r].ctx = X ? (r == me ? ctxs[0] : nullptr) : ctxs[r]; sh[r].f0 = edge[r]; sh[r].f1 = edge[r + 1]; }
   }
   {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums); });
+    for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
+  }
+  if (X) {
+    // exchange 1: every rank's fragment table (lengths, owning files, SHA-1s) and file checksums
+    Bytes snd; std::vector<Bytes> got;
+    const Shard& L = sh[me];
+    put64(snd, L.nf);
+    snd.insert(snd.end(), (const uint8_t*)L.flen.data(), (const uint8_t*)L.flen.data() + L.nf * 4);
+    snd.insert(snd.end(), (const uint8_t*)L.ffile.data(), (const uint8_t*)L.ffile.data() + L.nf * 4);
+    snd.insert(snd.end(), L.dig.begin(), L.dig.begin() + L.nf * 20);
+    put64(snd, L.crc.size());
+    snd.insert(snd.end(), (const uint8_t*)L.crc.data(), (const uint8_t*)L.crc.data() + L.crc.size() * 4);
+    snd.insert(snd.end(), (const uint8_t*)L.xxh.data(), (const uint8_t*)L.xxh.data() + L.xxh.size() * 8);
+    int rcx = xchg_all(*X, snd, got);
+    if (rcx) return rcx;
+    for (size_t r = 0; r < nctx; ++r) {
+      if (r == me) continue;
+      const Bytes& g = got[r];
+      if (g.size() < 16) return ZPQ_ERR_FORMAT;
+      const uint64_t n = get64(g.data());
+      if (g.size() < 16 + n * 28) return ZPQ_ERR_FORMAT;
+      Shard& S = sh[r];
+      S.nf = (size_t)n; S.flen.resize(n); S.ffile.resize(n); S.dig.resize(n * 20);
+      memcpy(S.flen.data(), g.data() + 8, n * 4); memcpy(S.ffile.data(), g.data() + 8 + n * 4, n * 4); memcpy(S.dig.data(), g.data() + 8 + n * 8, n * 20);
+      const uint8_t* q = g.data() + 8 + n * 28;
+      const uint64_t nc = get64(q); q += 8;
+      if ((size_t)(g.data() + g.size() - q) < nc * 12) return ZPQ_ERR_FORMAT;
+      S.crc.resize(nc); S.xxh.resize(nc);
+      memcpy(S.crc.data(), q, nc * 4); memcpy(S.xxh.data(), q + nc * 4, nc * 8);
+    }
   }
   // 2. the global fragment table: ranges in order (the "all-gather"), global first-occurrence dedup on context 0
   std::vector<size_t> base(nctx + 1, 0);
@@ -343,14 +396,49 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   std::vector<Bytes> dblock(blocks.size());
   std::vector<int> brc(nctx, ZPQ_OK);
+  // exchange 2 (process-sharded): the fragments a block takes from a rank other than its owner (the packing crosses a range
+  // edge at most once per edge, so this is a few fragments per rank).  Every rank derives the same list from the global
+  // table; a sender gathers its part on the device, and xoff[k] is where fragment newfrags[k] sits in its sender's string.
+  std::vector<uint64_t> xoff;
+  std::vector<Bytes> xgot;
+  if (X) {
+    xoff.assign(newfrags.size(), 0);
+    std::vector<uint64_t> cur(nctx, 0), so, dso; std::vector<uint32_t> sl;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const size_t owner = shard_of[newfrags[blocks[b].first]];
+      for (size_t k = blocks[b].first; k < blocks[b].second; ++k) {
+        const uint32_t f = newfrags[k]; const size_t src = shard_of[f];
+        if (src == owner) continue;
+        xoff[k] = cur[src];
+        if (src == me) { so.push_back(sh[me].foff[f - base[me]]); sl.push_back(flen[f]); dso.push_back(cur[src]); }
+        cur[src] += flen[f];
+      }
+    }
+    Bytes snd((size_t)cur[me]);
+    if (!so.empty() && cur[me]) {
+      zpq_ctx* c = ctxs[0];
+      struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{c, {}};
+      void *d_st, *d_so, *d_sl, *d_dso;
+      if ((rc = zpq_dev_alloc(c, cur[me] + 64, &d_st))) return rc; dev.p.push_back(d_st);
+      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+      if ((rc = zpq_dev_alloc(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+      if ((rc = zpq_h2d(c, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(c, d_sl, sl.data(), sl.size() * 4)) ||
+          (rc = zpq_h2d(c, d_dso, dso.data(), dso.size() * 8))) return rc;
+      if ((rc = zpq_gather_dev(c, (const uint8_t*)sh[me].d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_st))) return rc;
+      if ((rc = zpq_d2h(c, snd.data(), d_st, snd.size()))) return rc;
+    }
+    if ((rc = xchg_all(*X, snd, xgot))) return rc;
+    for (size_t r = 0; r < nctx; ++r) if (r != me && xgot[r].size() != cur[r]) return ZPQ_ERR_FORMAT;
+  }
   auto compress_owned = [&](size_t r) -> int {
-    zpq_ctx* c = ctxs[r];
+    zpq_ctx* c = X ? ctxs[0] : ctxs[r];
     std::vector<size_t> mine;
     for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == r) mine.push_back(b);
     if (mine.empty()) return ZPQ_OK;
     struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{c, {}};
     std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(mine.size()); std::vector<uint32_t> bn(mine.size());
-    struct Remote { size_t src_shard; uint64_t src_off; uint64_t dst_off; uint32_t len; };
+    struct Remote { size_t src_shard; uint64_t src_off; uint64_t dst_off; uint32_t len; };    // src_off: in the peer's buffer, or in its exchanged string
     std::vector<Remote> remote;
     uint64_t pos = 0;
     for (size_t m = 0; m < mine.size(); ++m) {
@@ -358,7 +446,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       boff[m] = pos; uint64_t q = pos;
       for (size_t k = blocks[b].first; k < blocks[b].second; ++k) {
         const uint32_t f = newfrags[k]; const size_t s = shard_of[f];
-        const uint64_t src = sh[s].foff[f - base[s]];
+        const uint64_t src = (X && s != r) ? xoff[k] : sh[s].foff[f - base[s]];
         if (s == r) { so.push_back(src); sl.push_back(flen[f]); dso.push_back(q); }
         else remote.push_back({s, src, q, flen[f]});
         q += flen[f];
@@ -378,8 +466,14 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
           (rc = zpq_h2d(c, d_dso, dso.data(), dso.size() * 8))) return rc;
       if ((rc = zpq_gather_dev(c, (const uint8_t*)sh[r].d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blk))) return rc;
     }
-    for (const Remote& R : remote)       // fragments of this block that another GPU holds: peer to peer
+    for (const Remote& R : remote) {     // fragments of this block that another GPU holds: peer to peer, or from the exchange
+      if (X) {
+        if (R.src_off + R.len > xgot[R.src_shard].size()) return ZPQ_ERR_FORMAT;
+        if (R.len && (rc = zpq_h2d(c, (uint8_t*)d_blk + R.dst_off, xgot[R.src_shard].data() + R.src_off, R.len))) return rc;
+        continue;
+      }
       if (R.len && (rc = zpq_copy_peer(c, (uint8_t*)d_blk + R.dst_off, sh[R.src_shard].ctx, (const uint8_t*)sh[R.src_shard].d_data + R.src_off, R.len))) return rc;
+    }
     std::vector<zpq_block_job> jobs(mine.size());
     std::vector<std::string> nm(mine.size());
     uint64_t opos = 0; std::vector<uint64_t> ooff(mine.size());
@@ -436,9 +530,28 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   };
   {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < nctx; ++r) th.emplace_back([&, r] { brc[r] = compress_owned(r); });
+    for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { brc[r] = compress_owned(r); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (brc[r]) return brc[r];
+  }
+  if (X) {
+    // exchange 3: the compressed d blocks; afterwards every rank assembles the same archive
+    Bytes snd; std::vector<Bytes> got;
+    for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == me) {
+      put32(snd, (uint32_t)b); put32(snd, (uint32_t)dblock[b].size()); snd.insert(snd.end(), dblock[b].begin(), dblock[b].end());
+    }
+    if ((rc = xchg_all(*X, snd, got))) return rc;
+    for (size_t r = 0; r < nctx; ++r) {
+      if (r == me) continue;
+      const Bytes& g = got[r];
+      for (size_t q = 0; q < g.size();) {
+        if (g.size() - q < 8) return ZPQ_ERR_FORMAT;
+        const uint32_t b = get32(&g[q]), n = get32(&g[q + 4]); q += 8;
+        if (b >= blocks.size() || shard_of[newfrags[blocks[b].first]] != r || g.size() - q < n) return ZPQ_ERR_FORMAT;
+        dblock[b].assign(g.begin() + q, g.begin() + q + n); q += n;
+      }
+    }
+    for (size_t b = 0; b < blocks.size(); ++b) if (dblock[b].empty()) return ZPQ_ERR_FORMAT;
   }
   Bytes dpart;                                      // the d blocks, in block order whoever compressed them
   std::vector<uint32_t> dsize(blocks.size());
@@ -682,6 +795,31 @@ int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, si
                    const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date,
                    const char* method, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
   return guarded([&] { return add_impl(ctxs, nctx, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats); });
+}
+
+// The same across PROCESSES (one GPU each; ranks of an MPI / torch.distributed job, or a C++ Jidac forked per GPU): every
+// rank passes the same names / sizes / dates / archive, but data only for the files zpqj_shard_files marks as its own;
+// `allgatherv` is the one collective needed (called three times, by every rank, in the same order).  Every rank returns
+// the same bytes -- the bytes zpqj_add returns for the whole batch on one GPU.
+int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allgatherv, void* user, const uint8_t* archive, size_t archive_len,
+                     const char* const* names, const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
+                     int64_t version_date, const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  const Xchg X{rank, world, allgatherv, user};
+  return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats, flags, &X); });
+}
+
+// mine[k] = 1 where rank `rank` of `world` must supply datas[k] to zpqj_add_sharded, else 0.
+int zpqj_shard_files(const char* const* names, const uint64_t* sizes, size_t nfiles, int world, int rank, uint8_t* mine) {
+  if (world < 1 || rank < 0 || rank >= world || (nfiles && (!names || !sizes || !mine))) return ZPQ_ERR_ARG;
+  return guarded([&] {
+    std::vector<size_t> order(nfiles), edge;
+    for (size_t i = 0; i < nfiles; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
+    shard_plan(order, sizes, (size_t)world, edge);
+    for (size_t i = 0; i < nfiles; ++i) mine[i] = 0;
+    for (size_t f = edge[rank]; f < edge[rank + 1]; ++f) mine[order[f]] = 1;
+    return (int)ZPQ_OK;
+  });
 }
 
 // Extracts the latest version of every file: decompresses the d blocks on the GPU, verifies every

@@ -25,6 +25,20 @@ int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, si
 int zpqj_add_opts(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
                   const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
                   int64_t version_date, const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]);
+/* The add across processes, one GPU each.  The caller supplies ONE collective: an all-gather of byte strings over its
+ * ranks (MPI_Allgatherv, torch.distributed.all_gather_object, RCCL all_gather on padded buffers ...).  It must fill
+ * recv[r] / recv_len[r] for every rank r (memory it owns, valid until its next call or the return of zpqj_add_sharded;
+ * recv[rank] may repeat `send`) and return 0.  zpqj_add_sharded calls it exactly three times on every rank: fragment
+ * tables (28 bytes per fragment), the fragments that a d block takes across a range edge (at most one block per edge),
+ * the compressed d blocks.  Every rank passes the same archive / names / sizes / dates / method / flags and the data of
+ * the files zpqj_shard_files marks for it (other datas[k] are not read) and gets back the same bytes: those zpqj_add
+ * returns for the whole batch on one GPU. */
+typedef int (*zpqj_allgatherv_fn)(void* user, const void* send, size_t send_len, void** recv, size_t* recv_len);
+int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allgatherv, void* user, const uint8_t* archive,
+                     size_t archive_len, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
+                     const int64_t* dates, size_t nfiles, int64_t version_date, const char* method, uint32_t flags,
+                     uint8_t** out, size_t* out_len, uint64_t stats[6]);
+int zpqj_shard_files(const char* const* names, const uint64_t* sizes, size_t nfiles, int world, int rank, uint8_t* mine);
 int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes,
                  char** names, size_t* nfiles);
 /* zpaqfranz t: decode + verify everything on the device (block SHA-1s, fragment SHA-1s against the h table, and the
