@@ -455,3 +455,19 @@ def test_jidac_rejects_hostile_archives(eng):
     for broken in (bad2, arc[: len(arc) - 7], arc[:40], arc[:200] + b"\xff" * 50 + arc[250:]):
         with pytest.raises(ZpqError):
             E.jidac_extract(eng, broken)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("staged", ["1", "0"])
+def test_sha1_extents_staged_and_direct_forms_agree_with_hashlib(staged):
+    """The fragment SHA-1 pass in both forms (wave-fetched through LDS = default for > 4096 extents, lane loads = fallback)
+    on fragment-shaped extents (exponential lengths 4 KiB..508 KiB, back to back) and on equal extents scattered over the
+    buffer; 52 digests of each (longest, shortest, first, last, random) against hashlib.  The form is chosen once per
+    process, hence the subprocess."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZPQ_SHA1_STAGED=staged)
+    for kind in ("frag", "scattered"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sha1_extents_probe.py"), kind, "1.5"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "digests ok: True" in r.stdout and ("staged=%s" % staged) in r.stdout, r.stdout

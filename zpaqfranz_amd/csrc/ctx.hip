@@ -1,6 +1,9 @@
 // Context, error reporting and device-memory helpers of the C ABI (include/zpaqhip.h).
 #include <stdarg.h>
 
+#include <atomic>
+#include <vector>
+
 #include "zpq_internal.h"
 
 int zpq_fail(zpq_ctx* ctx, int status, const char* fmt, ...) {
@@ -37,6 +40,9 @@ void* zpq_pinned(zpq_ctx* ctx, size_t bytes) {
   return p;
 }
 
+static std::atomic<int> g_live_contexts{0};
+int zpq_live_contexts() { return g_live_contexts.load(std::memory_order_relaxed); }
+
 extern "C" {
 
 int zpq_create(int device_ordinal, zpq_ctx** out) {
@@ -56,19 +62,39 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
   c->pinned = nullptr;
   c->pinned_cap = 0;
   c->profiling = false;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+  // The serial chains (block SHA-1 / SHA-256: one wave each, bound by dependent issue) run on stream2.  A chain shares
+  // its SIMD's issue slots with whatever else is resident there, and with several jobs in flight the chip-wide passes of
+  // the other jobs stretch it 2.5x (215 -> 550 ms for a 16 MiB block).  ZPQ_CHAIN_CUS=N gives the chains N compute units
+  // of their own: stream2 is created with a CU mask of the first N units, the main stream with the complement.
+  int chain_cus = 0;
+  if (const char* e = getenv("ZPQ_CHAIN_CUS")) chain_cus = atoi(e);
+  bool masked = false;
+  if (chain_cus > 0 && chain_cus < c->cu_count) {
+    const uint32_t words = (uint32_t)((c->cu_count + 31) / 32);
+    std::vector<uint32_t> m_chain(words, 0), m_main(words, 0);
+    for (int i = 0; i < c->cu_count; ++i) (i < chain_cus ? m_chain : m_main)[i / 32] |= 1u << (i % 32);
+    masked = hipExtStreamCreateWithCUMask(&c->stream, words, m_main.data()) == hipSuccess;
+    if (masked && hipExtStreamCreateWithCUMask(&c->stream2, words, m_chain.data()) != hipSuccess) {
+      (void)hipStreamDestroy(c->stream);
+      masked = false;
+    }
+    if (!masked) (void)hipGetLastError();
+  }
+  if ((!masked && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+                   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess)) ||
       hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ZPQ_ERR_HIP;
   }
+  g_live_contexts.fetch_add(1, std::memory_order_relaxed);
   *out = c;
   return ZPQ_OK;
 }
 
 void zpq_destroy(zpq_ctx* ctx) {
   if (!ctx) return;
+  g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);

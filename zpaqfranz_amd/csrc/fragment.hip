@@ -606,8 +606,10 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
              d_parked, budget);
   ZPQ_HIP(ctx, hipGetLastError());
   // parked walks: a few waves, every lane live (waves that find nothing exit at once)
+  int resume_waves_per_cu = 2;
+  if (const char* e = getenv("ZPQ_FRAG_RESUME_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) resume_waves_per_cu = v; }
   ZPQ_LAUNCH(ctx, "fragment_resume_kernel", st, fragment_spec_kernel<true>,
-             dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * 2))), dim3(64), d_base, total,
+             dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * resume_waves_per_cu))), dim3(64), d_base, total,
              d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget);
   ZPQ_HIP(ctx, hipGetLastError());
   ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,

@@ -137,6 +137,109 @@ __global__ __launch_bounds__(256) void sha1_extents_kernel(const u8* __restrict_
   }
 }
 
+// ---- the same, input staged through LDS -------------------------------------------------------------------------
+// Lane-per-extent makes every load instruction of a wave touch 64 unrelated places (64 pages, 64 cache lines, 16 bytes
+// of each): the address translation, not the data, is what the memory side is busy with (UTCL2 busy 88 % of the
+// kernel, profiles/r02_pmc_sq.json).  Here the WAVE fetches for its lanes: a load instruction reads the next 128 bytes
+// of EIGHT lanes' streams (8 lanes x 16 bytes each: whole cache lines, 8 pages per instruction instead of 64, an
+// eighth of the instructions) and parks them in LDS; a lane then takes its 64-byte blocks from its own LDS row.
+// The loop runs in trips of two blocks per lane; the rows for trip T+1 are requested at the start of trip T and
+// written to the other half of the LDS buffer between its two blocks, so a trip's worth of rounds hides the fetch.
+// Pieces that are not wholly inside their extent are not loaded at all (nothing is read outside the extents); the
+// last < 64 bytes of an extent come from memory directly, as before.  A lane that takes a new extent sits out the
+// rest of its trip (3 block slots of ~1250 per average fragment).
+constexpr u32 kRowDwords = 36;                   // 128 bytes + 16 of padding: rows 8 lanes apart share banks, neighbours do not
+constexpr u32 kHalfDwords = 64 * kRowDwords;
+
+__global__ __launch_bounds__(64) void sha1_extents_staged_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                                  const u32* __restrict__ len, u32 n, u8* __restrict__ digests,
+                                                                  u32* __restrict__ counter, const u32* __restrict__ order) {
+  __shared__ u32x4 stage_raw[2 * kHalfDwords / 4];
+  u32* const stage = (u32*)stage_raw;
+  const u32 lane = (u32)lane_id();
+  bool have = false, fresh = false, marker = false, drained = false;
+  u32 idx = 0;
+  const u8* p = base;                // next byte to hash
+  u32 total = 0, rem = 0;
+  Sha1State s = {0, 0, 0, 0, 0};
+  u32 cur = 0;                       // LDS half holding this trip's rows
+  const u32 src_sub = (lane >> 3) << 2;      // bpermute byte index of (lane >> 3); + 32 * i selects row 8 i + (lane >> 3)
+  const u32 piece = (lane & 7) * 16;
+  for (;;) {
+    // (A) lanes without work take the next extent
+    if (!have && !drained) {
+      idx = atomicAdd(counter, 1u);
+      if (idx >= n) drained = true;
+      else {
+        if (order) idx = order[idx];
+        p = base + off[idx];
+        total = rem = len[idx];
+        s = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+        marker = false;
+        have = true;
+        fresh = true;                // nothing staged for it yet: it starts consuming next trip
+      }
+    }
+    if (__ballot(have) == 0ull) return;
+    // (B) request the rows of the NEXT trip: a fresh lane's first 128 bytes, a streaming lane's bytes 128..255 from here
+    const bool ahead = have && !fresh && rem >= 128;
+    const u8* c = fresh ? p : p + 128;
+    const u32 crem = !have ? 0u : fresh ? rem : ahead ? rem - 128 : 0u;
+    const u64 coff = (u64)(c - base);        // offsets from the kernel argument keep the loads in the global address space
+    const u32 c_lo = (u32)coff, c_hi = (u32)(coff >> 32);
+    u32x4 row[8];
+    u32 a_lo[8], a_hi[8], a_rem[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {            // all 24 exchanges in flight before the first address is needed
+      const int src = (int)(src_sub + 32 * i);
+      a_lo[i] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)c_lo);
+      a_hi[i] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)c_hi);
+      a_rem[i] = (u32)__builtin_amdgcn_ds_bpermute(src, (int)crem);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      row[i] = u32x4{0, 0, 0, 0};
+      if (piece + 16 <= a_rem[i]) row[i] = *(const u32x4_u*)(base + ((((u64)a_hi[i] << 32) | a_lo[i]) + piece));
+    }
+    const u32* mine = stage + cur * kHalfDwords + lane * kRowDwords;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      if (slot == 1) {
+        // (D) the requested rows go to the other half (nobody reads it during this trip)
+        u32* dst = stage + (cur ^ 1) * kHalfDwords + (lane >> 3) * kRowDwords + (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(u32x4*)(dst + 8 * i * kRowDwords) = row[i];
+      }
+      // (C)/(E) one block per lane
+      if (have && !fresh) {
+        u32 w[16];
+        bool last = false;
+        if (rem >= 64) {
+          const u32x4* q = (const u32x4*)(mine + 16 * slot);
+          const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+          p += 64; rem -= 64;
+          w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+          w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+          w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+          w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+        } else {
+          last = tail_block(w, p, rem, marker, total);
+          p += rem; rem = 0;
+        }
+        sha1_rounds(w, s);
+        if (last) {
+          u32* o = (u32*)(digests + (size_t)idx * 20);
+          o[0] = bswap32(s.a); o[1] = bswap32(s.b); o[2] = bswap32(s.c); o[3] = bswap32(s.d); o[4] = bswap32(s.e);
+          have = false;
+        }
+      }
+    }
+    fresh = false;
+    cur ^= 1;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __constant__ u32 K256[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
     0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
@@ -467,8 +570,11 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   // Each chain wants a SIMD to itself (it is bound by dependent-issue latency; a co-resident wave of a
-  // concurrent kernel would stretch it, or be stretched by it).  Asking for most of a CU's LDS keeps
-  // other workgroups that use LDS off the CU; chains are few (one per block), so the cost is nil.
+  // concurrent kernel would stretch it, or be stretched by it).  With ONE job in the process, asking for most of a
+  // CU's LDS keeps other workgroups that use LDS off the CU (a 16 MiB block: 215 ms instead of ~240).  With several
+  // jobs in flight (several engine contexts) that is the wrong trade: 13 chains per job x 6 jobs would take 78 of the
+  // 256 CUs away from the LDS-using passes of the other jobs (fragmenter, staged SHA-1) -- measured 172 -> 144 ms
+  // per step on the headline without the reservation -- so it is only made when this is the only context.
   static bool attr_set = false;
   const unsigned hog = 163840 - 512;
   if (!attr_set) {
@@ -477,7 +583,8 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
   }
   {
     ZpqProfScope prof_scope_(ctx, "sha1_chain_kernel", s);
-    const bool reserve = n <= 64 && getenv("ZPQ_CHAIN_NO_HOG") == nullptr;
+    const char* hog_env = getenv("ZPQ_CHAIN_HOG");
+    const bool reserve = n <= 64 && (hog_env ? atoi(hog_env) != 0 : zpq_live_contexts() == 1);
     hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);
   }
   ZPQ_HIP(ctx, hipGetLastError());
@@ -496,6 +603,14 @@ int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64
   ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
   const int grid = persistent_grid(ctx, n, 2);
   const u32* order = extent_order(ctx, s, d_len, n, grid);
+  static const int staged = [] { const char* e = getenv("ZPQ_SHA1_STAGED"); return e ? atoi(e) : 1; }();
+  if (staged && n > 4096) {
+    // many extents: the wave-fetched form (one wave per workgroup, 18 KiB of LDS each)
+    ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_staged_kernel, dim3(grid * 4), dim3(64), d_base, d_off, d_len, (u32)n, d_digests, counter,
+               order);
+    ZPQ_HIP(ctx, hipGetLastError());
+    return ZPQ_OK;
+  }
   ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_kernel, dim3(grid), dim3(256), d_base, d_off, d_len, (u32)n, d_digests, counter,
              order);
   ZPQ_HIP(ctx, hipGetLastError());

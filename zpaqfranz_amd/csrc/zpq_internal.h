@@ -112,6 +112,7 @@ extern const u8 zpq_pcomp_lz1[302];
 // the level-1 post-processor programs decoded natively: rb = 0..7 raw offset bits, with / without the E8E9 inverse
 const std::vector<u8>& zpq_known_pcomp(u32 rb, bool e8);
 // inverse Burrows-Wheeler transform of a level-3 stream (ibwt.hip); synchronous
+int zpq_live_contexts();       // engine contexts alive in this process (several = several jobs in flight)
 int zpq_ibwt_dev(zpq_ctx* ctx, const u8* d_bwt, u32 m, u8* d_out, u32 out_cap, u32* out_len);
 // decode path for blocks that need host parsing (context-model coded data, arbitrary PCOMP programs): jobs[].in are
 // HOST pointers; jobs[].out are device pointers when out_dev, else host pointers (block.hip)
