@@ -635,8 +635,9 @@ def main_text_m2(a, rank, world, local, dev):
     method = b"2"                          # compressBlock: 64 MiB - 4096 byte blocks -> "x6,1,4,0,7,27,1"
     bs = (1 << 26) - 4096
     # steps in flight: a block's SHA-1 (64 MiB through one wave: 0.87 s) is as long as the whole LZ77 path of a step, and
-    # both leave most of the chip idle at times -- two steps on two engine contexts overlap them
-    depth = max(1, a.pipeline if a.pipeline is not None else 2)
+    # both leave most of the chip idle at times -- three steps on three engine contexts overlap them (measured per
+    # step: 777 ms with two, 732 with three, 739 with four)
+    depth = max(1, a.pipeline if a.pipeline is not None else 3)
     engines = [Engine(local) for _ in range(depth)]
     eng = engines[0]
     blocks = text_blocks_dev(dev, a.text_bytes, rank)
@@ -696,7 +697,7 @@ def main_text_m2(a, rank, world, local, dev):
         torch.cuda.synchronize()
         for e_ in engines:
             e_.sync()
-    steps = a.steps if a.steps is not None else 4
+    steps = a.steps if a.steps is not None else 6
     warm = a.warmup if a.warmup is not None else 1
     stagger = 0.0
     for c in range(depth):              # one untimed step per context sizes its scratch; the last one gives the stagger
@@ -1040,7 +1041,7 @@ def main():
         return main_text_m2(a, rank, world, local, dev)
     if a.workload == "cm_m5":
         return main_cm_m5(a, rank, world, local, dev)
-    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 12, "dup8_m1": 2, "extract_m1": 6}[a.workload]
+    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 24, "dup8_m1": 2, "extract_m1": 6}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
     # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6: six by default
