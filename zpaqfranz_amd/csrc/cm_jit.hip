@@ -256,6 +256,9 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   // waits it removes -- most of a bit's waiting is LDS latency on the dependent chain, not the round of loads.  Kept
   // behind ZPQ_CM_SPEC=1 for tuning.
   s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") ? "1" : "0") + "\n";
+  // ZPQ_CM_PRE_LATE=1: the second nibble's bucket is fetched when the nibble is known (one line per component and
+  // nibble) instead of both candidates one bit early (two lines): less memory traffic, one exposed round trip per byte
+  s += std::string("#define ZPRE_LATE ") + (getenv("ZPQ_CM_PRE_LATE") ? "1" : "0") + "\n";
   std::string body = kSpecSrc;
   const std::string marker = "//@@HCOMP@@";
   const size_t k = body.find(marker);
