@@ -205,6 +205,8 @@ class Pipeline:
         self.first = torch.empty(self.cap * max(1, world), dtype=i32, device=device)
         self.tstream = torch.cuda.Stream(device=device)
         self.keep_outputs = True
+        self.use_twins = True        # zpq_fragment_sha1_dev with the twin-file fold (False: the two plain calls, every byte hashed)
+        self.twin_stats = None
         torch.cuda.synchronize()
 
     def step(self, order=None, idx=0, keep=True):
@@ -219,10 +221,16 @@ class Pipeline:
         for step i+1 while the main thread is in phase_b of step i (the multi-rank pipeline)."""
         eng = self.eng
         with torch.cuda.stream(self.tstream):
-            nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
-                                  self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
-            eng.sha1_extents_dev(self.data.data_ptr(), self.frag_off.data_ptr(), self.frag_len.data_ptr(), nf,
-                                 self.digests.data_ptr())
+            if self.use_twins:
+                # one call: files equal to an earlier file are found by comparison, the rest is fragmented and hashed
+                nf = eng.fragment_sha1_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
+                                           self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.digests.data_ptr(), self.cap)
+                self.twin_stats = eng.last_twin_stats
+            else:
+                nf = eng.fragment_dev(self.data.data_ptr(), self.file_off, self.params, self.frag_off.data_ptr(),
+                                      self.frag_len.data_ptr(), self.frag_file.data_ptr(), self.cap)
+                eng.sha1_extents_dev(self.data.data_ptr(), self.frag_off.data_ptr(), self.frag_len.data_ptr(), nf,
+                                     self.digests.data_ptr())
             eng.sync()
         return nf
 
@@ -578,7 +586,11 @@ class ExtractPipeline:
             self.blake3_mismatches = sum(1 for g_, w_ in zip(got, self.blake3_want) if g_ != w_)
             return self.arc_bytes
         # SHA-256 of every restored file against the original's
-        eng.sha256_extents_dev(self.out.data_ptr(), self.d_foff.data_ptr(), self.d_flen.data_ptr(), self.nfiles, self.d_sha_got.data_ptr())
+        if getattr(self, "use_twins", True):
+            # restored files whose bytes equal an earlier restored file's (compared on the device) take its digest
+            self.twin_stats = eng.sha256_files_dev(self.out.data_ptr(), self.file_off, self.d_sha_got.data_ptr())
+        else:
+            eng.sha256_extents_dev(self.out.data_ptr(), self.d_foff.data_ptr(), self.d_flen.data_ptr(), self.nfiles, self.d_sha_got.data_ptr())
         mism, first = eng.digest_compare_dev(self.d_sha_got.data_ptr(), self.d_sha_want.data_ptr(), self.nfiles, 32)
         self.sha256_mismatches = int(mism)
         return self.arc_bytes
@@ -988,6 +1000,9 @@ def main():
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
+    ap.add_argument("--no-twins", action="store_true",
+                    help="add workloads: no twin-file fold -- every file is fragmented and hashed even when its bytes equal an earlier file's "
+                         "(the default run reports this variant beside the headline as 'every_byte_hashed')")
     a = ap.parse_args()
     run_all = a.workload in (None, "all")
     if run_all:
@@ -1009,7 +1024,8 @@ def main():
             cmd += ["--copies", str(a.copies)]
         if a.scale != 1.0:
             cmd += ["--scale", str(a.scale)]
-        for flag, on in (("--no-cpu-baseline", a.no_cpu_baseline), ("--no-verify", a.no_verify), ("--no-kernel-timing", a.no_kernel_timing)):
+        for flag, on in (("--no-cpu-baseline", a.no_cpu_baseline), ("--no-verify", a.no_verify), ("--no-kernel-timing", a.no_kernel_timing),
+                         ("--no-twins", a.no_twins)):
             if on:
                 cmd.append(flag)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -1048,7 +1064,7 @@ def main():
     # (multi-rank runs keep three: every step in flight adds three collective sections to the fixed order, and that depth
     # is the one exercised over RCCL)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 3}[a.workload])
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 4}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
@@ -1075,6 +1091,7 @@ def main():
         pipes.append(Pipeline(engines[-1], dev, layout, rank, world, a.force_collectives))
     for p_ in pipes:
         p_.no_block_sha1 = a.no_block_sha1
+        p_.use_twins = not a.no_twins
     ex_pipe = None
     if a.workload == "extract_m1":
         import hashlib
@@ -1083,6 +1100,7 @@ def main():
         pipes[0].step()                                     # the archive to extract (untimed)
         sha = [hashlib.sha256(b).digest() for _, b in corpus]
         ex_pipe = ExtractPipeline(eng, dev, pipes[0], layout, sha * a.copies)
+        ex_pipe.use_twins = not a.no_twins
         layout["data"] = None; del pipes[0].verify_blocks  # the originals are not needed any more
         for p_ in pipes:
             p_.data = None
@@ -1173,7 +1191,12 @@ def main():
             ub = sum(pipe.usize)
             # per STEP: the two SHA-256 kernels split the files between them (wave-wide for the longest, lane-wise for the rest)
             chain_bytes = sum(sorted((pipe.file_off[i + 1] - pipe.file_off[i] for i in range(pipe.nfiles)), reverse=True)[:1024])
-            alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": pipe.total - chain_bytes, "gather_kernel": pipe.total + ub,
+            tw = getattr(pipe, "twin_stats", None) if getattr(pipe, "use_twins", True) else None
+            tw = tw or dict(twins=0, twin_bytes=0, compared=0, compared_bytes=0)
+            hashed = pipe.total - tw["twin_bytes"]      # bytes SHA-256 actually sees (the representatives)
+            chain_bytes = min(chain_bytes, hashed)
+            alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": hashed - chain_bytes, "gather_kernel": pipe.total + ub,
+                   "twin_compare_kernel": tw["compared_bytes"] + (hashed if tw["compared_bytes"] else 0),
                    "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
             waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": pipe.nfiles}
             alg_step = pipe.arc_bytes + 2 * pipe.total  # r bytes read + 1 byte written per restored byte + 1 byte read back for SHA-256
@@ -1183,7 +1206,11 @@ def main():
             ub = st["unique_bytes"]
             # algorithmic bytes per launch: fragment/hash kernels read every input byte once;
             # the LZ77 and checksum kernels read every unique byte once (+ r bytes written)
-            alg = {"fragment_spec_kernel": pipe.total, "sha1_extents_kernel": pipe.total, "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
+            tw = pipe.twin_stats if (pipe.use_twins and pipe.twin_stats) else dict(twins=0, twin_bytes=0, compared=0, compared_bytes=0)
+            walked = pipe.total - tw["twin_bytes"]          # bytes the fragment loop and the fragment SHA-1 pass actually see
+            alg = {"fragment_spec_kernel": walked, "sha1_extents_kernel": walked,
+                   # member bytes streamed once + the representatives they are compared with (cache resident after the first touch)
+                   "twin_compare_kernel": tw["compared_bytes"] + (walked if tw["compared_bytes"] else 0), "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
                    "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
             waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)), "lz77_direct_kernel": st["blocks"]}
             alg_step = pipe.total + ub // max(1, world) + out_bytes // max(1, world)   # SURVEY 8(d), per rank: every input byte read once + the unique bytes into the compressor + the output
@@ -1212,9 +1239,15 @@ def main():
                 r["waves"] = int(waves[k])
                 r["note"] = "serial chain(s): %d waves of 1024 SIMDs; one instruction per ~4 cycles per wave" % waves[k]
             return r
-        # the headline roofline is the kernel that holds the most GPU time per step, whatever its shape
-        dom = max((k for k in kern if alg.get(k)), key=lambda k: kern[k][1], default=None)
+        # the headline roofline is the chip-filling kernel with the most GPU time per step -- what bounds a pipelined step; the
+        # serial chains (a few waves: block checksums, LZ77 segments) bound one job's latency and are hidden by the jobs in
+        # flight: the longest of them is reported as roofline_longest_chain (it was `roofline` up to round 3's first profile)
+        simds = 1024
+        fill = [k for k in kern if alg.get(k) and waves.get(k, simds) >= simds]
+        chains = [k for k in kern if alg.get(k) and waves.get(k, simds) < simds]
+        dom = max(fill, key=lambda k: kern[k][1], default=None)
         roof_dom = roof(dom) if dom else None
+        roof_chain = roof(max(chains, key=lambda k: kern[k][1])) if chains else None
         roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r]
         e2e = alg_step / 1e9 / sec
         res = {"metric": metric, "value": round(out_bytes / 1e6 / sec, 3),
@@ -1229,12 +1262,15 @@ def main():
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
                "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof_dom, "roofline_all": roof_all,
+               "roofline": roof_dom, "roofline_longest_chain": roof_chain, "roofline_all": roof_all,
                "roofline_end_to_end": {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 5),
                                        "algorithmic_bytes_per_step": int(alg_step),
                                        "note": "whole step: SURVEY 8(d) algorithmic bytes (input once + unique + output; extract: r + 1 + 1) / ms_per_step; the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
         if extract:
             res["sha256_mismatches"] = pipe.sha256_mismatches
+            res["twin_fold"] = dict(enabled=bool(getattr(pipe, "use_twins", True)), **tw,
+                                    note="restored files whose bytes equal an earlier restored file's (every byte compared on the device) take that "
+                                         "file's SHA-256; the representatives are hashed (zpq_sha256_files_dev)")
             if world == 1 and not a.no_verify:
                 # the same extract with BLAKE3 as the per-file check (what zpaqfranz offers beside SHA-256 / XXHASH64)
                 import orc
@@ -1266,6 +1302,27 @@ def main():
                 res["verified_all_blocks"] = True           # every d block decoded with its stored SHA-1 matching (step() raises otherwise)
             else:
                 res.update(verify_add(pipe, layout, corpus, threads))
+        if not extract:
+            res["twin_fold"] = dict(enabled=bool(pipe.use_twins), **(pipe.twin_stats or {}),
+                                    note="files whose bytes equal an earlier file's are found by comparing every byte on the device (HBM-bound) "
+                                         "before anything is hashed; only the representatives go through the fragment loop and SHA-1, twins take "
+                                         "their records: identical tables for any input (zpq_fragment_sha1_dev, csrc/twins.hip)")
+        if a.workload == "silesia_x256_m1" and pipe.use_twins and world == 1 and not a.force_collectives and not os.environ.get("ZPQ_BENCH_NO_PLAIN"):
+            # the same job with the fold off: all 54 GB through the fragment loop and SHA-1 (what every round before measured)
+            for p_ in pipes:
+                p_.use_twins = False
+            try:
+                run_steps(len(pipes))
+                barrier(); tb = time.perf_counter()
+                n2 = max(6, min(steps, 12))
+                ob2 = run_steps(n2)
+                barrier(); sec2 = (time.perf_counter() - tb) / n2
+                res["every_byte_hashed"] = {"ms_per_step": round(sec2 * 1e3, 3), "value": round(ob2 / 1e6 / sec2, 3), "unit": "MB/s", "steps": n2,
+                                            "input_GBps": round(in_bytes / 1e9 / sec2, 3),
+                                            "note": "twin fold off (--no-twins): every file fragmented and SHA-1'd; same tables, same blocks"}
+            finally:
+                for p_ in pipes:
+                    p_.use_twins = True
         if world == 1 and not a.no_cpu_baseline:
             base = b"".join(b for _, b in corpus)
             if a.workload == "silesia_x256_m1":

@@ -112,6 +112,31 @@ int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_o
                      const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len,
                      uint32_t* d_frag_file, size_t frag_cap, size_t* nfrags);
 
+/* ---- twin files: whole-file duplicates found by comparison (rows a1-a3) -------------- */
+/* Jidac::add discovers that two files hold the same data through their fragment ids (the index lookup of
+ * ZSFX/zsfx.cpp:651-659 over ids made by the fragment loop + SHA1).  Both are functions of the file's bytes alone, so a
+ * file that EQUALS an earlier one has that file's fragments and ids; comparing is HBM-bound streaming, hashing is not.
+ * file_rep[f] (HOST, nfiles entries) = earliest file with the same bytes as file f, established by comparing every
+ * byte, else f.  Only files of at least min_bytes whose length occurs more than once are looked at.
+ * stats (HOST, may be NULL): twins found, their bytes, files compared, bytes compared. */
+int zpq_file_twins_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles, uint64_t min_bytes,
+                       uint32_t* file_rep, uint64_t stats[4]);
+/* zpq_fragment_dev + zpq_sha1_extents_dev over the same files in one call (d_digests: DEVICE, 20 bytes per record,
+ * 4-byte aligned), with the twin fold in front: representatives are fragmented and hashed, twins receive their
+ * representative's records moved to their own offsets.  Output identical to the two separate calls for any input.
+ * flags: ZPQ_FS_NO_TWINS = skip the fold.  file_rep (HOST, may be NULL) and stats as above. */
+#define ZPQ_FS_NO_TWINS 1u
+int zpq_fragment_sha1_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                          const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
+                          uint8_t* d_digests, size_t frag_cap, size_t* nfrags, uint32_t flags, uint32_t* file_rep,
+                          uint64_t stats[4]);
+
+/* SHA-256 of every file [file_off[f], file_off[f+1]) (HOST offsets) into d_digests (DEVICE, 32 bytes per file, 4-byte
+ * aligned): zpq_sha256_extents_dev over whole files with the twin fold in front -- what extract's per-file check needs
+ * when a tree holds copies (ZSFX/zsfx.cpp:2018-2281).  flags / stats as for zpq_fragment_sha1_dev. */
+int zpq_sha256_files_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles, uint8_t* d_digests,
+                         uint32_t flags, uint64_t stats[4]);
+
 /* ---- file-level checksums (section 8f-2) ------------------------------------------------------ */
 /* What zpaqfranz stores per file in the i blocks and re-checks on extract / test (README.md:95-105; attribute
  * layout: SURVEY.md Appendix B.4): CRC-32 (zlib polynomial), XXH64 (seed 0) and, optionally, BLAKE3 (32 bytes).

@@ -415,13 +415,18 @@ __global__ __launch_bounds__(256) void fragment_stitch_kernel(const u8* __restri
                                                                const u32* __restrict__ spec_cnt,
                                                                const CrossOut* __restrict__ cross,
                                                                const u64* __restrict__ cut_base,
-                                                               u64* __restrict__ cuts, u32* __restrict__ cut_cnt) {
+                                                               u64* __restrict__ cuts, u32* __restrict__ cut_cnt,
+                                                               const u32* __restrict__ rep) {
   __shared__ WaveLds lds[4];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const u32 f = blockIdx.x * 4 + wave;
   lds[wave].M[lane] = 0; lds[wave].M[lane + 64] = 0; lds[wave].M[lane + 128] = 0; lds[wave].M[lane + 192] = 0;
   __builtin_amdgcn_wave_barrier();
   if (f >= nfiles) return;
+  if (rep && rep[f] != f) {          // a twin (twins.hip): its list is its representative's, shifted (fragment_emit_kernel)
+    if (lane == 0) cut_cnt[f] = 0;
+    return;
+  }
   const u64 fs = file_off[f], fe = file_off[f + 1];
   const u64 sb = seg_base[f];
   const u64 kSegBytes = P.seg;
@@ -492,21 +497,176 @@ __global__ __launch_bounds__(256) void fragment_emit_kernel(const u64* __restric
                                                              const u32* __restrict__ cut_cnt,
                                                              const u64* __restrict__ frag_base,
                                                              u64* __restrict__ frag_off, u32* __restrict__ frag_len,
-                                                             u32* __restrict__ frag_file) {
+                                                             u32* __restrict__ frag_file, const u32* __restrict__ rep) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const u32 f = blockIdx.x * 4 + wave;
   if (f >= nfiles) return;
-  const u64* c = cuts + cut_base[f];
-  const u32 n = cut_cnt[f];
+  const u32 r = rep ? rep[f] : f;            // a twin takes its representative's cuts, moved by the distance between the two
+  const u64* c = cuts + cut_base[r];
+  const u32 n = cut_cnt[r];
   const u64 fb = frag_base[f];
+  const u64 shift = file_off[f] - file_off[r];
   for (u32 j = lane; j < n; j += 64) {
-    const u64 start = j ? c[j - 1] + 1 : file_off[f];
+    const u64 start = (j ? c[j - 1] + 1 : file_off[r]) + shift;
     frag_off[fb + j] = start;
-    frag_len[fb + j] = (u32)(c[j] + 1 - start);
+    frag_len[fb + j] = (u32)(c[j] + 1 + shift - start);
     frag_file[fb + j] = f;
   }
 }
 
+// ---- twins: fragment ids of the representatives hashed once, then handed to every file --------------------------
+// compact: the (offset, length) records of the representatives' fragments back to back (the SHA-1 pass runs over these)
+__global__ __launch_bounds__(256) void twin_compact_kernel(const u32* __restrict__ ufile, u32 nu, const u64* __restrict__ frag_base,
+                                                            const u64* __restrict__ ubase, const u64* __restrict__ frag_off,
+                                                            const u32* __restrict__ frag_len, u64* __restrict__ uoff,
+                                                            u32* __restrict__ ulen) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const u32 u = blockIdx.x * 4 + wave;
+  if (u >= nu) return;
+  const u32 f = ufile[u];
+  const u64 fb = frag_base[f], n = frag_base[f + 1] - fb, ub = ubase[f];
+  for (u64 j = lane; j < n; j += 64) { uoff[ub + j] = frag_off[fb + j]; ulen[ub + j] = frag_len[fb + j]; }
+}
+// spread: every file's ids = its representative's (20 bytes = 5 words each; digest arrays are 4-byte aligned)
+__global__ __launch_bounds__(256) void twin_spread_kernel(u32 nfiles, const u32* __restrict__ rep, const u64* __restrict__ frag_base,
+                                                           const u64* __restrict__ ubase, const u32* __restrict__ udig,
+                                                           u32* __restrict__ dig) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const u32 f = blockIdx.x * 4 + wave;
+  if (f >= nfiles) return;
+  const u64 fb = frag_base[f], n = (frag_base[f + 1] - fb) * 5, ub = ubase[rep[f]];
+  const u32* src = udig + ub * 5;
+  u32* dst = dig + fb * 5;
+  for (u64 j = lane; j < n; j += 64) dst[j] = src[j];
+}
+
+}  // namespace
+
+namespace {
+// files f with rep && rep[f] != f are twins of file rep[f] (twins.hip): they are not walked, their records are their
+// representative's moved by the distance between the two.  frag_base_out (may be null): per-file record prefix, nfiles + 1.
+int fragment_run(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                 const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
+                 size_t frag_cap, size_t* nfrags, const u32* rep, std::vector<u64>* frag_base_out) {
+  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
+  if (!ctx || !file_off || !p || !nfrags) return ZPQ_ERR_ARG;
+  *nfrags = 0;
+  if (nfiles == 0) return ZPQ_OK;
+  if (nfiles > 0x7fffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many files");
+  if (((uintptr_t)d_base & 15) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "d_base must be 16-byte aligned");
+  if (p->min_fragment == 0 || p->max_fragment < p->min_fragment) return zpq_fail(ctx, ZPQ_ERR_ARG, "bad fragment limits");
+  FragP P;
+  P.minf = p->min_fragment; P.maxf = p->max_fragment;
+  P.thresh = p->fragment_log2 <= 22 ? 1u << (22 - p->fragment_log2) : 0u;
+  const u64 all_bytes = file_off[nfiles];
+  u64 total = 0;                             // bytes that are walked: twins are not
+  for (size_t f = 0; f < nfiles; ++f)
+    if (!rep || rep[f] == f) total += file_off[f + 1] - file_off[f];
+  const u64 readable = (all_bytes + 3) & ~3ull;  // callers pad allocations by >= 16 bytes (see header)
+  // every resident lane owns 256 B of LDS: 10 waves per CU fill the 160 KiB
+  int waves_per_cu = 10;
+  if (const char* e = getenv("ZPQ_FRAG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) waves_per_cu = v; }
+  u64 cap_waves = (u64)ctx->cu_count * (u64)waves_per_cu;
+  {
+    const u64 lanes = cap_waves * 64;
+    u64 seg = (total + lanes - lanes / 32 - 1) / (lanes - lanes / 32);         // ~3% slack for the ragged file ends
+    seg = (seg + kSegGrain - 1) / kSegGrain * kSegGrain;
+    seg = std::min(std::max(seg, kSegMin), kSegMax);
+    if (const char* e = getenv("ZPQ_FRAG_SEG")) { const long long v = atoll(e); if (v >= 4096) seg = (u64)v; }   // tests
+    P.seg = seg; P.pad = 0;
+  }
+  const u64 kSegBytes = P.seg;
+
+  // host-side segment and capacity tables
+  std::vector<u64> seg_base(nfiles + 1), cut_base(nfiles + 1);
+  u64 nseg = 0, ncut = 0;
+  for (size_t f = 0; f < nfiles; ++f) {
+    if (file_off[f + 1] < file_off[f]) return zpq_fail(ctx, ZPQ_ERR_ARG, "file_off not monotone");
+    if (rep && (rep[f] > f || rep[rep[f]] != rep[f])) return zpq_fail(ctx, ZPQ_ERR_ARG, "bad representative table");
+    const bool walked = !rep || rep[f] == f;
+    u64 len = walked ? file_off[f + 1] - file_off[f] : 0;
+    seg_base[f] = nseg; cut_base[f] = ncut;
+    nseg += (len + kSegBytes - 1) / kSegBytes;
+    ncut += walked ? len / P.minf + 1 : 0;
+  }
+  seg_base[nfiles] = nseg; cut_base[nfiles] = ncut;
+  if (nseg == 0) { if (frag_base_out) frag_base_out->assign(nfiles + 1, 0); return ZPQ_OK; }
+  std::vector<u32> seg_file(nseg);
+  for (size_t f = 0; f < nfiles; ++f)
+    for (u64 s = seg_base[f]; s < seg_base[f + 1]; ++s) seg_file[s] = (u32)f;
+  const u32 spec_cap = (u32)(kSegBytes / P.minf + 2);
+
+  // device scratch: [file_off | seg_base | cut_base | frag_base | seg_file | spec_cnt | cut_cnt] , spec_rel, cuts
+  const size_t nf1 = nfiles + 1;
+  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 * 2 + 64 + 256;
+  u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
+  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4 + nseg * (sizeof(CrossOut) + sizeof(Parked)) + 512);
+  u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
+  if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
+  CrossOut* d_cross = (CrossOut*)(d_spec_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
+  Parked* d_parked = (Parked*)(d_cross + nseg);
+  u64* d_file_off = (u64*)meta;
+  u64* d_seg_base = d_file_off + nf1;
+  u64* d_cut_base = d_seg_base + nf1;
+  u64* d_frag_base = d_cut_base + nf1;
+  u32* d_seg_file = (u32*)(d_frag_base + nf1);
+  u32* d_spec_cnt = d_seg_file + nseg;
+  u32* d_cut_cnt = d_spec_cnt + nseg;
+  unsigned long long* d_counter = (unsigned long long*)(((uintptr_t)(d_cut_cnt + nfiles) + 7) & ~(uintptr_t)7);
+  u32* d_rep = rep ? (u32*)(d_counter + 4) : nullptr;
+  hipStream_t st = ctx->stream;
+  ZPQ_HIP(ctx, hipMemsetAsync(d_counter, 0, 24, st));
+  if (rep) ZPQ_HIP(ctx, hipMemcpyAsync(d_rep, rep, nfiles * 4, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_file_off, file_off, nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_base, seg_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
+
+  u64 want_waves = (nseg + 63) / 64;
+  if (const char* e = getenv("ZPQ_FRAG_MAX_WAVES")) { const int v = atoi(e); if (v >= 1) cap_waves = std::min<u64>(cap_waves, (u64)v); }  // tests
+  u64 budget = 256 << 10;      // bytes a lane may walk past its segment before it parks the walk
+  if (const char* e = getenv("ZPQ_FRAG_BUDGET")) { const long long v = atoll(e); budget = v > 0 ? (u64)v : ~0ull >> 1; }
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel<false>, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64),
+             d_base, all_bytes, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter,
+             d_parked, budget);
+  ZPQ_HIP(ctx, hipGetLastError());
+  // parked walks: a few waves, every lane live (waves that find nothing exit at once)
+  int resume_waves_per_cu = 2;
+  if (const char* e = getenv("ZPQ_FRAG_RESUME_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) resume_waves_per_cu = v; }
+  ZPQ_LAUNCH(ctx, "fragment_resume_kernel", st, fragment_spec_kernel<true>,
+             dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * resume_waves_per_cu))), dim3(64), d_base, all_bytes,
+             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
+             readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_cut_base, d_cuts,
+             d_cut_cnt, (const u32*)d_rep);
+  ZPQ_HIP(ctx, hipGetLastError());
+
+  if (getenv("ZPQ_FRAG_STATS")) {
+    unsigned long long st8[8] = {0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_frag_stats), sizeof(st8));
+    fprintf(stderr, "[frag stats] nseg=%llu in_step=%llu cross_unusable=%llu lookups_missed=%llu exact_evals=%llu exact_bytes=%llu\n",
+            (unsigned long long)nseg, st8[0], st8[1], st8[2], st8[3], st8[4]);
+  }
+  // per-file counts -> exclusive prefix on the host (nfiles words; the data never leaves HBM)
+  std::vector<u32> cnt(nfiles);
+  ZPQ_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cut_cnt, nfiles * 4, hipMemcpyDeviceToHost, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  std::vector<u64> frag_base(nf1);
+  u64 nf = 0;
+  for (size_t f = 0; f < nfiles; ++f) { frag_base[f] = nf; nf += cnt[rep ? rep[f] : f]; }
+  frag_base[nfiles] = nf;
+  if (frag_base_out) *frag_base_out = frag_base;
+  *nfrags = (size_t)nf;
+  if (nf > frag_cap) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "fragment capacity %zu < %llu", frag_cap, (unsigned long long)nf);
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_frag_base, frag_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
+  ZPQ_LAUNCH(ctx, "fragment_emit_kernel", st, fragment_emit_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_file_off,
+                     (u32)nfiles, d_cut_base, d_cuts, d_cut_cnt, d_frag_base, d_frag_off, d_frag_len, d_frag_file, (const u32*)d_rep);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  return ZPQ_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -530,115 +690,70 @@ size_t zpq_fragment_capacity(const uint64_t* file_off, size_t nfiles, const zpq_
 int zpq_fragment_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
                      const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
                      size_t frag_cap, size_t* nfrags) {
-  if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
+  return fragment_run(ctx, d_base, file_off, nfiles, p, d_frag_off, d_frag_len, d_frag_file, frag_cap, nfrags, nullptr, nullptr);
+}
+
+// Fragment + SHA-1 of every fragment in one call, with the twin-file fold (twins.hip) in front: files whose bytes equal an
+// earlier file's are found by comparison, only the representatives are fragmented and hashed, and the records of the
+// twins are their representative's, moved.  The result is what zpq_fragment_dev + zpq_sha1_extents_dev give.
+int zpq_fragment_sha1_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, size_t nfiles,
+                          const zpq_fragment_params* p, uint64_t* d_frag_off, uint32_t* d_frag_len, uint32_t* d_frag_file,
+                          uint8_t* d_digests, size_t frag_cap, size_t* nfrags, uint32_t flags, uint32_t* file_rep, uint64_t stats[4]) {
+  if (ctx) (void)hipSetDevice(ctx->device);
   if (!ctx || !file_off || !p || !nfrags) return ZPQ_ERR_ARG;
   *nfrags = 0;
-  if (nfiles == 0) return ZPQ_OK;
-  if (nfiles > 0x7fffffffu) return zpq_fail(ctx, ZPQ_ERR_ARG, "too many files");
-  if (((uintptr_t)d_base & 15) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "d_base must be 16-byte aligned");
-  if (p->min_fragment == 0 || p->max_fragment < p->min_fragment) return zpq_fail(ctx, ZPQ_ERR_ARG, "bad fragment limits");
-  FragP P;
-  P.minf = p->min_fragment; P.maxf = p->max_fragment;
-  P.thresh = p->fragment_log2 <= 22 ? 1u << (22 - p->fragment_log2) : 0u;
-  const u64 total = file_off[nfiles];
-  const u64 readable = (total + 3) & ~3ull;  // callers pad allocations by >= 16 bytes (see header)
-  // every resident lane owns 256 B of LDS: 10 waves per CU fill the 160 KiB
-  int waves_per_cu = 10;
-  if (const char* e = getenv("ZPQ_FRAG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) waves_per_cu = v; }
-  u64 cap_waves = (u64)ctx->cu_count * (u64)waves_per_cu;
-  {
-    const u64 lanes = cap_waves * 64;
-    u64 seg = (total + lanes - lanes / 32 - 1) / (lanes - lanes / 32);         // ~3% slack for the ragged file ends
-    seg = (seg + kSegGrain - 1) / kSegGrain * kSegGrain;
-    seg = std::min(std::max(seg, kSegMin), kSegMax);
-    if (const char* e = getenv("ZPQ_FRAG_SEG")) { const long long v = atoll(e); if (v >= 4096) seg = (u64)v; }   // tests
-    P.seg = seg; P.pad = 0;
-  }
-  const u64 kSegBytes = P.seg;
-
-  // host-side segment and capacity tables
-  std::vector<u64> seg_base(nfiles + 1), cut_base(nfiles + 1);
-  u64 nseg = 0, ncut = 0;
-  for (size_t f = 0; f < nfiles; ++f) {
-    if (file_off[f + 1] < file_off[f]) return zpq_fail(ctx, ZPQ_ERR_ARG, "file_off not monotone");
-    u64 len = file_off[f + 1] - file_off[f];
-    seg_base[f] = nseg; cut_base[f] = ncut;
-    nseg += (len + kSegBytes - 1) / kSegBytes;
-    ncut += len / P.minf + 1;
-  }
-  seg_base[nfiles] = nseg; cut_base[nfiles] = ncut;
-  if (nseg == 0) return ZPQ_OK;
-  std::vector<u32> seg_file(nseg);
-  for (size_t f = 0; f < nfiles; ++f)
-    for (u64 s = seg_base[f]; s < seg_base[f + 1]; ++s) seg_file[s] = (u32)f;
-  const u32 spec_cap = (u32)(kSegBytes / P.minf + 2);
-
-  // device scratch: [file_off | seg_base | cut_base | frag_base | seg_file | spec_cnt | cut_cnt] , spec_rel, cuts
-  const size_t nf1 = nfiles + 1;
-  size_t meta_bytes = nf1 * 8 * 4 + nseg * 4 * 2 + nfiles * 4 + 32 + 256;
-  u8* meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
-  u32* d_spec_rel = (u32*)zpq_scratch(ctx, 3, nseg * (size_t)spec_cap * 4 + nseg * (sizeof(CrossOut) + sizeof(Parked)) + 512);
-  u64* d_cuts = (u64*)zpq_scratch(ctx, 4, ncut * 8);
-  if (!meta || !d_spec_rel || !d_cuts) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "fragment scratch");
-  CrossOut* d_cross = (CrossOut*)(d_spec_rel + nseg * (size_t)spec_cap + ((nseg * (size_t)spec_cap) & 1));
-  Parked* d_parked = (Parked*)(d_cross + nseg);
-  u64* d_file_off = (u64*)meta;
-  u64* d_seg_base = d_file_off + nf1;
-  u64* d_cut_base = d_seg_base + nf1;
-  u64* d_frag_base = d_cut_base + nf1;
-  u32* d_seg_file = (u32*)(d_frag_base + nf1);
-  u32* d_spec_cnt = d_seg_file + nseg;
-  u32* d_cut_cnt = d_spec_cnt + nseg;
-  unsigned long long* d_counter = (unsigned long long*)(((uintptr_t)(d_cut_cnt + nfiles) + 7) & ~(uintptr_t)7);
+  if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  if (((uintptr_t)d_digests & 3) != 0) return zpq_fail(ctx, ZPQ_ERR_ARG, "d_digests must be 4-byte aligned");
   hipStream_t st = ctx->stream;
-  ZPQ_HIP(ctx, hipMemsetAsync(d_counter, 0, 24, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_file_off, file_off, nf1 * 8, hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_base, seg_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_cut_base, cut_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_seg_file, seg_file.data(), nseg * 4, hipMemcpyHostToDevice, st));
-
-  u64 want_waves = (nseg + 63) / 64;
-  if (const char* e = getenv("ZPQ_FRAG_MAX_WAVES")) { const int v = atoi(e); if (v >= 1) cap_waves = std::min<u64>(cap_waves, (u64)v); }  // tests
-  u64 budget = 256 << 10;      // bytes a lane may walk past its segment before it parks the walk
-  if (const char* e = getenv("ZPQ_FRAG_BUDGET")) { const long long v = atoll(e); budget = v > 0 ? (u64)v : ~0ull >> 1; }
-  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel<false>, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64),
-             d_base, total, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter,
-             d_parked, budget);
-  ZPQ_HIP(ctx, hipGetLastError());
-  // parked walks: a few waves, every lane live (waves that find nothing exit at once)
-  int resume_waves_per_cu = 2;
-  if (const char* e = getenv("ZPQ_FRAG_RESUME_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) resume_waves_per_cu = v; }
-  ZPQ_LAUNCH(ctx, "fragment_resume_kernel", st, fragment_spec_kernel<true>,
-             dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * resume_waves_per_cu))), dim3(64), d_base, total,
-             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget);
-  ZPQ_HIP(ctx, hipGetLastError());
-  ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
-             readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_cut_base, d_cuts,
-             d_cut_cnt);
-  ZPQ_HIP(ctx, hipGetLastError());
-
-  if (getenv("ZPQ_FRAG_STATS")) {
-    unsigned long long st8[8] = {0};
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpyFromSymbol(st8, HIP_SYMBOL(g_frag_stats), sizeof(st8));
-    fprintf(stderr, "[frag stats] nseg=%llu in_step=%llu cross_unusable=%llu lookups_missed=%llu exact_evals=%llu exact_bytes=%llu\n",
-            (unsigned long long)nseg, st8[0], st8[1], st8[2], st8[3], st8[4]);
+  std::vector<u32> rep_local;
+  u32* rep = file_rep;
+  bool twins = false;
+  static const bool env_off = [] { const char* e = getenv("ZPQ_TWINS"); return e && atoi(e) == 0; }();
+  if (!(flags & ZPQ_FS_NO_TWINS) && !env_off && nfiles >= 2) {
+    if (!rep) { rep_local.resize(nfiles); rep = rep_local.data(); }
+    std::vector<u64> len(nfiles);
+    for (size_t f = 0; f < nfiles; ++f) {
+      if (file_off[f + 1] < file_off[f]) return zpq_fail(ctx, ZPQ_ERR_ARG, "file_off not monotone");
+      len[f] = file_off[f + 1] - file_off[f];
+    }
+    u64 tst[4];
+    const int rc = zpq_twins_find(ctx, st, d_base, file_off, len.data(), nfiles, p->min_fragment, rep, tst);
+    if (rc) return rc;
+    if (stats) memcpy(stats, tst, sizeof tst);
+    twins = tst[0] != 0;
+  } else if (rep) {
+    for (size_t f = 0; f < nfiles; ++f) rep[f] = (u32)f;
   }
-  // per-file counts -> exclusive prefix on the host (nfiles words; the data never leaves HBM)
-  std::vector<u32> cnt(nfiles);
-  ZPQ_HIP(ctx, hipMemcpyAsync(cnt.data(), d_cut_cnt, nfiles * 4, hipMemcpyDeviceToHost, st));
-  ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  std::vector<u64> frag_base(nf1);
-  u64 nf = 0;
-  for (size_t f = 0; f < nfiles; ++f) { frag_base[f] = nf; nf += cnt[f]; }
-  frag_base[nfiles] = nf;
-  *nfrags = (size_t)nf;
-  if (nf > frag_cap) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "fragment capacity %zu < %llu", frag_cap, (unsigned long long)nf);
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_frag_base, frag_base.data(), nf1 * 8, hipMemcpyHostToDevice, st));
-  ZPQ_LAUNCH(ctx, "fragment_emit_kernel", st, fragment_emit_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_file_off,
-                     (u32)nfiles, d_cut_base, d_cuts, d_cut_cnt, d_frag_base, d_frag_off, d_frag_len, d_frag_file);
+  std::vector<u64> frag_base;
+  int rc = fragment_run(ctx, d_base, file_off, nfiles, p, d_frag_off, d_frag_len, d_frag_file, frag_cap, nfrags, twins ? rep : nullptr,
+                        &frag_base);
+  if (rc) return rc;
+  const size_t nf = *nfrags;
+  if (nf == 0) return ZPQ_OK;
+  if (!twins) return zpq_sha1_extents_on(ctx, st, d_base, d_frag_off, d_frag_len, nf, d_digests);
+  // ids of the representatives' fragments, then every file takes its representative's
+  std::vector<u32> ufile;
+  std::vector<u64> ubase(nfiles, 0);
+  u64 nu = 0;
+  for (size_t f = 0; f < nfiles; ++f)
+    if (rep[f] == f) { ufile.push_back((u32)f); ubase[f] = nu; nu += frag_base[f + 1] - frag_base[f]; }
+  const size_t o_ubase = 0, o_fbase = o_ubase + nfiles * 8, o_uoff = o_fbase + (nfiles + 1) * 8, o_rep = o_uoff + nu * 8,
+               o_ufile = o_rep + nfiles * 4, o_ulen = o_ufile + ufile.size() * 4, o_udig = (o_ulen + nu * 4 + 63) & ~(size_t)63;
+  u8* d_t = (u8*)zpq_scratch(ctx, 29, o_udig + nu * 20 + 256);
+  if (!d_t) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "twin scratch");
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_t + o_ubase, ubase.data(), nfiles * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_t + o_fbase, frag_base.data(), (nfiles + 1) * 8, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_t + o_rep, rep, nfiles * 4, hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_t + o_ufile, ufile.data(), ufile.size() * 4, hipMemcpyHostToDevice, st));
+  ZPQ_LAUNCH(ctx, "twin_compact_kernel", st, twin_compact_kernel, dim3((unsigned)((ufile.size() + 3) / 4)), dim3(256), (const u32*)(d_t + o_ufile),
+             (u32)ufile.size(), (const u64*)(d_t + o_fbase), (const u64*)(d_t + o_ubase), (const u64*)d_frag_off, (const u32*)d_frag_len,
+             (u64*)(d_t + o_uoff), (u32*)(d_t + o_ulen));
   ZPQ_HIP(ctx, hipGetLastError());
-  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  if ((rc = zpq_sha1_extents_on(ctx, st, d_base, (const u64*)(d_t + o_uoff), (const u32*)(d_t + o_ulen), (size_t)nu, d_t + o_udig))) return rc;
+  ZPQ_LAUNCH(ctx, "twin_spread_kernel", st, twin_spread_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), (u32)nfiles, (const u32*)(d_t + o_rep),
+             (const u64*)(d_t + o_fbase), (const u64*)(d_t + o_ubase), (const u32*)(d_t + o_udig), (u32*)d_digests);
+  ZPQ_HIP(ctx, hipGetLastError());
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));      // the host tables above are locals
   return ZPQ_OK;
 }
 

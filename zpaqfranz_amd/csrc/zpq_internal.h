@@ -11,8 +11,8 @@
 
 // grow-only device scratch arenas; slot numbers are fixed per use (see the zpq_scratch callers):
 // 0-11 compress side / hashing, 12-17 the device-resident decode path (unblock.hip), 18-19 checksums, 20-22 E8E9,
-// 24 per-block arrays of the suffix-array LZ77 path
-#define ZPQ_SCRATCH_SLOTS 28
+// 24 per-block arrays of the suffix-array LZ77 path, 28-29 twin files (twins.hip, fragment.hip)
+#define ZPQ_SCRATCH_SLOTS 32
 
 struct zpq_ctx {
   int device;
@@ -152,6 +152,9 @@ struct zpq_spec_comp { u64 cm, ht; u32 type, a1, a2, a3, a4, a5, limit, cm_mask,
 struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap; u64 prof; };
 static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 80, "layout shared with the generated kernels");
 
+// twin files (twins.hip): rep[f] = earliest extent with the same bytes (compared), else f; off / len are host arrays
+int zpq_twins_find(zpq_ctx* ctx, hipStream_t st, const u8* d_base, const u64* off, const u64* len, size_t n, u64 min_bytes, u32* rep,
+                   u64 stats[4]);
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests);

@@ -87,6 +87,11 @@ def load():
     L.zpq_fragment_capacity.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FragmentParams)]
     L.zpq_fragment_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FragmentParams), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_file_twins_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.zpq_fragment_sha1_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(FragmentParams), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_void_p,
+                                        C.c_void_p]
+    L.zpq_sha256_files_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]
     L.zpq_dedup_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_gather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.zpq_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -277,6 +282,13 @@ class Engine:
     def sha256_extents_dev(self, d_base, d_off, d_len, n, d_digests):
         self._ck(self.L.zpq_sha256_extents_dev(self.ctx, d_base, d_off, d_len, n, d_digests))
 
+    def sha256_files_dev(self, d_base, file_off, d_digests, twins=True):
+        """SHA-256 of every file of one device buffer, twin files folded first (digest of the earlier equal file); -> twin stats"""
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        st = (C.c_uint64 * 4)()
+        self._ck(self.L.zpq_sha256_files_dev(self.ctx, d_base, arr, len(file_off) - 1, d_digests, 0 if twins else 1, st))
+        return dict(twins=st[0], twin_bytes=st[1], compared=st[2], compared_bytes=st[3])
+
     # ---- fragmenter -----------------------------------------------------------------------------
     def fragment_params(self, fragment=6, min_fragment=None, max_fragment=None):
         p = FragmentParams()
@@ -294,6 +306,29 @@ class Engine:
         n = C.c_size_t(0)
         self._ck(self.L.zpq_fragment_dev(self.ctx, d_base, arr, len(file_off) - 1, C.byref(params), d_frag_off, d_frag_len,
                                          d_frag_file, cap, C.byref(n)))
+        return n.value
+
+    def file_twins_dev(self, d_base, file_off, min_bytes=4096):
+        """-> (rep, stats): rep[f] = earliest file with the same bytes as file f (all bytes compared on the device), else f."""
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        nfiles = len(file_off) - 1
+        rep = (C.c_uint32 * max(1, nfiles))()
+        st = (C.c_uint64 * 4)()
+        self._ck(self.L.zpq_file_twins_dev(self.ctx, d_base, arr, nfiles, min_bytes, rep, st))
+        return list(rep[:nfiles]), dict(twins=st[0], twin_bytes=st[1], compared=st[2], compared_bytes=st[3])
+
+    def fragment_sha1_dev(self, d_base, file_off, params, d_frag_off, d_frag_len, d_frag_file, d_digests, cap, twins=True, want_rep=False):
+        """fragment_dev + sha1_extents_dev in one call, twin files folded first (include/zpaqhip.h); -> n or (n, rep, stats)."""
+        arr = (C.c_uint64 * len(file_off))(*file_off)
+        nfiles = len(file_off) - 1
+        n = C.c_size_t(0)
+        rep = (C.c_uint32 * max(1, nfiles))() if want_rep else None
+        st = (C.c_uint64 * 4)()
+        self._ck(self.L.zpq_fragment_sha1_dev(self.ctx, d_base, arr, nfiles, C.byref(params), d_frag_off, d_frag_len, d_frag_file,
+                                              d_digests, cap, C.byref(n), 0 if twins else 1, rep, st))
+        self.last_twin_stats = dict(twins=st[0], twin_bytes=st[1], compared=st[2], compared_bytes=st[3])
+        if want_rep:
+            return n.value, list(rep[:nfiles]), self.last_twin_stats
         return n.value
 
     def fragment_files(self, files, params=None):

@@ -249,9 +249,10 @@ int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes,
   if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_ffile))) return rc; S.dev.push_back(d_ffile);
   if ((rc = zpq_dev_alloc(ctx, cap * 20 + 64, &d_dig))) return rc; S.dev.push_back(d_dig);
   size_t nf = 0;
-  if (nfiles && (rc = zpq_fragment_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
-                                       (uint32_t*)d_ffile, cap, &nf))) return rc;
-  if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)S.d_data, (const uint64_t*)d_foff, (const uint32_t*)d_flen, nf, (uint8_t*)d_dig))) return rc;
+  // fragment loop + SHA-1 of every fragment; files whose bytes equal an earlier file of this range (compared on the device,
+  // csrc/twins.hip) are not walked again: their records are the earlier file's, moved
+  if (nfiles && (rc = zpq_fragment_sha1_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
+                                            (uint32_t*)d_ffile, (uint8_t*)d_dig, cap, &nf, 0, nullptr, nullptr))) return rc;
   if (checksums && nfiles) {       // zpaqfranz stores XXHASH64 + CRC-32 of every file in its i-block attribute: same pass over HBM
     S.crc.resize(nfiles); S.xxh.resize(nfiles);
     if ((rc = zpq_file_checksums_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, S.crc.data(), S.xxh.data(), nullptr))) return rc;
