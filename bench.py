@@ -1307,7 +1307,7 @@ def main():
                                     note="files whose bytes equal an earlier file's are found by comparing every byte on the device (HBM-bound) "
                                          "before anything is hashed; only the representatives go through the fragment loop and SHA-1, twins take "
                                          "their records: identical tables for any input (zpq_fragment_sha1_dev, csrc/twins.hip)")
-        if a.workload == "silesia_x256_m1" and pipe.use_twins and world == 1 and not a.force_collectives and not os.environ.get("ZPQ_BENCH_NO_PLAIN"):
+        if a.workload == "silesia_x256_m1" and pipe.use_twins and world == 1 and not a.force_collectives and not a.dump_archive and not os.environ.get("ZPQ_BENCH_NO_PLAIN"):
             # the same job with the fold off: all 54 GB through the fragment loop and SHA-1 (what every round before measured)
             for p_ in pipes:
                 p_.use_twins = False

@@ -1,0 +1,23 @@
+# Round 3: where the pipelined headline step goes once the twin fold has removed the hashing passes -- depth trend,
+# repeatability, chain isolation (CU masks), fragmenter segment size on a small unique set, hardware queues.
+R=$GRAFT_REPO_ROOT
+T=${1:-r03d}
+mkdir -p $R/gpurun_out
+cd $R
+export PYTHONUNBUFFERED=1
+S0=$(date +%s)
+el() { echo "[$(( $(date +%s) - S0 )) s] $*"; }
+timeout 200 python -m pytest tests/test_gpu_parity.py -k "two_rank" -x -q -p no:cacheprovider > gpurun_out/${T}_tests.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/${T}_tests.log; tail -2 gpurun_out/${T}_tests.log; el tests
+export ZPQ_BENCH_NO_PLAIN=1
+B="python bench.py --workload silesia_x256_m1 --no-cpu-baseline --no-verify --steps 24"
+sw() { # label, env, args
+  local out; out=$(env $2 timeout 150 $B $3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print(d['value'], d['ms_per_step'], d.get('ms_per_step_serial'), d.get('steps_in_flight'), 'chain', k.get('sha1_chain_kernel'), 'spec', k.get('lz77_spec_kernel'), 'resume', k.get('fragment_resume_kernel'), 'stitch', k.get('fragment_stitch_kernel'))" 2>&1 | tail -1)
+  echo "$1 | $2 | $3 | $out" | tee -a gpurun_out/${T}_sweep.txt; }
+: > gpurun_out/${T}_sweep.txt
+while IFS='|' read -r label envs args; do
+  [ -z "$label" ] && continue
+  sw "$label" "$envs" "$args"
+  el "$label"
+done < tools/sweep_r3d.txt
+el done
