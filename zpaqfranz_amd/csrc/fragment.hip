@@ -31,7 +31,7 @@ namespace {
 // The speculation segment (independent of the fragment size limits) is chosen per call so that the
 // resident lanes get one segment each: a lane walks ~10-40 MB/s, so a second, partly filled round of
 // segments would cost as much again as the first.
-constexpr u64 kSegMin = 1ull << 16, kSegMax = 1ull << 20, kSegGrain = 1ull << 14;
+constexpr u64 kSegMin = 1ull << 18, kSegMax = 1ull << 20, kSegGrain = 1ull << 14;   // (64 KiB segments: 19 ms of per-file stitching on a 212 MB call, 4 ms with 256 KiB)
 constexpr u64 kNone = ~0ull;
 
 struct FragP {
@@ -755,7 +755,17 @@ int zpq_fragment_sha1_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* f
              (u32)ufile.size(), (const u64*)(d_t + o_fbase), (const u64*)(d_t + o_ubase), (const u64*)d_frag_off, (const u32*)d_frag_len,
              (u64*)(d_t + o_uoff), (u32*)(d_t + o_ulen));
   ZPQ_HIP(ctx, hipGetLastError());
-  if ((rc = zpq_sha1_extents_on(ctx, st, d_base, (const u64*)(d_t + o_uoff), (const u32*)(d_t + o_ulen), (size_t)nu, d_t + o_udig))) return rc;
+  // Few fragments (what is left of a tree of copies): one WAVE per fragment -- a lane hashes ~25 MB/s, so lane-wise the
+  // pass lasts as long as its longest fragment (20 ms for 508 KiB) however few there are; wave-wise (schedule off the
+  // chain, 78 MB/s) it is 6.5 ms, at 39x the issue slots per byte: worth it below ~0.5 GB.
+  u64 ubytes = 0;
+  for (u32 f : ufile) ubytes += file_off[f + 1] - file_off[f];
+  static const int wave_ids = [] { const char* e = getenv("ZPQ_TWIN_WAVE_IDS"); return e ? atoi(e) : 1; }();
+  if (wave_ids && nu <= 65535 && ubytes <= (512ull << 20))
+    rc = zpq_sha1_chains_on(ctx, st, d_base, (const u64*)(d_t + o_uoff), (const u32*)(d_t + o_ulen), (size_t)nu, d_t + o_udig, "sha1_fragment_waves_kernel");
+  else
+    rc = zpq_sha1_extents_on(ctx, st, d_base, (const u64*)(d_t + o_uoff), (const u32*)(d_t + o_ulen), (size_t)nu, d_t + o_udig);
+  if (rc) return rc;
   ZPQ_LAUNCH(ctx, "twin_spread_kernel", st, twin_spread_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), (u32)nfiles, (const u32*)(d_t + o_rep),
              (const u64*)(d_t + o_fbase), (const u64*)(d_t + o_ubase), (const u32*)(d_t + o_udig), (u32*)d_digests);
   ZPQ_HIP(ctx, hipGetLastError());

@@ -566,7 +566,7 @@ const u32* extent_order(zpq_ctx* ctx, hipStream_t s, const L* d_len, size_t n, i
 }  // namespace
 
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
-                       u8* d_digests) {
+                       u8* d_digests, const char* prof_name) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (n == 0) return ZPQ_OK;
   // Each chain wants a SIMD to itself (it is bound by dependent-issue latency; a co-resident wave of a
@@ -582,7 +582,7 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
     attr_set = true;
   }
   {
-    ZpqProfScope prof_scope_(ctx, "sha1_chain_kernel", s);
+    ZpqProfScope prof_scope_(ctx, prof_name, s);
     const char* hog_env = getenv("ZPQ_CHAIN_HOG");
     const bool reserve = n <= 64 && (hog_env ? atoi(hog_env) != 0 : zpq_live_contexts() == 1);
     hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);

@@ -157,6 +157,6 @@ int zpq_twins_find(zpq_ctx* ctx, hipStream_t st, const u8* d_base, const u64* of
                    u64 stats[4]);
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
-                       u8* d_digests);
+                       u8* d_digests, const char* prof_name = "sha1_chain_kernel");
 int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off,
                         const u32* d_len, size_t n, u8* d_digests, const char* prof_name = "sha1_extents_kernel");
