@@ -1,6 +1,7 @@
 // Context, error reporting and device-memory helpers of the C ABI (include/zpaqhip.h).
 #include <stdarg.h>
 
+#include <algorithm>
 #include <atomic>
 #include <vector>
 
@@ -40,7 +41,48 @@ void* zpq_pinned(zpq_ctx* ctx, size_t bytes) {
   return p;
 }
 
+// ---- cooperative wave placement (zpq_internal.h) -----------------------------------------------------------------
+#include <mutex>
+u32* zpq_simd_table(zpq_ctx* ctx) {
+  static std::mutex mu;
+  static u32* tab[64] = {nullptr};
+  std::lock_guard<std::mutex> g(mu);
+  const int d = ctx->device & 63;
+  if (!tab[d]) {
+    (void)hipSetDevice(ctx->device);
+    void* p = nullptr;
+    if (hipMalloc(&p, 65536 * 4) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 65536 * 4) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    tab[d] = (u32*)p;
+  }
+  return tab[d];
+}
 static std::atomic<int> g_live_contexts{0};
+bool zpq_place_enabled() {
+  static const int mode = [] { const char* e = getenv("ZPQ_PLACE"); return e ? atoi(e) : 0; }();   // 0 off, 1 with several contexts, 2 always
+  return mode == 2 || (mode == 1 && g_live_contexts.load(std::memory_order_relaxed) > 1);
+}
+
+// ZPQ_PLACE_DEBUG: how many distinct SIMD keys a chip-wide launch sees (1024 expected on MI355X)
+__global__ __launch_bounds__(64) void place_probe_kernel(u32* __restrict__ out) {
+  if ((threadIdx.x & 63u) == 0) out[blockIdx.x] = zpq_simd_key();
+  for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(10);
+}
+static void place_probe(zpq_ctx* c) {
+  const u32 n = 8192;
+  u32* d = nullptr;
+  if (hipMalloc((void**)&d, n * 4) != hipSuccess) return;
+  hipLaunchKernelGGL(place_probe_kernel, dim3(n), dim3(64), 0, c->stream, d);
+  std::vector<u32> h(n);
+  (void)hipMemcpyAsync(h.data(), d, n * 4, hipMemcpyDeviceToHost, c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  std::vector<u32> u(h); std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+  u32 xcc = 0; for (u32 k : u) xcc |= 1u << (k >> 12);
+  fprintf(stderr, "[zpaqhip] placement probe: %u workgroups landed on %zu distinct SIMD keys, XCC mask %#x, first keys %#x %#x %#x %#x\n", n, u.size(), xcc,
+          h[0], h[1], h[8], h[9]);
+}
+
 int zpq_live_contexts() { return g_live_contexts.load(std::memory_order_relaxed); }
 
 extern "C" {
@@ -119,6 +161,7 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
     return ZPQ_ERR_HIP;
   }
   if (!c->stream3) c->stream3 = c->stream;
+  if (getenv("ZPQ_PLACE_DEBUG")) place_probe(c);
   g_live_contexts.fetch_add(1, std::memory_order_relaxed);
   *out = c;
   return ZPQ_OK;

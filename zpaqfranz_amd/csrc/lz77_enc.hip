@@ -530,21 +530,29 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
 
 // ---- speculative parse: one wave per segment ------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
+__global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list, const zpq_place P) {
   // The block-checksum chains (sha1_chain_kernel, other stream) are pure VALU and may land on the same
   // SIMD: this latency-bound parse must win issue arbitration or its slowest wave doubles the launch.
   __builtin_amdgcn_s_setprio(3);
-  const LzSegDev S = segs[list[blockIdx.x]];
   __shared__ unsigned long long T[256];
   const u32 lane = (u32)lane_id();
-  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
-  __builtin_amdgcn_wave_barrier();
-  TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
-  u32 cur = S.x0, lit = 0;
-  lz_walk<NB>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
-  if (lane == 0) {
-    S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
-    S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
+  // plain launch: segment list[blockIdx.x]; with placement (zpq_internal.h): surplus workgroups over a queue of segments,
+  // a wave parses where it has a SIMD to itself
+  u32 key; bool polite;
+  u32 item = zpq_place_begin(P, key, polite);
+  while (item != 0xffffffffu) {
+    const LzSegDev S = segs[list[item]];
+    T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
+    __builtin_amdgcn_wave_barrier();
+    TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
+    u32 cur = S.x0, lit = 0;
+    lz_walk<NB>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
+    if (lane == 0) {
+      S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
+      S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
+    }
+    __builtin_amdgcn_wave_barrier();
+    item = zpq_place_next(P, key, polite);
   }
 }
 
@@ -1029,20 +1037,31 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     // the segment parse (one wave per segment, ~150 ms) goes to this context's own compute units when the chip is sliced
     // (ctx.hip, ZPQ_CU_SLICES) and there are not more segments than two waves per SIMD of the slice
     hipStream_t sp = (ctx->slice_simds && rng[nb].sn <= (size_t)ctx->slice_simds * 2) ? ctx->stream3 : st;
+    zpq_place PL{nullptr, nullptr, (u32)rng[nb].sn, 0};
+    if (rng[nb].sn <= 4096 && zpq_place_enabled()) {
+      u32* tab = zpq_simd_table(ctx);
+      u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
+      if (tab && counter) {
+        counter += 44 + nb;
+        ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, sp));
+        PL.queue = counter; PL.tab = tab; PL.polite = (u32)(2 * rng[nb].sn + 64);
+        gs = dim3((unsigned)(3 * rng[nb].sn + 64));
+      }
+    }
     if (sp != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3a, st)); ZPQ_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev3a, 0)); }
 #define ZPQ_SPEC_DONE if (sp != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3b, sp)); ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev3b, 0)); }
     switch (nb) {
-      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<1>, gs, blk, d_segs, sl); ZPQ_SPEC_DONE
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, gs, blk, d_segs, sl);
+      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<2>, gs, blk, d_segs, sl); ZPQ_SPEC_DONE
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, gs, blk, d_segs, sl);
+      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<4>, gs, blk, d_segs, sl); ZPQ_SPEC_DONE
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, gs, blk, d_segs, sl);
+      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<8>, gs, blk, d_segs, sl); ZPQ_SPEC_DONE
-               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, gs, blk, d_segs, sl);
+      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
     }
 #undef ZPQ_SPEC_DONE

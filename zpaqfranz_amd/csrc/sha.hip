@@ -348,9 +348,8 @@ __device__ __forceinline__ void sha1_rounds_lane(const u32 (&w)[80], int blk, Sh
   s.e += __builtin_amdgcn_readlane(e, blk);
 }
 
-__global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
-                                                        const u32* __restrict__ len, u8* __restrict__ digests) {
-  const u32 idx = blockIdx.x;
+__device__ __forceinline__ void sha1_chain_one(const u8* __restrict__ base, const u64* __restrict__ off,
+                                               const u32* __restrict__ len, u8* __restrict__ digests, const u32 idx) {
   const int lane = lane_id();
   const u8* p = base + off[idx];
   const u64 total = len[idx];
@@ -390,6 +389,23 @@ __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ b
   if (lane == 0) {
     u32* o = (u32*)(digests + (size_t)idx * 20);
     o[0] = bswap32(s.a); o[1] = bswap32(s.b); o[2] = bswap32(s.c); o[3] = bswap32(s.d); o[4] = bswap32(s.e);
+  }
+}
+
+__global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                        const u32* __restrict__ len, u8* __restrict__ digests) {
+  sha1_chain_one(base, off, len, digests, blockIdx.x);
+}
+
+// The same over a queue of extents with surplus workgroups: a wave keeps a SIMD to itself where it can (zpq_internal.h,
+// cooperative wave placement)
+__global__ __launch_bounds__(64) void sha1_chain_placed_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                               const u32* __restrict__ len, u8* __restrict__ digests, const zpq_place P) {
+  u32 key; bool polite;
+  u32 item = zpq_place_begin(P, key, polite);
+  while (item != 0xffffffffu) {
+    sha1_chain_one(base, off, len, digests, item);
+    item = zpq_place_next(P, key, polite);
   }
 }
 
@@ -585,7 +601,17 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
     ZpqProfScope prof_scope_(ctx, prof_name, s);
     const char* hog_env = getenv("ZPQ_CHAIN_HOG");
     const bool reserve = n <= 64 && (hog_env ? atoi(hog_env) != 0 : zpq_live_contexts() == 1);
-    hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);
+    u32* tab = (n <= 1024 && zpq_place_enabled()) ? zpq_simd_table(ctx) : nullptr;
+    u32* counter = tab ? (u32*)zpq_scratch(ctx, 7, 256) : nullptr;
+    if (tab && counter) {
+      // few long chains beside other jobs: surplus workgroups, one chain per free SIMD (the last n drain what is left)
+      counter += s == ctx->stream2 ? 41 : 40;
+      ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, s));
+      const zpq_place P{counter, tab, (u32)n, (u32)(4 * n + 64)};
+      hipLaunchKernelGGL(sha1_chain_placed_kernel, dim3((unsigned)(5 * n + 64)), dim3(64), 0, s, d_base, d_off, d_len, d_digests, P);
+    } else {
+      hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);
+    }
   }
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;

@@ -85,6 +85,50 @@ static __device__ __forceinline__ u32 rotl32(u32 x, int k) { return __builtin_ro
 static __device__ __forceinline__ u32 rotr32(u32 x, int k) { return __builtin_rotateright32(x, k); }
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// ---- cooperative wave placement ("one hungry wave per SIMD") ------------------------------------------------------
+// With several jobs in flight the long few-wave kernels (13 checksum chains, 212 LZ77 segment waves per job) land on
+// SIMDs at the dispatcher's whim: ~550 such waves on 1024 SIMDs, yet a kernel lasts as long as its unluckiest wave --
+// the one that shares its SIMD's issue slots with two others (measured: chains 215 -> 313 ms, segment parse 148 -> 250 ms
+// with six jobs).  So these kernels are launched with SURPLUS single-wave workgroups over a queue of work items; a wave
+// reads where it has landed (HW_ID / XCC_ID), registers in a process-wide table of SIMD loads, and a "polite" wave that
+// finds its SIMD taken gives the slot back and exits -- the dispatcher tries another SIMD with the next workgroup.  The
+// last n workgroups are not polite: they drain whatever is left, so every item is processed whatever the placement.
+struct zpq_place { u32* queue; u32* tab; u32 n; u32 polite; };     // tab == nullptr: plain launch, item = blockIdx.x
+u32* zpq_simd_table(zpq_ctx* ctx);                                  // 65536 zeroed counters per device, shared by every context of the process
+bool zpq_place_enabled();                                           // several contexts alive and ZPQ_PLACE != 0
+static __device__ __forceinline__ u32 zpq_simd_key() {
+  const u32 hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_ID: simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]
+  const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // XCC_ID [3:0]
+  return ((xcc & 15u) << 12) | ((hw >> 4) & 0xFFFu);
+}
+// wave-uniform; every lane executes the atomics (adding 0 except lane 0): nothing lane-dependent next to a loop edge
+static __device__ __forceinline__ u32 zpq_wave_add(u32* p, u32 v) {
+  const u32 r = atomicAdd(p, (threadIdx.x & 63u) == 0 ? v : 0u);
+  return (u32)__builtin_amdgcn_readfirstlane((int)r);
+}
+// -> first item of this workgroup (0xffffffff: exit now); key/held are the caller's to pass to zpq_place_next / _end
+static __device__ __forceinline__ u32 zpq_place_begin(const zpq_place& P, u32& key, bool& polite) {
+  key = 0; polite = true;
+  if (!P.tab) return blockIdx.x < P.n ? blockIdx.x : 0xffffffffu;
+  key = zpq_simd_key();
+  polite = blockIdx.x < P.polite;
+  const u32 prev = zpq_wave_add(P.tab + key, 1u);
+  if (polite && prev != 0) { (void)zpq_wave_add(P.tab + key, 0xffffffffu); return 0xffffffffu; }
+  const u32 item = zpq_wave_add(P.queue, 1u);
+  if (item >= P.n) { (void)zpq_wave_add(P.tab + key, 0xffffffffu); return 0xffffffffu; }
+  return item;
+}
+// -> next item for a wave that must drain the queue (0xffffffff: done; the table entry has been given back)
+static __device__ __forceinline__ u32 zpq_place_next(const zpq_place& P, u32 key, bool polite) {
+  if (!P.tab) return 0xffffffffu;
+  if (!polite) {
+    const u32 item = zpq_wave_add(P.queue, 1u);
+    if (item < P.n) return item;
+  }
+  (void)zpq_wave_add(P.tab + key, 0xffffffffu);
+  return 0xffffffffu;
+}
+
 // device-side job record of the LZ77 level-1 decoder (lz77_dec.hip); result[0] = out_len, result[1] = status
 struct zpq_lzdec_dev {
   const u8* in; u32 n; u32 rb;
