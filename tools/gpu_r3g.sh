@@ -6,8 +6,8 @@ cd $R
 export PYTHONUNBUFFERED=1
 S0=$(date +%s)
 el() { echo "[$(( $(date +%s) - S0 )) s] $*"; }
-ZPQ_PLACE=2 timeout 200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -k "lz77 or compress_block or journaling" -x -q -p no:cacheprovider > gpurun_out/${T}_tests.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/${T}_tests.log; tail -2 gpurun_out/${T}_tests.log; el tests
+: # (parity with ZPQ_PLACE=2: r03g first run, 43 passed)
+:
 export ZPQ_BENCH_NO_PLAIN=1
 B="python bench.py --workload silesia_x256_m1 --no-cpu-baseline --steps 24"
 sw() { # label, env, args
