@@ -1213,6 +1213,12 @@ def main():
                    "twin_compare_kernel": tw["compared_bytes"] + (walked if tw["compared_bytes"] else 0), "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
                    "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
             waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)), "lz77_direct_kernel": st["blocks"]}
+            if tw["twin_bytes"]:
+                # what is left after the fold is walked by a handful of waves (one lane per 256 KiB segment / per fragment)
+                seg_b = max(256 << 10, walked // 158720)
+                nfw = max(1, int(st["fragments"] * walked // max(1, pipe.total)))
+                waves.update({"fragment_spec_kernel": -(-walked // seg_b // 64) or 1, "fragment_resume_kernel": -(-walked // seg_b // 64) or 1,
+                              "sha1_extents_kernel": -(-nfw // 64)})
             alg_step = pipe.total + ub // max(1, world) + out_bytes // max(1, world)   # SURVEY 8(d), per rank: every input byte read once + the unique bytes into the compressor + the output
             metric = ("MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x%d" % a.copies) if a.workload == "silesia_x256_m1" else \
                      ("MB/s compressed output (bit-identical .zpaq) at -m1, %d unique 16 MiB units x%d duplication per GPU" % (a.units, a.dup))

@@ -122,45 +122,13 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
     }
     if (!masked) (void)hipGetLastError();
   }
-  // ZPQ_CU_SLICES=N: several jobs in flight (one context each) otherwise place their few-wave, long-running kernels -- 13
-  // checksum chains, 212 LZ77 segment waves, the fragmenter's lane walks -- on the same compute units, where they share
-  // SIMD issue slots (measured with six jobs: chains 215 -> 300 ms, segment parse 148 -> 222 ms, while three quarters of
-  // the chip idles).  With N slices, context k owns the units {i : i mod N == k mod N}: its chains run on the first
-  // ZPQ_SLICE_CHAIN_CUS of them (stream2), its other long kernels on the rest (stream3); the chip-filling kernels stay on
-  // the unmasked main stream.
-  c->stream3 = nullptr; c->slice_simds = 0;
-  int slices = 0, slice_chain = 4;
-  if (const char* e = getenv("ZPQ_CU_SLICES")) slices = atoi(e);
-  if (const char* e = getenv("ZPQ_SLICE_CHAIN_CUS")) slice_chain = atoi(e);
-  if (!masked && slices >= 2 && slices <= c->cu_count / 8 && slice_chain >= 1) {
-    static std::atomic<int> next_slice{0};
-    const int me = next_slice.fetch_add(1) % slices;
-    const uint32_t words = (uint32_t)((c->cu_count + 31) / 32);
-    std::vector<uint32_t> m_chain(words, 0), m_rest(words, 0);
-    int k = 0, nrest = 0;
-    for (int i = me; i < c->cu_count; i += slices, ++k) {
-      if (k < slice_chain) m_chain[i / 32] |= 1u << (i % 32);
-      else { m_rest[i / 32] |= 1u << (i % 32); ++nrest; }
-    }
-    bool ok = nrest > 0 && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    if (ok && hipExtStreamCreateWithCUMask(&c->stream2, words, m_chain.data()) != hipSuccess) { (void)hipStreamDestroy(c->stream); ok = false; }
-    if (ok && hipExtStreamCreateWithCUMask(&c->stream3, words, m_rest.data()) != hipSuccess) {
-      (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream2); c->stream3 = nullptr; ok = false;
-    }
-    if (ok) { masked = true; c->slice_simds = nrest * 4; }
-    else { (void)hipGetLastError(); fprintf(stderr, "[zpaqhip] ZPQ_CU_SLICES: masked streams unavailable, running unsliced\n"); }
-    if (getenv("ZPQ_CU_SLICES_VERBOSE")) fprintf(stderr, "[zpaqhip] context slice %d of %d: %d chain units, %d other units, masked=%d\n", me, slices, slice_chain, nrest, (int)ok);
-  }
   if ((!masked && (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
                    hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess)) ||
       hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev3a, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev3b, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev2, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return ZPQ_ERR_HIP;
   }
-  if (!c->stream3) c->stream3 = c->stream;
   if (getenv("ZPQ_PLACE_DEBUG")) place_probe(c);
   g_live_contexts.fetch_add(1, std::memory_order_relaxed);
   *out = c;
@@ -173,9 +141,6 @@ void zpq_destroy(zpq_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
-  if (ctx->stream3 != ctx->stream) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
-  (void)hipEventDestroy(ctx->ev3a);
-  (void)hipEventDestroy(ctx->ev3b);
   for (int i = 0; i < ZPQ_SCRATCH_SLOTS; ++i)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

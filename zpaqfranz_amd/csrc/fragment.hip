@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
                                                             u32 spec_cap, u32* __restrict__ spec_rel,
                                                             u32* __restrict__ spec_cnt, CrossOut* __restrict__ cross,
                                                             unsigned long long* __restrict__ counters, Parked* __restrict__ parked,
-                                                            u64 budget, u64 cross_cap) {
+                                                            u64 budget) {
   __shared__ u8 tab[16384];
   const u32 lane = (u32)lane_id();
   LaneO1 o{(lds_u8*)tab, (lane >> 5) * 128u + (lane & 31u) * 4u};
@@ -352,8 +352,7 @@ __global__ __launch_bounds__(64) void fragment_spec_kernel(const u8* __restrict_
         fe = file_off[f + 1];                                                                                 \
         g = fs + (s - seg_base[f]) * P.seg;                                                                   \
         segend = g + P.seg < fe ? g + P.seg : fe;                                                             \
-        u64 far = segend + (u64)P.minf + (u64)kCrossMax * P.maxf + 64; /* kCrossMax crossing fragments */    \
-        if (segend + cross_cap < far) far = segend + cross_cap; /* give up earlier: the stitch evaluates exactly */ \
+        const u64 far = segend + (u64)P.minf + (u64)kCrossMax * P.maxf + 64; /* kCrossMax crossing fragments */ \
         lim = far < fe ? far : fe;                                                                            \
         if (!RESUME) { pos = g; cnt = 0; nx = 0; x0 = x1 = x2 = x3 = 0; }                                     \
         out = spec_rel + s * (u64)spec_cap;                                                                   \
@@ -627,27 +626,17 @@ int fragment_run(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, 
   if (const char* e = getenv("ZPQ_FRAG_MAX_WAVES")) { const int v = atoi(e); if (v >= 1) cap_waves = std::min<u64>(cap_waves, (u64)v); }  // tests
   u64 budget = 256 << 10;      // bytes a lane may walk past its segment before it parks the walk
   if (const char* e = getenv("ZPQ_FRAG_BUDGET")) { const long long v = atoll(e); budget = v > 0 ? (u64)v : ~0ull >> 1; }
-  // ZPQ_FRAG_CROSS_CAP: a crossing walk that has not met a usable cut this many bytes behind its segment is dropped and the
-  // per-file stitch evaluates that stretch exactly, wave-wide (~6x a lane's speed): shortens the longest chain of the
-  // resume launch (data on which the hash rarely fires) at the price of wave work in the stitch.  Off by default.
-  u64 cross_cap = ~0ull >> 2;
-  if (const char* e = getenv("ZPQ_FRAG_CROSS_CAP")) { const long long v = atoll(e); if (v >= (long long)P.minf) cross_cap = (u64)v; }
-  // a small call (a folded tree: a dozen waves walking for tens of milliseconds) runs on this context's own compute units
-  // when the chip is sliced between the jobs in flight (ctx.hip, ZPQ_CU_SLICES)
-  hipStream_t sw = (ctx->slice_simds && want_waves <= (u64)ctx->slice_simds * 2) ? ctx->stream3 : st;
-  if (sw != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3a, st)); ZPQ_HIP(ctx, hipStreamWaitEvent(sw, ctx->ev3a, 0)); }
-  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", sw, fragment_spec_kernel<false>, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64),
+  ZPQ_LAUNCH(ctx, "fragment_spec_kernel", st, fragment_spec_kernel<false>, dim3((unsigned)std::min(want_waves, cap_waves)), dim3(64),
              d_base, all_bytes, d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter,
-             d_parked, budget, cross_cap);
+             d_parked, budget);
   ZPQ_HIP(ctx, hipGetLastError());
   // parked walks: a few waves, every lane live (waves that find nothing exit at once)
   int resume_waves_per_cu = 2;
   if (const char* e = getenv("ZPQ_FRAG_RESUME_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) resume_waves_per_cu = v; }
-  ZPQ_LAUNCH(ctx, "fragment_resume_kernel", sw, fragment_spec_kernel<true>,
+  ZPQ_LAUNCH(ctx, "fragment_resume_kernel", st, fragment_spec_kernel<true>,
              dim3((unsigned)std::min<u64>(want_waves, std::min<u64>(cap_waves, (u64)ctx->cu_count * resume_waves_per_cu))), dim3(64), d_base, all_bytes,
-             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget, cross_cap);
+             d_file_off, d_seg_file, d_seg_base, nseg, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_counter, d_parked, budget);
   ZPQ_HIP(ctx, hipGetLastError());
-  if (sw != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3b, sw)); ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev3b, 0)); }
   ZPQ_LAUNCH(ctx, "fragment_stitch_kernel", st, fragment_stitch_kernel, dim3((unsigned)((nfiles + 3) / 4)), dim3(256), d_base,
              readable, d_file_off, (u32)nfiles, d_seg_base, P, spec_cap, d_spec_rel, d_spec_cnt, d_cross, d_cut_base, d_cuts,
              d_cut_cnt, (const u32*)d_rep);

@@ -1034,37 +1034,31 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     if (!rng[nb].sn) continue;
     dim3 gs((unsigned)rng[nb].sn), gj((unsigned)rng[nb].jn), blk(64);
     const u32* sl = d_lists + rng[nb].soff; const u32* jl = d_lists + rng[nb].joff;
-    // the segment parse (one wave per segment, ~150 ms) goes to this context's own compute units when the chip is sliced
-    // (ctx.hip, ZPQ_CU_SLICES) and there are not more segments than two waves per SIMD of the slice
-    hipStream_t sp = (ctx->slice_simds && rng[nb].sn <= (size_t)ctx->slice_simds * 2) ? ctx->stream3 : st;
     zpq_place PL{nullptr, nullptr, (u32)rng[nb].sn, 0};
     if (rng[nb].sn <= 4096 && zpq_place_enabled()) {
       u32* tab = zpq_simd_table(ctx);
       u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
       if (tab && counter) {
         counter += 44 + nb;
-        ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, sp));
+        ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, st));
         PL.queue = counter; PL.tab = tab; PL.polite = (u32)(2 * rng[nb].sn + 64);
         gs = dim3((unsigned)(3 * rng[nb].sn + 64));
       }
     }
-    if (sp != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3a, st)); ZPQ_HIP(ctx, hipStreamWaitEvent(sp, ctx->ev3a, 0)); }
-#define ZPQ_SPEC_DONE if (sp != st) { ZPQ_HIP(ctx, hipEventRecord(ctx->ev3b, sp)); ZPQ_HIP(ctx, hipStreamWaitEvent(st, ctx->ev3b, 0)); }
     switch (nb) {
-      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL);
               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL);
               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", sp, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL); ZPQ_SPEC_DONE
+      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL);
                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
     }
-#undef ZPQ_SPEC_DONE
     ZPQ_HIP(ctx, hipGetLastError());
   }
   {

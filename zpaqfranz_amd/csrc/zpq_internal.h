@@ -18,9 +18,6 @@ struct zpq_ctx {
   int device;
   hipStream_t stream;
   hipStream_t stream2;      // second stream: block SHA-1 chains overlap the LZ77 parse
-  hipStream_t stream3;      // long few-wave kernels (LZ77 segment parse, fragmenter walks of a small call): == stream unless ZPQ_CU_SLICES
-  hipEvent_t ev3a, ev3b;    // stream -> stream3 -> stream ordering
-  int slice_simds;          // SIMDs behind stream3 (0: stream3 is the main stream)
   hipEvent_t ev;
   hipEvent_t ev2;           // main stream -> second stream ordering (work the caller enqueued before a call)
   int cu_count;
