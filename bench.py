@@ -1198,7 +1198,9 @@ def main():
             alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": hashed - chain_bytes, "gather_kernel": pipe.total + ub,
                    "twin_compare_kernel": tw["compared_bytes"] + (hashed if tw["compared_bytes"] else 0),
                    "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
-            waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": pipe.nfiles}
+            nhashed = pipe.nfiles - tw["twins"]       # files SHA-256 actually sees: one wave (chain) or one lane each
+            waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": nhashed, "sha256_extents_kernel": -(-nhashed // 64),
+                     "lz77_copy_kernel": pipe.nb, "sha1_extents_kernel": -(-pipe.nu // 64)}
             alg_step = pipe.arc_bytes + 2 * pipe.total  # r bytes read + 1 byte written per restored byte + 1 byte read back for SHA-256
             metric = "MB/s compressed archive input extracted + verified (SHA-1 per fragment, SHA-256 per file), Silesia x%d -m1" % a.copies
         else:
