@@ -312,6 +312,11 @@ int zpq_make_config(zpq_ctx* ctx, const char* method, int32_t args[9], char* out
  * type), pcomp = post-processor bytecode with its closing 0 (empty when the config has none). */
 int zpq_compile_config(zpq_ctx* ctx, const char* source, const int32_t* args, uint8_t* header, size_t header_cap,
                        size_t* header_len, uint8_t* pcomp, size_t pcomp_cap, size_t* pcomp_len);
+/* The block headers libzpaq's Compressor::startBlock(int level) selects, level 1..3 = min.cfg / mid.cfg / max.cfg of the
+ * ZPAQ distribution (ZSFX/libzpaq.h:1346; libzpaq keeps them as a byte array in the half of libzpaq.cpp the snapshot
+ * lacks): hsize[2] hh hm ph pm n COMP 0 HCOMP 0, 28 / 71 / 198 bytes.  zpq_builtin_model_source gives the config text. */
+int zpq_builtin_model(int level, uint8_t* header, size_t header_cap, size_t* header_len);
+const char* zpq_builtin_model_source(int level);
 
 #ifdef __cplusplus
 }

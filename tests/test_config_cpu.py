@@ -193,3 +193,64 @@ def test_reference_encoder_reproduces_level5_fixture(name):
     coded = orc.ref_cm_encode(header, b"\0" + plain)
     assert arc[q:q + len(coded)] == coded
     assert arc[q + len(coded)] == 253 and arc[-1] == 255
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Compressor::startBlock(int level) (ZSFX/libzpaq.h:1346): libzpaq's built-in models.  The byte array `models[]` sits in
+# the half of libzpaq.cpp the snapshot lacks; it is libzpaq 7.15's (public domain), held here as the expectation.  The
+# engine keeps the models as min / mid / max.cfg SOURCE: the same bytes must come out of its compiler AND out of the
+# reference Compiler, and the reference Predictor must code with them.
+# ---------------------------------------------------------------------------------------------------------------------
+def _u8(v):
+    return bytes((x + 256) % 256 for x in v)
+
+
+BUILTIN = {
+    1: _u8([26, 0, 1, 2, 0, 0, 2, 3, 16, 8, 19, 0, 0, 96, 4, 28, 59, 10, 59, 112, 25, 10, 59, 10, 59, 112, 56, 0]),
+    2: _u8([69, 0, 3, 3, 0, 0, 8, 3, 5, 8, 13, 0, 8, 17, 1, 8, 18, 2, 8, 18, 3, 8, 19, 4, 4, 22, 24, 7, 16, 0, 7, 24, -1, 0, 17, 104, 74, 4, 95, 1, 59, 112, 10, 25, 59,
+            112, 10, 25, 59, 112, 10, 25, 59, 112, 10, 25, 59, 112, 10, 25, 59, 10, 59, 112, 25, 69, -49, 8, 112, 56, 0]),
+    3: _u8([-60, 0, 5, 9, 0, 0, 22, 1, -96, 3, 5, 8, 13, 1, 8, 16, 2, 8, 18, 3, 8, 19, 4, 8, 19, 5, 8, 20, 6, 4, 22, 24, 3, 17, 8, 19, 9, 3, 13, 3, 13, 3, 13, 3, 14, 7, 16,
+            0, 15, 24, -1, 7, 8, 0, 16, 10, -1, 6, 0, 15, 16, 24, 0, 9, 8, 17, 32, -1, 6, 8, 17, 18, 16, -1, 9, 16, 19, 32, -1, 6, 0, 19, 20, 16, 0, 0, 17, 104, 74, 4,
+            95, 2, 59, 112, 10, 25, 59, 112, 10, 25, 59, 112, 10, 25, 59, 112, 10, 25, 59, 112, 10, 25, 59, 10, 59, 112, 10, 25, 59, 112, 10, 25, 69, -73, 32, -17, 64, 47,
+            14, -25, 91, 47, 10, 25, 60, 26, 48, -122, -105, 20, 112, 63, 9, 70, -33, 0, 39, 3, 25, 112, 26, 52, 25, 25, 74, 10, 4, 59, 112, 25, 10, 4, 59, 112, 25, 10, 4,
+            59, 112, 25, 65, -113, -44, 72, 4, 59, 112, 8, -113, -40, 8, 68, -81, 60, 60, 25, 69, -49, 9, 112, 25, 25, 25, 25, 25, 112, 56, 0]),
+}
+
+
+def builtin_model(cfg, level):
+    import ctypes as C
+    L = cfg.load()
+    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_builtin_model_source.restype = C.c_char_p
+    L.zpq_builtin_model_source.argtypes = [C.c_int]
+    buf = C.create_string_buffer(512)
+    n = C.c_size_t(0)
+    rc = L.zpq_builtin_model(level, buf, 512, C.byref(n))
+    src = L.zpq_builtin_model_source(level)
+    return rc, buf.raw[: n.value], src.decode() if src else None
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_builtin_models_are_libzpaqs(cfg, level):
+    rc, h, src = builtin_model(cfg, level)
+    assert rc == 0 and h == BUILTIN[level]
+    assert h[0] | h[1] << 8 == len(h) - 2 and (h[6], len(h)) == {1: (2, 28), 2: (8, 71), 3: (22, 198)}[level]
+    assert cfg.compile_config(src, [0] * 9) == (BUILTIN[level], b"")
+
+
+def test_builtin_model_levels_out_of_range(cfg):
+    for level in (0, 4, -1):
+        rc, h, src = builtin_model(cfg, level)
+        assert rc != 0 and src is None
+
+
+@needs_ref
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_builtin_models_through_the_reference_compiler_and_predictor(cfg, level):
+    import datagen
+    _, h, src = builtin_model(cfg, level)
+    assert ref_compiled(src, [0] * 9) == (BUILTIN[level], b"")
+    x = b"\0" + datagen.text_like(6000, level) + datagen.binary_like(3000, level + 10)
+    coded = orc.ref_cm_encode(h, x)
+    assert len(coded) < len(x) * 3 // 4                     # it is a model, not noise
+    assert orc.ref_cm_decode(h, coded, len(x) + 16) == x

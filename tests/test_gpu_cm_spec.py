@@ -184,3 +184,22 @@ def test_reference_archive_in_full_both_directions():
     for name, data in files.items():
         xx, crc = attrs[name]
         assert "%08X" % zlib.crc32(data) == crc and orc.xxh64(data) == int(xx, 16), name
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_builtin_models_of_startblock_level_equal_reference(eng, level):
+    """Compressor::startBlock(int level) (ZSFX/libzpaq.h:1346): min / mid / max.cfg as zpq_builtin_model gives them, coded by
+    the specialised kernels like the reference Predictor does."""
+    import ctypes as C
+    from zpaqfranz_amd import engine
+    L = engine.load()
+    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    buf = C.create_string_buffer(512)
+    n = C.c_size_t(0)
+    assert L.zpq_builtin_model(level, buf, 512, C.byref(n)) == 0
+    h = buf.raw[: n.value]
+    x = b"\0" + datagen.text_like(30000, 40 + level) + datagen.binary_like(12000, 50 + level)
+    (st, got), = eng.cm_code([h], [x], [len(x) + 4096], encode=True)
+    assert st == 0 and got == orc.ref_cm_encode(h, x)
+    (st, back), = eng.cm_code([h], [got], [len(x) + 16], encode=False)
+    assert st == 0 and back == x

@@ -639,6 +639,113 @@ int zpq_make_config(zpq_ctx* ctx, const char* method, int32_t args[9], char* out
   }
 }
 
+// ---- the models behind Compressor::startBlock(int level) (ZSFX/libzpaq.h:1346) ------------------------------------------
+// libzpaq keeps them as a byte array `models[]` in Compressor::startBlock(int), which is in the part of libzpaq.cpp the
+// snapshot lacks.  They are min.cfg, mid.cfg and max.cfg of the ZPAQ distribution (public domain); kept here as config
+// SOURCE and compiled by the same compiler as every other config, which gives libzpaq's 28 / 71 / 198 header bytes
+// (tests/test_config_cpu.py holds the byte arrays and also runs the sources through the reference Compiler).
+static const char* const kBuiltinModel[3] = {
+    // level 1: min.cfg
+    "comp 1 2 0 0 2 (hh hm ph pm n)\n"
+    "  0 icm 16\n"
+    "  1 isse 19 0\n"
+    "hcomp\n"
+    "  *b=a a=0 (save in rotating buffer M)\n"
+    "  d=0 hash b-- hash *d=a (order 2 hash for icm)\n"
+    "  d++ b-- hash b-- hash *d=a (order 4 for isse)\n"
+    "  halt\n"
+    "end\n",
+    // level 2: mid.cfg
+    "comp 3 3 0 0 8 (hh hm ph pm n)\n"
+    "  0 icm 5\n"
+    "  1 isse 13 0\n"
+    "  2 isse 17 1\n"
+    "  3 isse 18 2\n"
+    "  4 isse 18 3\n"
+    "  5 isse 19 4\n"
+    "  6 match 22 24\n"
+    "  7 mix 16 0 7 24 255\n"
+    "hcomp\n"
+    "  c++ *c=a b=c a=0 (save in rotating buffer M)\n"
+    "  d= 1 hash *d=a   (orders 1...5 for isse)\n"
+    "  b-- d++ hash *d=a\n"
+    "  b-- d++ hash *d=a\n"
+    "  b-- d++ hash *d=a\n"
+    "  b-- d++ hash *d=a\n"
+    "  b-- d++ hash b-- hash *d=a (order 7 for match)\n"
+    "  d++ a=*c a<<= 8 *d=a (order 1 for mix)\n"
+    "  halt\n"
+    "end\n",
+    // level 3: max.cfg
+    "comp 5 9 0 0 22 (hh hm ph pm n)\n"
+    "  0 const 160\n"
+    "  1 icm 5  (orders 0-6)\n"
+    "  2 isse 13 1 (sizebits j)\n"
+    "  3 isse 16 2\n"
+    "  4 isse 18 3\n"
+    "  5 isse 19 4\n"
+    "  6 isse 19 5\n"
+    "  7 isse 20 6\n"
+    "  8 match 22 24\n"
+    "  9 icm 17 (order 0 word)\n"
+    "  10 isse 19 9 (order 1 word)\n"
+    "  11 icm 13 (sparse with gaps 1-3)\n"
+    "  12 icm 13\n"
+    "  13 icm 13\n"
+    "  14 icm 14 (pic)\n"
+    "  15 mix 16 0 15 24 255 (mix orders 1 and 0)\n"
+    "  16 mix 8 0 16 10 255 (including last mixer)\n"
+    "  17 mix2 0 15 16 24 0\n"
+    "  18 sse 8 17 32 255 (order 0)\n"
+    "  19 mix2 8 17 18 16 255\n"
+    "  20 sse 16 19 32 255 (order 1)\n"
+    "  21 mix2 0 19 20 16 0\n"
+    "hcomp\n"
+    "  c++ *c=a b=c a=0 (save in rotating buffer)\n"
+    "  d= 2 hash *d=a b-- (orders 1,2,3,4,5,7)\n"
+    "  d++ hash *d=a b--\n"
+    "  d++ hash *d=a b--\n"
+    "  d++ hash *d=a b--\n"
+    "  d++ hash *d=a b--\n"
+    "  d++ hash b-- hash *d=a b--\n"
+    "  d++ hash *d=a b-- (match, order 8)\n"
+    "  d++ a=*c a&~ 32 (lowercase words)\n"
+    "  a> 64 if\n"
+    "    a< 91 if (if a-z)\n"
+    "      d++ hashd d-- (update order 1 word hash)\n"
+    "      *d<>a a+=*d a*= 20 *d=a (order 0 word hash)\n"
+    "      jmp 9\n"
+    "    endif\n"
+    "  endif\n"
+    "  (else not a letter)\n"
+    "    a=*d a== 0 ifnot (move word order 0 to 1)\n"
+    "      d++ *d=a d--\n"
+    "    endif\n"
+    "    *d=0  (clear order 0 word hash)\n"
+    "  (end else)\n"
+    "  d++\n"
+    "  d++ b=c b-- a=0 hash *d=a (sparse 2)\n"
+    "  d++ b-- a=0 hash *d=a (sparse 3)\n"
+    "  d++ b-- a=0 hash *d=a (sparse 4)\n"
+    "  d++ a=b a-= 212 b=a a=0 hash\n"
+    "    *d=a b<>a a-= 216 b<>a a=*b a&= 60 hashd (pic)\n"
+    "  d++ a=*c a<<= 9 *d=a (mix)\n"
+    "  d++\n"
+    "  d++\n"
+    "  d++ d++\n"
+    "  d++ *d=a (sse)\n"
+    "  halt\n"
+    "end\n"};
+
+const char* zpq_builtin_model_source(int level) { return level >= 1 && level <= 3 ? kBuiltinModel[level - 1] : nullptr; }
+
+int zpq_builtin_model(int level, uint8_t* header, size_t header_cap, size_t* header_len) {
+  if (level < 1 || level > 3) return ZPQ_ERR_ARG;
+  uint8_t p[8];
+  size_t pl = 0;
+  return zpq_compile_config(nullptr, kBuiltinModel[level - 1], nullptr, header, header_cap, header_len, p, sizeof p, &pl);
+}
+
 int zpq_compile_config(zpq_ctx* ctx, const char* source, const int32_t* args, uint8_t* header, size_t header_cap,
                        size_t* header_len, uint8_t* pcomp, size_t pcomp_cap, size_t* pcomp_len) {
   try {

@@ -439,8 +439,15 @@ void Compressor::writeTag() {
   out_->write((const char*)kTag, 13);
 }
 
-void Compressor::startBlock(int) {
-  error("Compressor::startBlock(level): the byte code of the built-in models is not part of the reference snapshot; pass a config");
+// level = 1, 2, 3: libzpaq's built-in models (min / mid / max.cfg), ZSFX/libzpaq.h:1346
+void Compressor::startBlock(int level) {
+  if (level < 1) error("compression level must be at least 1");
+  if (level > 3) error("compression level too high");
+  uint8_t h[256];
+  size_t hl = 0;
+  const int rc = zpq_builtin_model(level, h, sizeof h, &hl);
+  if (rc != ZPQ_OK) fail(nullptr, rc, "Compressor::startBlock(level)");
+  startBlock((const char*)h);
 }
 
 void Compressor::startBlock(const char* hcomp) {
