@@ -18,5 +18,5 @@ while IFS='|' read -r label envs args; do
   [ -z "$label" ] && continue
   sw "$label" "$envs" "$args"
   el "$label"
-done < tools/sweep_r3g.txt
+done < tools/sweep_r3h_chain_cus_place.txt
 el done
