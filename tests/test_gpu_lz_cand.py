@@ -1,0 +1,46 @@
+"""EXPERIMENTAL, not part of the round-3 record: the candidate-table formulation of the LZ77 hash-table parse
+(lz77_enc.hip, ZPQ_LZ_CAND=1) was written at the end of round 3 without GPU time left to run it.  These tests are what it
+has to pass before it may become the default; they only run with ZPQ_TEST_EXPERIMENTAL=1.  The switch is read once per
+process, so every case runs in a process of its own with the environment set."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("ZPQ_TEST_EXPERIMENTAL") != "1", reason="experimental path: set ZPQ_TEST_EXPERIMENTAL=1")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import datagen, orc
+from zpaqfranz_amd import Engine
+eng = Engine(0)
+rng = np.random.default_rng(9)
+unit = rng.integers(0, 256, size=60000, dtype=np.uint8).tobytes()
+inputs = {"text": datagen.text_like(300000, 1), "binary": datagen.binary_like(250000, 2), "mixed": datagen.mixed(2500000, 3),
+          "runs": bytes(100000) + b"ab" * 50000 + datagen.random_bytes(3000, 4), "long": unit + unit + unit[:100] + datagen.random_bytes(20000, 5) + unit,
+          "tiny": b"abcabcabcabc", "one": b"x", "empty": b""}
+bad = 0
+for args in ([4, 1, 5, 0, 3, 24], [0, 1, 4, 0, 1, 15], [4, 1, 4, 0, 2, 16], [0, 1, 6, 0, 3, 20], [4, 1, 5, 0, 0, 22]):
+    names = list(inputs)
+    got = eng.lz77_encode([inputs[k] for k in names], [args] * len(names))
+    for k, g in zip(names, got):
+        want = orc.lz77_encode(inputs[k], args)
+        if g != want:
+            bad += 1
+            print("MISMATCH", args, k, len(g), len(want))
+print("cases done, mismatches:", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_SEG": "65536"}, {"ZPQ_LZ_SEG": "1048576"}],
+                         ids=["segments", "direct", "seg64k", "seg1m"])
+def test_candidate_table_parse_equals_the_oracle(env):
+    e = dict(os.environ, ZPQ_LZ_CAND="1", **env)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])

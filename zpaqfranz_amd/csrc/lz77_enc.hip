@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include <rocprim/device/device_radix_sort.hpp>     // (only the experimental candidate-table path sorts)
+
 #include "zpq_internal.h"
 
 namespace {
@@ -230,7 +232,12 @@ struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 // (which must hold exactly the inserts of all positions < wbase) and continues the greedy parse
 // from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
 // matches ends where a speculative match ends and returns that token's index (else -1).
-template <int NB, bool DIRECT = false>
+//
+// CAND (experimental, ZPQ_LZ_CAND=1; written at the end of round 3, not yet run on hardware): `ht_generic` is the block's
+// precomputed candidate table instead -- cand[q * NB + k] = the word the reference's search at position q reads from
+// ht[h1 ^ k], i.e. the table as of q, already in probe order (lz77_cand_sweep_kernel).  Lookups become one sequential
+// read per position, nothing is inserted or forwarded, and windows a match swallowed are skipped.
+template <int NB, bool DIRECT = false, bool CAND = false>
 __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
                        SpecList* spec, unsigned long long* T_generic, BitSink* bits = nullptr) {
   const u32 lane = (u32)lane_id();
@@ -249,6 +256,9 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 #endif
 
   for (u32 base = wbase; base < x1 && base < n; base += 64) {
+    if constexpr (CAND) {
+      if (cur >= base + 64) { base += ((cur - base) & ~63u) - 64u; continue; }   // nothing to insert: go to the window that holds cur
+    }
     const u32 q = base + lane;
     const bool inb = q < n && q < x1;
     u32 wend = base + 64 < x1 ? base + 64 : x1;
@@ -269,14 +279,14 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 
     LZ_T(0);
     u32 ent[NB];
-    if (look) GroupLoad<NB>::ld((g_cu32*)(ht + grp), ent);   // bypasses L1: the table is rewritten by this wave
+    if (look) GroupLoad<NB>::ld((g_cu32*)(ht + (CAND ? (size_t)q * NB : (size_t)grp)), ent);   // bypasses L1: the table is rewritten by this wave
     else {
 #pragma unroll
       for (int j = 0; j < NB; ++j) ent[j] = 0;
     }
     // ---- forward inserts of earlier lanes in this window; find superseded stores ---------------
     bool superseded = false;
-    {
+    if constexpr (!CAND) {
       const u32 tk = (grp >> 3) & 255u;
       if (inb) __hip_atomic_fetch_or(&T[tk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       __builtin_amdgcn_wave_barrier();
@@ -301,7 +311,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
     }
     LZ_T(1);
     // ---- reorder the group into probe order ht[h1^k], k = 0..bucket (:6397) ---------------------
-    {
+    if constexpr (!CAND) {
       const u32 hb = h & C.bucket;
 #pragma unroll
       for (int bit = 1; bit < NB; bit <<= 1) {
@@ -488,8 +498,10 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
     }
     LZ_T(4);
     // ---- insert this window's positions (latest writer of a slot wins) --------------------------
-    if (ins && !superseded) ht[slot] = val;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!CAND) {
+      if (ins && !superseded) ht[slot] = val;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     LZ_T(5);
   }
 #ifdef ZPQ_LZ_PROFILE
@@ -528,8 +540,79 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
   }
 }
 
-// ---- speculative parse: one wave per segment ------------------------------------------------------------
+// ---- candidate tables (experimental, ZPQ_LZ_CAND=1; not yet run on hardware) -----------------------------------------
+// Every position is inserted whatever the parse decides, so the eight words the reference's search reads at position q
+// are a function of the data.  Sort all positions of a batch by (block, hash group, position); the entries of one
+// group then form a run in position order, and ONE lane sweeps a run carrying the group's bucket+1 table words in
+// registers: write them out as cand[q] (probe order ht[h1 ^ k]), then apply q's own insert.  A run is a serial chain
+// (the most frequent 5-gram of a 16 MiB block of the stand-in: ~150 k entries), the runs are independent.
+struct CandJob { LzCfg c; u64 pos0; u32* cand; u32 lb, pad; };     // pos0: index of the block's first position in the batch
+
+// key = block << 48 | (h1 >> lb) << 26 | q (lb = log2(bucket + 1), q < 2^26, h1 >> lb < 2^22); val = (h1 & bucket) << 8 | in[q+3]
+__global__ __launch_bounds__(256) void lz77_cand_keys_kernel(const CandJob* __restrict__ jobs, u64* __restrict__ keys, u32* __restrict__ vals) {
+  const CandJob J = jobs[blockIdx.y];
+  const LzCfg& C = J.c;
+  g_cu8* in = (g_cu8*)C.in;
+  for (u32 q = blockIdx.x * 256u + threadIdx.x; q < C.n; q += gridDim.x * 256u) {
+    const u64 qb = load8(in + q);
+    u32 h;
+    if (C.minMatch <= 8 && q >= C.minMatch && q <= C.upd_limit) h = hash_fast(C, qb);
+    else h = hash_at(C, q);                                   // the first minMatch positions, and the frozen hash behind upd_limit
+    const u32 b3 = q + 3 < C.n ? (u32)((qb >> 24) & 255u) : 0u;
+    keys[J.pos0 + q] = ((u64)blockIdx.y << 48) | ((u64)(h >> J.lb) << 26) | (u64)q;
+    vals[J.pos0 + q] = ((h & C.bucket) << 8) | b3;
+  }
+}
+
+// One lane per sorted entry; the lane that holds the first entry of a run sweeps the run, the others leave.
 template <int NB>
+__global__ __launch_bounds__(64) void lz77_cand_sweep_kernel(const CandJob* __restrict__ jobs, const u64* __restrict__ keys,
+                                                             const u32* __restrict__ vals, u64 total) {
+  const u64 i0 = (u64)blockIdx.x * 64u + threadIdx.x;
+  if (i0 >= total) return;
+  const u64 g0 = keys[i0] >> 26;
+  if (i0 && (keys[i0 - 1] >> 26) == g0) return;
+  const CandJob J = jobs[(u32)(g0 >> 22)];
+  const u32 mask = (1u << J.c.checkbits) - 1u;
+  u32 v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = 0;
+  for (u64 i = i0; i < total; ++i) {
+    const u64 key = keys[i];
+    if ((key >> 26) != g0) break;
+    const u32 q = (u32)(key & ((1u << 26) - 1u));
+    const u32 val = vals[i];
+    const u32 hb = (val >> 8) & J.c.bucket, b3 = val & 255u;
+    // cand[q][k] = v[hb ^ k]: butterfly on the bits of hb
+    u32 o[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) o[j] = v[j];
+#pragma unroll
+    for (int bit = 1; bit < NB; bit <<= 1) {
+      const bool sw = (hb & (u32)bit) != 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (!(j & bit)) {
+          const u32 a = o[j], b = o[j | bit];
+          o[j] = sw ? b : a;
+          o[j | bit] = sw ? a : b;
+        }
+    }
+    u32* dst = J.cand + (size_t)q * NB;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dst[j] = o[j];
+    // q's own insert: ht[h1 ^ ih] = (q << checkbits) | (in[q+3] & mask)   (:6435-6440)
+    if (q < J.c.upd_limit) {
+      const u32 slot = hb ^ (((q * 1234547u) >> 19) & J.c.bucket);
+      const u32 nv = (q << J.c.checkbits) | (b3 & mask);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) v[j] = slot == (u32)j ? nv : v[j];
+    }
+  }
+}
+
+// ---- speculative parse: one wave per segment ------------------------------------------------------------
+template <int NB, bool CAND = false>
 __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list, const zpq_place P) {
   // The block-checksum chains (sha1_chain_kernel, other stream) are pure VALU and may land on the same
   // SIMD: this latency-bound parse must win issue arbitration or its slowest wave doubles the launch.
@@ -546,7 +629,7 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
     __builtin_amdgcn_wave_barrier();
     TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
     u32 cur = S.x0, lit = 0;
-    lz_walk<NB>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
+    lz_walk<NB, false, CAND>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
     if (lane == 0) {
       S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
       S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
@@ -557,7 +640,7 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
 }
 
 // ---- one wave per block, no speculation: parse and emit in one go (many blocks: "one wavefront per ZPAQ block") --------
-template <int NB>
+template <int NB, bool CAND = false>
 __global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
                                                          const u32* __restrict__ list) {
   const LzJobDev J = jobs[list[blockIdx.x]];
@@ -572,7 +655,7 @@ __global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restr
   bs.in = (__attribute__((address_space(1))) const u8*)J.in;
   bs.acc = 0; bs.accbits = 0; bs.bytepos = 0; bs.gap_start = 0; bs.rb = J.rb; bs.overflow = 0;
   u32 cur = 0, lit = 0;
-  lz_walk<NB, true>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
+  lz_walk<NB, true, CAND>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
   const u32 bytes = bs.finish(J.n, lane);
   const unsigned long long ov = __ballot(bs.overflow != 0);
   if (lane == 0) { J.result[0] = sink.n; J.result[1] = bytes; J.result[2] = (ov != 0 || bytes > J.out_cap) ? 1u : 0u; }
@@ -582,7 +665,7 @@ __global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restr
 // Seam k continues the parse from where segment k-1's SPECULATION ended (true whenever segment k-1 got back
 // in step, which the stitch kernel verifies) into segment k, on the pristine table of x0, until one of its
 // matches ends where a speculative match of segment k ends.
-template <int NB>
+template <int NB, bool CAND = false>
 __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
   __builtin_amdgcn_s_setprio(3);
   const u32 si = list[blockIdx.x];
@@ -600,7 +683,7 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
   if (cur == S.x0 && lit == 0) hit = -2;                           // in step from the first position
   else if (cur < S.x1) {
     SpecList sl{S.tpos, S.tlen, S.state[0], 0};
-    hit = lz_walk<NB>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+    hit = lz_walk<NB, false, CAND>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
   }
   if (lane == 0) {
     S.seam[0] = sink.n < sink.cap ? sink.n : sink.cap;
@@ -614,7 +697,7 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
 // Glues [speculative tokens of segment 0] [seam 1] [speculative tokens of segment 1 from its sync index] ...
 // A seam is used only if it started from the state the true chain really is in; otherwise the segment is
 // re-walked here on work[k-1] (after the speculative pass that table holds exactly the inserts < x0).
-template <int NB>
+template <int NB, bool CAND = false>
 __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
                                                          const u32* __restrict__ list) {
   __builtin_amdgcn_s_setprio(3);
@@ -658,7 +741,7 @@ __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restr
     // exact re-walk (rare: the previous segment never got back in step)
     SpecList sl{S.tpos, S.tlen, ns, 0};
     u32* table = k ? segs[J.seg0 + k - 1].work : S.work;
-    const int hit = lz_walk<NB>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    const int hit = lz_walk<NB, false, CAND>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
     T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
     __builtin_amdgcn_wave_barrier();
     if (hit >= 0) { append(0, (u32)hit + 1, ns); cur = S.state[1]; lit = S.state[2]; }
@@ -863,6 +946,14 @@ static T* carve(u8*& p, size_t count) {
 
 // HBM a job needs while it is parsed with segments of kSegBytes: 2*segments-1 hash tables plus the token lists
 static size_t job_bytes_direct(const zpq_lz77_job& z) { return ((size_t)4 << z.args[5]) + 4096; }
+// the same with a candidate table instead of table states (ZPQ_LZ_CAND): bucket+1 words per position, the sort's double
+// buffers (8 + 4 bytes per position, twice) and its temporary storage (bounded by another 12)
+static size_t job_bytes_cand(const zpq_lz77_job& z, u32 kSegBytes, bool direct) {
+  const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
+  const size_t mm = (size_t)(z.args[2] >= 4 ? z.args[2] : 4);
+  const size_t toks = direct ? 0 : (size_t)z.n / mm + 3 + 3 * nseg;
+  return (size_t)z.n * (((size_t)4 << z.args[4]) + 36) + toks * (16 + 12 + (nseg > 1 ? 12 : 0)) + 4096;
+}
 static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
   // tokens are matches of at least args[2] bytes that do not overlap: n / minMatch of them at most.  Final list 4 words
@@ -873,18 +964,21 @@ static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
 }
 
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
-static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct) {
+static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct, const bool cand = false) {
   hipStream_t st = ctx->stream;
   const size_t nj = hi - lo;
   std::vector<LzJobDev> hj(nj);
   std::vector<LzSegDev> hs;
   size_t table_words = 0, tok_words = 0;
   u32 max_n = 0, max_seg = 1;
+  u64 cand_positions = 0;            // candidate-table mode: positions of the batch (= sort keys)
+  size_t cand_sort_temp = 0;
   for (size_t i = 0; i < nj; ++i) {
     const zpq_lz77_job& z = jobs[lo + i];
     const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
     const size_t words = (size_t)1 << z.args[5];
-    table_words += words * (2 * (size_t)nseg - 1);
+    if (cand) { table_words += (size_t)z.n << z.args[4]; cand_positions += z.n; }
+    else table_words += words * (2 * (size_t)nseg - 1);
     const u32 mmt = (u32)(z.args[2] >= 4 ? z.args[2] : 4);
     if (!direct) tok_words += ((size_t)z.n / mmt + 3) * 4;  // final pos/len/off/bit
     for (u32 k = 0; k < nseg && !direct; ++k) {
@@ -895,9 +989,14 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   size_t nseg_total = 0;
   for (size_t i = 0; i < nj; ++i) nseg_total += std::max<u32>(1, (jobs[lo + i].n + kSegBytes - 1) / kSegBytes);
+  const size_t cand_words = table_words;       // (candidate-table mode) the sort buffers sit behind the tables
+  if (cand) {
+    ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, cand_sort_temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)cand_positions, 0u, 64u, st));
+    table_words = ((cand_words + 63) & ~(size_t)63) + (size_t)cand_positions * 6 + 64 + (cand_sort_temp + 3) / 4 + 64;
+  }
   u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
   u32* d_tok = (u32*)zpq_scratch(ctx, 1, tok_words * 4 + 256);
-  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4) + nseg_total * (sizeof(LzSegDev) + 48 + 36 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
+  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4 + sizeof(CandJob)) + 256 + nseg_total * (sizeof(LzSegDev) + 48 + 36 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
   u8* d_meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
   if (!d_tab || !d_tok || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 scratch (%zu MiB of tables)", table_words >> 18);
   u8* mp = d_meta;
@@ -910,6 +1009,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   u32* d_lists = carve<u32>(mp, (nj + nseg_total) * 4);      // per bucket width: job list, segment list
   CopyJob* d_copy = carve<CopyJob>(mp, nseg_total * 2);
   ScatterJob* d_scat = carve<ScatterJob>(mp, nseg_total);
+  CandJob* d_cjobs = carve<CandJob>(mp, nj);
   ZPQ_HIP(ctx, hipMemsetAsync(d_res, 0, nj * 16, st));
 
   size_t to = 0, tabo = 0;
@@ -938,19 +1038,22 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     // tables: work[0..nseg-1], pristine[1..nseg-1]
     u32* work0 = d_tab + tabo;
     u32* prist0 = work0 + words * nseg - words;   // pristine[k] = prist0 + k*words, k >= 1
-    tabo += words * (2 * (size_t)nseg - 1);
-    copy_step[0].push_back({nullptr, work0, (u32)words});
+    if (cand) tabo += (size_t)z.n << a[4];        // work0 = this block's candidate table; every segment reads it
+    else {
+      tabo += words * (2 * (size_t)nseg - 1);
+      copy_step[0].push_back({nullptr, work0, (u32)words});
+    }
     for (u32 k = 0; k < nseg; ++k) {
       LzSegDev S;
       S.c = c; S.x0 = k * kSegBytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + kSegBytes, z.n);
-      S.work = work0 + words * k;
-      S.pristine = k ? prist0 + words * k : nullptr;
+      S.work = cand ? work0 : work0 + words * k;
+      S.pristine = cand ? work0 : k ? prist0 + words * k : nullptr;
       const u32 scap = direct ? 0u : (S.x1 - S.x0) / mmt + 3;
       S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap ? scap - 1 : 0; to += (size_t)scap * 3;
       if (k) { S.qpos = d_tok + to; S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; to += (size_t)scap * 3; }
       else { S.qpos = S.tpos; S.qlen = S.tlen; S.qoff = S.toff; }       // no seam walk enters a first segment (never written, never read)
       S.state = d_state + 12 * hs.size(); S.seam = S.state + 4;
-      if (k) {
+      if (k && !cand) {
         copy_step[k].push_back({k == 1 ? nullptr : prist0 + words * (k - 1), S.pristine, (u32)words});
         scat_step[k].push_back({c, (k - 1) * kSegBytes, k * kSegBytes, S.pristine});
         copy_work.push_back({S.pristine, S.work, (u32)words});
@@ -962,8 +1065,43 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), nj * sizeof(LzJobDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_segs, hs.data(), hs.size() * sizeof(LzSegDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  // 1'. candidate tables instead of table states: keys, sort, one sweep (see lz77_cand_sweep_kernel)
+  if (cand) {
+    std::vector<CandJob> cjobs(nj);
+    u64 pos0 = 0;
+    for (size_t i = 0; i < nj; ++i) {
+      CandJob& Cj = cjobs[i];
+      Cj.c = hs[hj[i].seg0].c; Cj.pos0 = pos0; Cj.cand = hs[hj[i].seg0].work; Cj.lb = (u32)jobs[lo + i].args[4]; Cj.pad = 0;
+      pos0 += jobs[lo + i].n;
+    }
+    u64* d_keys0 = (u64*)(d_tab + ((cand_words + 63) & ~(size_t)63));
+    u64* d_keys1 = d_keys0 + cand_positions;
+    u32* d_vals0 = (u32*)(d_keys1 + cand_positions);
+    u32* d_vals1 = d_vals0 + cand_positions;
+    void* d_tmp = (void*)(((uintptr_t)(d_vals1 + cand_positions) + 255) & ~(uintptr_t)255);
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_cjobs, cjobs.data(), nj * sizeof(CandJob), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));          // cjobs is a local
+    ZPQ_LAUNCH(ctx, "lz77_cand_keys_kernel", st, lz77_cand_keys_kernel, dim3(std::min<u32>((max_n + 255) / 256, 2048), (unsigned)nj), dim3(256), d_cjobs,
+               d_keys0, d_vals0);
+    ZPQ_HIP(ctx, hipGetLastError());
+    {
+      ZpqProfScope prof_scope_(ctx, "lz77_cand_sort", st);
+      size_t tb = cand_sort_temp;
+      u32 end_bit = 48;
+      while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
+      ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)cand_positions, 0u, end_bit, st));
+    }
+    const unsigned sweep_grid = (unsigned)((cand_positions + 63) / 64);
+    switch (jobs[lo].args[4]) {
+      case 0: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<1>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
+      case 1: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<2>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
+      case 2: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<4>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
+      default: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<8>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
+    }
+    ZPQ_HIP(ctx, hipGetLastError());
+  }
   // 1. table states at the segment starts: pristine[k] = pristine[k-1] + inserts of segment k-1
-  {
+  if (!cand) {
     std::vector<CopyJob> cj; std::vector<ScatterJob> sj;
     std::vector<std::pair<size_t, size_t>> crange(max_seg), srange(max_seg);
     for (u32 k = 0; k < max_seg; ++k) {
@@ -1013,10 +1151,10 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       dim3 gj((unsigned)rng[nb].jn), blk(64);
       const u32* jl = d_lists + rng[nb].joff;
       switch (nb) {
-        case 0: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-        case 1: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-        case 2: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-        default: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+        case 0: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (cand ? lz77_direct_kernel<1, true> : lz77_direct_kernel<1, false>), gj, blk, d_jobs, d_segs, jl); break;
+        case 1: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (cand ? lz77_direct_kernel<2, true> : lz77_direct_kernel<2, false>), gj, blk, d_jobs, d_segs, jl); break;
+        case 2: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (cand ? lz77_direct_kernel<4, true> : lz77_direct_kernel<4, false>), gj, blk, d_jobs, d_segs, jl); break;
+        default: ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (cand ? lz77_direct_kernel<8, true> : lz77_direct_kernel<8, false>), gj, blk, d_jobs, d_segs, jl); break;
       }
       ZPQ_HIP(ctx, hipGetLastError());
     }
@@ -1046,18 +1184,18 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       }
     }
     switch (nb) {
-      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL);
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL);
-              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL);
-               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+      case 0: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (cand ? lz77_spec_kernel<1, true> : lz77_spec_kernel<1, false>), gs, blk, d_segs, sl, PL);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (cand ? lz77_seam_kernel<1, true> : lz77_seam_kernel<1, false>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (cand ? lz77_stitch_kernel<1, true> : lz77_stitch_kernel<1, false>), gj, blk, d_jobs, d_segs, jl); break;
+      case 1: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (cand ? lz77_spec_kernel<2, true> : lz77_spec_kernel<2, false>), gs, blk, d_segs, sl, PL);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (cand ? lz77_seam_kernel<2, true> : lz77_seam_kernel<2, false>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (cand ? lz77_stitch_kernel<2, true> : lz77_stitch_kernel<2, false>), gj, blk, d_jobs, d_segs, jl); break;
+      case 2: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (cand ? lz77_spec_kernel<4, true> : lz77_spec_kernel<4, false>), gs, blk, d_segs, sl, PL);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (cand ? lz77_seam_kernel<4, true> : lz77_seam_kernel<4, false>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (cand ? lz77_stitch_kernel<4, true> : lz77_stitch_kernel<4, false>), gj, blk, d_jobs, d_segs, jl); break;
+      default: ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (cand ? lz77_spec_kernel<8, true> : lz77_spec_kernel<8, false>), gs, blk, d_segs, sl, PL);
+               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (cand ? lz77_seam_kernel<8, true> : lz77_seam_kernel<8, false>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (cand ? lz77_stitch_kernel<8, true> : lz77_stitch_kernel<8, false>), gj, blk, d_jobs, d_segs, jl); break;
     }
     ZPQ_HIP(ctx, hipGetLastError());
   }
@@ -1125,6 +1263,38 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
       for (size_t i = 0; i < njobs; ++i) { bytes += job_bytes(jobs[i], seg); nseg += std::max<u32>(1, (u32)(((u64)jobs[i].n + seg - 1) / seg)); }
       if (bytes <= budget || seg >= max_n || nseg <= 2048 || seg >= (1u << 30)) break;
       seg <<= 1;
+    }
+  }
+  // Experimental (ZPQ_LZ_CAND=1; written at the end of round 3, not yet run on hardware): candidate tables instead of
+  // table states.  Memory per block no longer depends on the number of segments, so the segment size is chosen for waves
+  // alone (about four per SIMD, 256 KiB at least) and what does not fit runs in batches.
+  static const int cand_mode = [] { const char* e = getenv("ZPQ_LZ_CAND"); return e ? atoi(e) : 0; }();
+  if (cand_mode) {
+    bool ok = njobs < 65536;
+    u64 all_n = 0;
+    for (size_t i = 0; i < njobs && ok; ++i) {
+      ok = jobs[i].args[4] == jobs[0].args[4] && jobs[i].args[5] - jobs[i].args[4] <= 22 && jobs[i].n < (1u << 26);
+      all_n += jobs[i].n;
+    }
+    if (ok) {
+      u32 cseg = 256u << 10;
+      if (const char* e = getenv("ZPQ_LZ_SEG")) cseg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));
+      else while ((u64)cseg * 4096 < all_n && cseg < (1u << 30)) cseg <<= 1;
+      bool cdirect = false;
+      if (const char* e = getenv("ZPQ_LZ_DIRECT")) cdirect = atoi(e) != 0;
+      size_t lo = 0;
+      while (lo < njobs) {
+        size_t hi = lo, bytes = 0;
+        while (hi < njobs) {
+          const size_t bts = job_bytes_cand(jobs[hi], cseg, cdirect);
+          if (hi > lo && bytes + bts > budget) break;
+          bytes += bts; ++hi;
+        }
+        int rc = encode_batch(ctx, jobs, lo, hi, cdirect ? (1u << 30) : cseg, cdirect, true);
+        if (rc) return rc;
+        lo = hi;
+      }
+      return ZPQ_OK;
     }
   }
   // Two ways to run a batch.  Speculative segments: many waves per block, 2*segments-1 tables and token lists per block
