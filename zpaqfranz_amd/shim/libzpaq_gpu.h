@@ -154,7 +154,7 @@ class Compressor {
   ~Compressor();
   void setOutput(Writer* out) { out_ = out; }
   void writeTag();
-  void startBlock(int level);                 // built-in models 1..3: their byte code is not in the reference snapshot -> error()
+  void startBlock(int level);                 // libzpaq's built-in models: 1 = min.cfg, 2 = mid.cfg, 3 = max.cfg (zpq_builtin_model)
   void startBlock(const char* hcomp);         // ZPAQL byte code, starting at hsize[2]
   void startBlock(const char* config, int* args, Writer* pcomp_cmd = 0);   // ZPAQL source
   void setVerify(bool) {}
