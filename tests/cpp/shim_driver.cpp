@@ -80,6 +80,7 @@ static int extract_mode(const char* path, size_t max_usize) {
 static int compressor_mode(const char* in_path, const char* config_path, int nseg, const char* out_path) {
   std::vector<char> data, cfg;
   for (int k = 0; k < 2; ++k) {
+    if (k && strncmp(config_path, "level:", 6) == 0) break;
     FILE* f = fopen(k ? config_path : in_path, "rb");
     if (!f) return 3;
     char buf[1 << 16]; size_t r;
@@ -95,7 +96,8 @@ static int compressor_mode(const char* in_path, const char* config_path, int nse
     co.setOutput(&w);
     co.writeTag();
     int args[9] = {0};
-    co.startBlock(cfg.data(), args);
+    if (strncmp(config_path, "level:", 6) == 0) co.startBlock(atoi(config_path + 6));     // libzpaq's built-in models 1..3
+    else co.startBlock(cfg.data(), args);
     const size_t share = (data.size() + nseg - 1) / std::max(1, nseg);
     for (int k = 0; k < nseg; ++k) {
       const size_t lo = std::min(data.size(), k * share), hi = std::min(data.size(), lo + share);

@@ -471,3 +471,30 @@ def test_sha1_extents_staged_and_direct_forms_agree_with_hashlib(staged):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "sha1_extents_probe.py"), kind, "1.5"], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-1500:]
         assert "digests ok: True" in r.stdout and ("staged=%s" % staged) in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_shim_compressor_startblock_level(tmp_path, level):
+    """Compressor::startBlock(int level) (ZSFX/libzpaq.h:1346): the block carries libzpaq's built-in model `level`, the coded
+    bytes are the reference Encoder's for that model, the real reference decoder restores the input."""
+    import subprocess
+    import ctypes as C
+    from zpaqfranz_amd import build, engine
+    build.build(verbose=False)
+    drv = build.build_shim_driver(str(tmp_path / "shim_driver"))
+    small = datagen.mixed(20000, 92 + level)
+    (tmp_path / "small.bin").write_bytes(small)
+    r = subprocess.run([drv, "--compressor", str(tmp_path / "small.bin"), "level:%d" % level, "1", str(tmp_path / "l.zpaq")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    arc = (tmp_path / "l.zpaq").read_bytes()
+    L = engine.load()
+    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    buf = C.create_string_buffer(512)
+    n = C.c_size_t(0)
+    assert L.zpq_builtin_model(level, buf, 512, C.byref(n)) == 0
+    hdr = buf.raw[: n.value]
+    coded = orc.ref_cm_encode(hdr, b"\0" + small)
+    want = bytes.fromhex("376b5374a03183d38cb228b0d3") + b"zPQ\x01\x01" + hdr + b"\x01seg0\0c\0\0" + coded + b"\xfd" + orc.sha1(small) + b"\xff"
+    assert arc == want
+    assert orc.ref_decompress(arc, len(small) + 64) == small
