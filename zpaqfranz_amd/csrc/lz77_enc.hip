@@ -577,36 +577,47 @@ __global__ __launch_bounds__(64) void lz77_cand_sweep_kernel(const CandJob* __re
   u32 v[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) v[j] = 0;
-  for (u64 i = i0; i < total; ++i) {
-    const u64 key = keys[i];
-    if ((key >> 26) != g0) break;
-    const u32 q = (u32)(key & ((1u << 26) - 1u));
-    const u32 val = vals[i];
-    const u32 hb = (val >> 8) & J.c.bucket, b3 = val & 255u;
-    // cand[q][k] = v[hb ^ k]: butterfly on the bits of hb
-    u32 o[NB];
+  // four entries per round, their loads issued together (a run is one chain of dependent rounds: the hottest group of a
+  // 16 MiB block holds ~150 k entries)
+  bool more = true;
+  for (u64 i = i0; more && i < total; i += 4) {
+    u64 kk[4]; u32 vv[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) o[j] = v[j];
-#pragma unroll
-    for (int bit = 1; bit < NB; bit <<= 1) {
-      const bool sw = (hb & (u32)bit) != 0;
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-        if (!(j & bit)) {
-          const u32 a = o[j], b = o[j | bit];
-          o[j] = sw ? b : a;
-          o[j | bit] = sw ? a : b;
-        }
+    for (int t = 0; t < 4; ++t) {
+      const u64 x = i + t < total ? i + t : total - 1;
+      kk[t] = keys[x]; vv[t] = vals[x];
     }
-    u32* dst = J.cand + (size_t)q * NB;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) dst[j] = o[j];
-    // q's own insert: ht[h1 ^ ih] = (q << checkbits) | (in[q+3] & mask)   (:6435-6440)
-    if (q < J.c.upd_limit) {
-      const u32 slot = hb ^ (((q * 1234547u) >> 19) & J.c.bucket);
-      const u32 nv = (q << J.c.checkbits) | (b3 & mask);
+    for (int t = 0; t < 4; ++t) {
+      if (!more || i + t >= total || (kk[t] >> 26) != g0) { more = false; continue; }
+      const u32 q = (u32)(kk[t] & ((1u << 26) - 1u));
+      const u32 val = vv[t];
+      const u32 hb = (val >> 8) & J.c.bucket, b3 = val & 255u;
+      // cand[q][k] = v[hb ^ k]: butterfly on the bits of hb
+      u32 o[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) v[j] = slot == (u32)j ? nv : v[j];
+      for (int j = 0; j < NB; ++j) o[j] = v[j];
+#pragma unroll
+      for (int bit = 1; bit < NB; bit <<= 1) {
+        const bool sw = (hb & (u32)bit) != 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (!(j & bit)) {
+            const u32 a = o[j], b = o[j | bit];
+            o[j] = sw ? b : a;
+            o[j | bit] = sw ? a : b;
+          }
+      }
+      u32* dst = J.cand + (size_t)q * NB;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) dst[j] = o[j];
+      // q's own insert: ht[h1 ^ ih] = (q << checkbits) | (in[q+3] & mask)   (:6435-6440)
+      if (q < J.c.upd_limit) {
+        const u32 slot = hb ^ (((q * 1234547u) >> 19) & J.c.bucket);
+        const u32 nv = (q << J.c.checkbits) | (b3 & mask);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) v[j] = slot == (u32)j ? nv : v[j];
+      }
     }
   }
 }
