@@ -44,3 +44,34 @@ def test_candidate_table_parse_equals_the_oracle(env):
     e = dict(os.environ, ZPQ_LZ_CAND="1", **env)
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("args", [[4, 1, 5, 0, 3, 24], [0, 1, 4, 0, 1, 15], [4, 1, 4, 0, 2, 16], [4, 1, 5, 0, 0, 22]], ids=lambda a: ",".join(map(str, a)))
+def test_candidate_table_equals_the_sequential_table(args):
+    """zpq_lz77_cand_dev (keys, sort, group sweep) against the oracle's sequential table, word for word."""
+    import ctypes as C
+    import numpy as np
+    import datagen
+    import orc
+    from zpaqfranz_amd import Engine, engine
+    eng = Engine(0)
+    try:
+        L = engine.load()
+        L.zpq_lz77_cand_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p]
+        for name, b in (("mixed", datagen.mixed(700000, 3)), ("text", datagen.text_like(200000, 1)), ("runs", bytes(100000) + b"ab" * 50000),
+                        ("nine", b"123456789"), ("one", b"x")):
+            d_in = eng.upload(b + bytes(64))
+            words = len(b) << args[4]
+            d_c = eng.alloc(words * 4 + 64)
+            try:
+                a = (C.c_int32 * 9)(*(args + [0] * 9)[:9])
+                rc = L.zpq_lz77_cand_dev(eng.ctx, d_in.ptr, len(b), a, d_c.ptr)
+                assert rc == 0, (name, rc)
+                got = np.frombuffer(d_c.download(words * 4), dtype=np.uint32)
+                want = orc.lz77_cand(b, args)
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, (name, args, int(bad[0]) >> args[4], int(bad[0]) & ((1 << args[4]) - 1), int(got[bad[0]]), int(want[bad[0]]), bad.size)
+            finally:
+                d_in.free(); d_c.free()
+    finally:
+        eng.close()

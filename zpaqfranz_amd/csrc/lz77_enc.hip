@@ -974,6 +974,41 @@ static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + toks * (16 + 12 + (nseg > 1 ? 12 : 0));
 }
 
+// Candidate tables of a batch: keys of every position, one sort, one sweep.  `buf` holds two key and two value arrays
+// (24 bytes per position) followed by `temp_bytes` of temporary storage for the sort; every job's `cand` pointer must have
+// room for n << lb words.
+static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& cjobs, CandJob* d_cjobs, u64 positions, u32 max_n, u8* buf,
+                      size_t temp_bytes) {
+  const size_t nj = cjobs.size();
+  if (!nj || !positions) return ZPQ_OK;
+  u64* d_keys0 = (u64*)buf;
+  u64* d_keys1 = d_keys0 + positions;
+  u32* d_vals0 = (u32*)(d_keys1 + positions);
+  u32* d_vals1 = d_vals0 + positions;
+  void* d_tmp = (void*)(((uintptr_t)(d_vals1 + positions) + 255) & ~(uintptr_t)255);
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_cjobs, cjobs.data(), nj * sizeof(CandJob), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));          // cjobs may be a local of the caller
+  ZPQ_LAUNCH(ctx, "lz77_cand_keys_kernel", st, lz77_cand_keys_kernel, dim3(std::min<u32>((max_n + 255) / 256, 2048), (unsigned)nj), dim3(256), d_cjobs,
+             d_keys0, d_vals0);
+  ZPQ_HIP(ctx, hipGetLastError());
+  {
+    ZpqProfScope prof_scope_(ctx, "lz77_cand_sort", st);
+    size_t tb = temp_bytes;
+    u32 end_bit = 48;
+    while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
+    ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, st));
+  }
+  const unsigned sweep_grid = (unsigned)((positions + 63) / 64);
+  switch (cjobs[0].lb) {
+    case 0: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<1>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
+    case 1: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<2>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
+    case 2: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<4>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
+    default: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<8>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
+  }
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
+
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
 static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct, const bool cand = false) {
   hipStream_t st = ctx->stream;
@@ -1085,31 +1120,8 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       Cj.c = hs[hj[i].seg0].c; Cj.pos0 = pos0; Cj.cand = hs[hj[i].seg0].work; Cj.lb = (u32)jobs[lo + i].args[4]; Cj.pad = 0;
       pos0 += jobs[lo + i].n;
     }
-    u64* d_keys0 = (u64*)(d_tab + ((cand_words + 63) & ~(size_t)63));
-    u64* d_keys1 = d_keys0 + cand_positions;
-    u32* d_vals0 = (u32*)(d_keys1 + cand_positions);
-    u32* d_vals1 = d_vals0 + cand_positions;
-    void* d_tmp = (void*)(((uintptr_t)(d_vals1 + cand_positions) + 255) & ~(uintptr_t)255);
-    ZPQ_HIP(ctx, hipMemcpyAsync(d_cjobs, cjobs.data(), nj * sizeof(CandJob), hipMemcpyHostToDevice, st));
-    ZPQ_HIP(ctx, hipStreamSynchronize(st));          // cjobs is a local
-    ZPQ_LAUNCH(ctx, "lz77_cand_keys_kernel", st, lz77_cand_keys_kernel, dim3(std::min<u32>((max_n + 255) / 256, 2048), (unsigned)nj), dim3(256), d_cjobs,
-               d_keys0, d_vals0);
-    ZPQ_HIP(ctx, hipGetLastError());
-    {
-      ZpqProfScope prof_scope_(ctx, "lz77_cand_sort", st);
-      size_t tb = cand_sort_temp;
-      u32 end_bit = 48;
-      while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
-      ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)cand_positions, 0u, end_bit, st));
-    }
-    const unsigned sweep_grid = (unsigned)((cand_positions + 63) / 64);
-    switch (jobs[lo].args[4]) {
-      case 0: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<1>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
-      case 1: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<2>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
-      case 2: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<4>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
-      default: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<8>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, cand_positions); break;
-    }
-    ZPQ_HIP(ctx, hipGetLastError());
+    int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)(d_tab + ((cand_words + 63) & ~(size_t)63)), cand_sort_temp);
+    if (rc) return rc;
   }
   // 1. table states at the segment starts: pristine[k] = pristine[k-1] + inserts of segment k-1
   if (!cand) {
@@ -1228,6 +1240,34 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     jobs[lo + i].out_len = res[4 * i + 1];
     if (res[4 * i + 2]) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: token or output capacity exceeded", lo + i);
   }
+  return ZPQ_OK;
+}
+
+// Experimental / test entry: the candidate table of ONE block (args as for zpq_lz77_encode_dev, hash-table finder):
+// d_cand receives n << args[4] words, cand[q * (bucket+1) + k] = what the reference's search at q reads from ht[h1 ^ k].
+extern "C" int zpq_lz77_cand_dev(zpq_ctx* ctx, const void* d_in, uint32_t n, const int32_t args[9], uint32_t* d_cand) {
+  if (!ctx || !args || (n && (!d_in || !d_cand))) return ZPQ_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  int rc = check_args(ctx, args, n);
+  if (rc) return rc;
+  if (uses_suffix_array(args) || args[4] > 3 || args[5] - args[4] > 22 || n >= (1u << 26)) return zpq_fail(ctx, ZPQ_ERR_ARG, "no candidate table for these arguments");
+  if (n == 0) return ZPQ_OK;
+  hipStream_t st = ctx->stream;
+  std::vector<CandJob> cj(1);
+  LzCfg& c = cj[0].c;
+  c.in = (const u8*)d_in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
+  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
+  const u32 mmb = args[2] + 4;
+  c.upd_limit = n > mmb ? n - mmb : 0;
+  cj[0].pos0 = 0; cj[0].cand = d_cand; cj[0].lb = (u32)args[4]; cj[0].pad = 0;
+  size_t temp = 0;
+  ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, st));
+  u8* buf = (u8*)zpq_scratch(ctx, 0, (size_t)n * 24 + temp + 1024);
+  CandJob* d_cjobs = (CandJob*)zpq_scratch(ctx, 2, sizeof(CandJob) + 256);
+  if (!buf || !d_cjobs) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "candidate table scratch");
+  rc = cand_build(ctx, st, cj, d_cjobs, n, n, buf, temp);
+  if (rc) return rc;
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
   return ZPQ_OK;
 }
 
