@@ -66,3 +66,50 @@ def test_candidate_table_is_what_a_group_sweep_gives():
         if q < upd:
             v[hb ^ (((q * 1234547) & 0xFFFFFFFF) >> 19 & B)] = ((q << cb) & 0xFFFFFFFF) | (int(a[q + 3]) & msk)
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The DEVICE source of the candidate-table kernels (zpaqfranz_amd/csrc/lz77_cand.inc) compiled for the host under a serial
+# SIMT shim (tests/cpp/cand_host.cpp): the same code the GPU runs, one thread after the other, must give the oracle's table.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cand_host(tmp_path_factory):
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("cand") / "cand_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I" + os.path.join(root, "zpaqfranz_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "cand_host.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.cand_host.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32), C.c_void_p]
+
+    def run(blocks, args):
+        off, pos = [], 0
+        for b in blocks:
+            off.append(pos); pos += len(b) + 3            # odd spacing: blocks at every alignment
+        buf = bytearray(pos + 16)
+        for o, b in zip(off, blocks):
+            buf[o:o + len(b)] = b
+        words = sum(len(b) << args[4] for b in blocks)
+        cand = np.zeros(max(1, words), dtype=np.uint32)
+        rc = L.cand_host(bytes(buf), (C.c_uint64 * len(blocks))(*off), (C.c_uint32 * len(blocks))(*[len(b) for b in blocks]), len(blocks),
+                         (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), cand.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        out, w = [], 0
+        for b in blocks:
+            out.append(cand[w:w + (len(b) << args[4])]); w += len(b) << args[4]
+        return out
+    return run
+
+
+@pytest.mark.parametrize("args", ARGS, ids=lambda a: ",".join(map(str, a)))
+def test_device_source_of_the_candidate_kernels_on_the_host(cand_host, args):
+    names = list(INPUTS)
+    got = cand_host([INPUTS[k] for k in names], args)           # all inputs as ONE batch of blocks
+    for k, g in zip(names, got):
+        want = orc.lz77_cand(INPUTS[k], args)
+        bad = np.nonzero(g != want)[0]
+        assert bad.size == 0, (k, int(bad[0]) >> args[4], int(bad[0]) & ((1 << args[4]) - 1), int(g[bad[0]]), int(want[bad[0]]), bad.size)
+    one, = cand_host([INPUTS["mixed"]], args)                    # and a block on its own
+    assert np.array_equal(one, orc.lz77_cand(INPUTS["mixed"], args))

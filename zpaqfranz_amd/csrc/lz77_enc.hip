@@ -39,12 +39,14 @@ constexpr u32 kNoCand = 0xffffffffu;
 constexpr u32 kSegMin = 1u << 20;            // smallest speculation segment (more segments do not help: the parse is bound by random-access throughput)
 constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB blocks at most)
 
-struct LzCfg {
-  const u8* in;
-  u32 n;
-  u32 minMatch, bucket, htbits, checkbits, shift1, rb;
-  u32 upd_limit;   // positions < upd_limit are inserted (i + minMatchBoth < n)
-};
+#define ZPQ_CAND_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define ZPQ_CAND_DEV __device__ __forceinline__
+#define ZPQ_CAND_TID ((u32)threadIdx.x)
+#define ZPQ_CAND_BID_X ((u32)blockIdx.x)
+#define ZPQ_CAND_BID_Y ((u32)blockIdx.y)
+#define ZPQ_CAND_GDIM_X ((u32)gridDim.x)
+#define ZPQ_CAND_GLOBAL __attribute__((address_space(1)))
+#include "lz77_cand.inc"      // LzCfg, CandJob, lz77_cand_keys_kernel, lz77_cand_sweep_kernel (also compiled for the host by tests/cpp/cand_host.cpp)
 
 // per (block, segment)
 struct LzSegDev {
@@ -546,81 +548,7 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
 // group then form a run in position order, and ONE lane sweeps a run carrying the group's bucket+1 table words in
 // registers: write them out as cand[q] (probe order ht[h1 ^ k]), then apply q's own insert.  A run is a serial chain
 // (the most frequent 5-gram of a 16 MiB block of the stand-in: ~150 k entries), the runs are independent.
-struct CandJob { LzCfg c; u64 pos0; u32* cand; u32 lb, pad; };     // pos0: index of the block's first position in the batch
-
-// key = block << 48 | (h1 >> lb) << 26 | q (lb = log2(bucket + 1), q < 2^26, h1 >> lb < 2^22); val = (h1 & bucket) << 8 | in[q+3]
-__global__ __launch_bounds__(256) void lz77_cand_keys_kernel(const CandJob* __restrict__ jobs, u64* __restrict__ keys, u32* __restrict__ vals) {
-  const CandJob J = jobs[blockIdx.y];
-  const LzCfg& C = J.c;
-  g_cu8* in = (g_cu8*)C.in;
-  for (u32 q = blockIdx.x * 256u + threadIdx.x; q < C.n; q += gridDim.x * 256u) {
-    const u64 qb = load8(in + q);
-    u32 h;
-    if (C.minMatch <= 8 && q >= C.minMatch && q <= C.upd_limit) h = hash_fast(C, qb);
-    else h = hash_at(C, q);                                   // the first minMatch positions, and the frozen hash behind upd_limit
-    const u32 b3 = q + 3 < C.n ? (u32)((qb >> 24) & 255u) : 0u;
-    keys[J.pos0 + q] = ((u64)blockIdx.y << 48) | ((u64)(h >> J.lb) << 26) | (u64)q;
-    vals[J.pos0 + q] = ((h & C.bucket) << 8) | b3;
-  }
-}
-
-// One lane per sorted entry; the lane that holds the first entry of a run sweeps the run, the others leave.
-template <int NB>
-__global__ __launch_bounds__(64) void lz77_cand_sweep_kernel(const CandJob* __restrict__ jobs, const u64* __restrict__ keys,
-                                                             const u32* __restrict__ vals, u64 total) {
-  const u64 i0 = (u64)blockIdx.x * 64u + threadIdx.x;
-  if (i0 >= total) return;
-  const u64 g0 = keys[i0] >> 26;
-  if (i0 && (keys[i0 - 1] >> 26) == g0) return;
-  const CandJob J = jobs[(u32)(g0 >> 22)];
-  const u32 mask = (1u << J.c.checkbits) - 1u;
-  u32 v[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) v[j] = 0;
-  // four entries per round, their loads issued together (a run is one chain of dependent rounds: the hottest group of a
-  // 16 MiB block holds ~150 k entries)
-  bool more = true;
-  for (u64 i = i0; more && i < total; i += 4) {
-    u64 kk[4]; u32 vv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const u64 x = i + t < total ? i + t : total - 1;
-      kk[t] = keys[x]; vv[t] = vals[x];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (!more || i + t >= total || (kk[t] >> 26) != g0) { more = false; continue; }
-      const u32 q = (u32)(kk[t] & ((1u << 26) - 1u));
-      const u32 val = vv[t];
-      const u32 hb = (val >> 8) & J.c.bucket, b3 = val & 255u;
-      // cand[q][k] = v[hb ^ k]: butterfly on the bits of hb
-      u32 o[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) o[j] = v[j];
-#pragma unroll
-      for (int bit = 1; bit < NB; bit <<= 1) {
-        const bool sw = (hb & (u32)bit) != 0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (!(j & bit)) {
-            const u32 a = o[j], b = o[j | bit];
-            o[j] = sw ? b : a;
-            o[j | bit] = sw ? a : b;
-          }
-      }
-      u32* dst = J.cand + (size_t)q * NB;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) dst[j] = o[j];
-      // q's own insert: ht[h1 ^ ih] = (q << checkbits) | (in[q+3] & mask)   (:6435-6440)
-      if (q < J.c.upd_limit) {
-        const u32 slot = hb ^ (((q * 1234547u) >> 19) & J.c.bucket);
-        const u32 nv = (q << J.c.checkbits) | (b3 & mask);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) v[j] = slot == (u32)j ? nv : v[j];
-      }
-    }
-  }
-}
+// (CandJob and the two kernels: lz77_cand.inc)
 
 // ---- speculative parse: one wave per segment ------------------------------------------------------------
 template <int NB, bool CAND = false>
