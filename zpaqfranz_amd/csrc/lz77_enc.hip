@@ -1102,10 +1102,10 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       dim3 gj((unsigned)rng[nb].jn), blk(64);
       const u32* jl = d_lists + rng[nb].joff;
       switch (nb) {
-        case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-        case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-        case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-        default: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+        case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<1, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+        case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<2, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+        case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<4, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+        default: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<8, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
       }
       ZPQ_HIP(ctx, hipGetLastError());
     }
@@ -1135,18 +1135,18 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       }
     }
     switch (nb) {
-      case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1, true>, gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1, true>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-      case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2, true>, gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2, true>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-      case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4, true>, gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4, true>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-      default: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8, true>, gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL);
-               if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8, true>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-               if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8, true>, gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+      case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<1, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<1, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<1, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+      case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<2, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<2, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<2, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+      case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<4, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<4, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<4, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+      default: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<8, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL);
+               if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<8, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
+               if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<8, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
     }
     ZPQ_HIP(ctx, hipGetLastError());
   }
