@@ -1,0 +1,68 @@
+"""lz_walk -- the heart of the LZ77 hash-table parse (zpaqfranz_amd/csrc/lz77_enc.hip) -- run on the CPU: tests/cpp/walk_emu.cpp
+compiles THE DEVICE SOURCE for the host and runs it as one emulated wave (64 lanes as fibres in lockstep, the wave-level
+operations as rendezvous).  Its tokens must be the oracle's, both in the table form the GPU runs by default and in the
+experimental candidate-table form (ZPQ_LZ_CAND).  Needs the ROCm clang++ (address spaces, ext vectors) as a host compiler."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import datagen
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ not found")
+
+
+@pytest.fixture(scope="module")
+def walk(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("walk") / "walk_emu.so")
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.walk_emu.restype = C.c_long
+    L.walk_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+
+    def run(b, args, cand):
+        n = len(b)
+        words = (n << args[4]) if cand else (1 << args[5])
+        raw = np.zeros(words + 16, dtype=np.uint32)
+        off = (-(raw.ctypes.data // 4)) % 4                      # 16-byte aligned view
+        tab = raw[off:off + words]
+        if cand:
+            tab[:] = orc.lz77_cand(b, args)
+        cap = n // 4 + 16
+        tok = np.zeros(3 * cap, dtype=np.uint32)
+        err = C.create_string_buffer(256)
+        r = L.walk_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, tok.ctypes.data, cap, err, 256)
+        assert r >= 0, err.value.decode()
+        return [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
+    return run
+
+
+def _inputs():
+    rng = np.random.default_rng(9)
+    unit = rng.integers(0, 256, size=9000, dtype=np.uint8).tobytes()
+    return {
+        "text": datagen.text_like(24000, 1),
+        "binary": datagen.binary_like(16000, 2),
+        "mixed": datagen.mixed(20000, 3),
+        "runs": bytes(4000) + b"ab" * 2500 + datagen.random_bytes(600, 4),            # very long matches: whole-wave compares
+        "long": unit + unit + unit[:100] + datagen.random_bytes(6000, 5) + unit,       # capped candidates, a literal run past 4096
+        "tiny": b"abcabcabcabc", "one": b"x", "empty": b"", "window": datagen.text_like(64, 7), "window+1": datagen.text_like(65, 8),
+    }
+
+
+ARGS = [[4, 1, 5, 0, 3, 18], [0, 1, 4, 0, 1, 15], [4, 1, 4, 0, 2, 16], [0, 1, 6, 0, 3, 17], [4, 1, 5, 0, 0, 16], [5, 1, 4, 0, 2, 18]]
+
+
+@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
+@pytest.mark.parametrize("args", ARGS, ids=lambda a: ",".join(map(str, a)))
+def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(walk, args, cand):
+    for name, b in _inputs().items():
+        want = orc.lz77_encode(b, args, trace=True)[1]
+        got = walk(b, args, cand)
+        assert got == want, (name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))

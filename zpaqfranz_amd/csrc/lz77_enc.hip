@@ -23,12 +23,17 @@
 //    bytes are OR-ed into the zeroed output in parallel (LSB-first, :6171-6186).
 // Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
 // n bytes: n read + r*n written (r = LZ ratio); the hash tables are implementation traffic.
+// tests/cpp/walk_emu.cpp compiles this file up to the end of lz_walk for the HOST (ZPQ_EMU_WALK_ONLY: 64 lanes as
+// fibres in lockstep, the wave intrinsics emulated) and checks the walk's tokens against the oracle on the CPU.
+#ifndef ZPQ_EMU_WALK_ONLY
 #include <algorithm>
 #include <stdlib.h>
 
 #include <rocprim/device/device_radix_sort.hpp>     // (only the experimental candidate-table path sorts)
 
 #include "zpq_internal.h"
+#define ZPQ_WAIT_VMCNT0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 namespace {
 
@@ -502,7 +507,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
     // ---- insert this window's positions (latest writer of a slot wins) --------------------------
     if constexpr (!CAND) {
       if (ins && !superseded) ht[slot] = val;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ZPQ_WAIT_VMCNT0;
     }
     LZ_T(5);
   }
@@ -511,6 +516,10 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 #endif
   return -1;
 }
+
+#ifdef ZPQ_EMU_WALK_ONLY
+}  // namespace (host emulation: nothing behind lz_walk is compiled)
+#else
 
 // ---- table state at every segment start --------------------------------------------------------------
 struct CopyJob { const u32* src; u32* dst; u32 words; };   // src == nullptr: zero fill
@@ -1304,3 +1313,4 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
   }
   return ZPQ_OK;
 }
+#endif  // ZPQ_EMU_WALK_ONLY
