@@ -79,9 +79,10 @@ const char* run_wave(void (*body)()) {
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define __shared__ static
-static inline int lane_id() { return emu::g_lane; }
 struct EmuDim { u32 x, y, z; };
 static EmuDim threadIdx, blockIdx, gridDim;
+static bool g_in_wave = false;
+static inline int lane_id() { return g_in_wave ? emu::g_lane : (int)(threadIdx.x & 63u); }
 static inline unsigned long long emu_ballot(bool p, int op) {
   const u64* a = emu::rendezvous(p ? 1 : 0, op);
   unsigned long long m = 0;
@@ -105,6 +106,13 @@ template <class T> static inline T emu_shfl(T v, int src, int op) {
 #define __ATOMIC_RELAXED_HIP 0
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 0
 #define ZPQ_WAIT_VMCNT0 ((void)emu::rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
+// serial stand-ins for the global atomics of the thread-independent kernels (one thread runs after the other)
+template <class T> static inline T emu_atomic_max(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+#define atomicMax(p, v) emu_atomic_max((p), (v))
+// zpq_internal.h: the plain-launch half of the cooperative placement helpers (tab == nullptr)
+struct zpq_place { u32* queue; u32* tab; u32 n; u32 polite; };
+static inline u32 zpq_place_begin(const zpq_place& P, u32& key, bool& polite) { key = 0; polite = true; return blockIdx.x < P.n ? blockIdx.x : 0xffffffffu; }
+static inline u32 zpq_place_next(const zpq_place&, u32, bool) { return 0xffffffffu; }
 struct zpq_lzjob_dev {                       // (zpq_internal.h; only named by a typedef in front of lz_walk)
   const u8* in; u32 n; u32 rb; u32 nseg, seg0; u32* tok_pos; u32* tok_len; u32* tok_off; u32* tok_bit; u32 tok_cap; u32* result; u8* out; u32 out_cap; u32* plan;
 };
@@ -144,7 +152,138 @@ extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table,
     case 2: body = cand ? walk_body<4, true> : walk_body<4, false>; break;
     default: body = cand ? walk_body<8, true> : walk_body<8, false>; break;
   }
+  g_in_wave = true;
   const char* e = emu::run_wave(body);
+  g_in_wave = false;
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   return (long)g_w.ntok;
+}
+
+// ---- the segment speculation of one block, as encode_batch() lays it out -----------------------------------------------------
+// table states (copy + scatter kernels) or a candidate table, then lz77_spec_kernel per segment, lz77_seam_kernel per
+// segment, lz77_stitch_kernel, lz77_move_tokens_kernel: the kernels themselves, 64-thread ones as emulated waves, the
+// thread-independent ones thread by thread.
+namespace {
+struct SpecRun { const LzSegDev* segs; const u32* list; const LzJobDev* jobs; int nb; bool cand; u32 nseg; };
+SpecRun g_s;
+template <int NB, bool CAND> void spec_body() { lz77_spec_kernel<NB, CAND>(g_s.segs, g_s.list, zpq_place{nullptr, nullptr, g_s.nseg, 0}); }
+template <int NB, bool CAND> void seam_body() { lz77_seam_kernel<NB, CAND>(g_s.segs, g_s.list); }
+template <int NB, bool CAND> void stitch_body() { lz77_stitch_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
+typedef void (*Body)();
+template <int NB> void bodies(bool cand, Body& sp, Body& se, Body& st) {
+  if (cand) { sp = spec_body<NB, true>; se = seam_body<NB, true>; st = stitch_body<NB, true>; }
+  else { sp = spec_body<NB, false>; se = seam_body<NB, false>; st = stitch_body<NB, false>; }
+}
+const char* wave(Body b, u32 bx) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_wave(b); g_in_wave = false; return e; }
+template <class F> void serial(u32 gx, u32 gy, u32 threads, F&& f) {
+  gridDim = {gx, gy, 1};
+  for (u32 by = 0; by < gy; ++by) for (u32 bx = 0; bx < gx; ++bx) for (u32 t = 0; t < threads; ++t) { blockIdx = {bx, by, 0}; threadIdx = {t, 0, 0}; f(); }
+}
+}  // namespace
+
+// cand_table: null (table states are built here, as the copy / scatter kernels build them) or the block's candidate table.
+// tok: 3 * cap words (pos | len | off) of the final list.  Returns the token count, < 0 on an emulation error, -2 on overflow.
+extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_bytes, u32* cand_table, u32* tok, u32 cap, char* err, u32 err_cap) {
+  LzCfg c;
+  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
+  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
+  const u32 mmb = args[2] + 4;
+  c.upd_limit = n > mmb ? n - mmb : 0;
+  const bool cand = cand_table != nullptr;
+  const u32 nseg = std::max<u32>(1, (u32)(((u64)n + seg_bytes - 1) / seg_bytes));
+  const size_t words = (size_t)1 << args[5];
+  const u32 mmt = (u32)(args[2] >= 4 ? args[2] : 4);
+  std::vector<u32> tables;                      // work[0..nseg-1], pristine[1..nseg-1]
+  if (!cand) tables.assign(words * (2 * (size_t)nseg - 1) + 16, 0);
+  u32* tab0 = cand ? cand_table : (u32*)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
+  u32* prist0 = tab0 + words * nseg - words;
+  const u32 fcap = n / mmt + 3;
+  std::vector<u32> ftok((size_t)fcap * 4, 0), state((size_t)nseg * 12, 0), plan((size_t)nseg * 8, 0), result(4, 0);
+  std::vector<std::vector<u32>> lists(nseg * 2);
+  std::vector<LzSegDev> segs(nseg);
+  LzJobDev J;
+  J.in = in; J.n = n; J.rb = c.rb; J.nseg = nseg; J.seg0 = 0;
+  J.tok_pos = ftok.data(); J.tok_len = J.tok_pos + fcap; J.tok_off = J.tok_len + fcap; J.tok_bit = J.tok_off + fcap; J.tok_cap = fcap - 1;
+  J.result = result.data(); J.out = nullptr; J.out_cap = 0; J.plan = plan.data();
+  for (u32 k = 0; k < nseg; ++k) {
+    LzSegDev& S = segs[k];
+    S.c = c; S.x0 = k * seg_bytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + seg_bytes, n);
+    S.work = cand ? tab0 : tab0 + words * k;
+    S.pristine = cand ? tab0 : k ? prist0 + words * k : nullptr;
+    const u32 scap = (S.x1 - S.x0) / mmt + 3;
+    lists[2 * k].assign((size_t)scap * 3, 0);
+    S.tpos = lists[2 * k].data(); S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap - 1;
+    if (k) { lists[2 * k + 1].assign((size_t)scap * 3, 0); S.qpos = lists[2 * k + 1].data(); S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; }
+    else { S.qpos = S.tpos; S.qlen = S.tlen; S.qoff = S.toff; }
+    S.state = state.data() + 12 * (size_t)k; S.seam = S.state + 4;
+  }
+  if (!cand) {            // table states: pristine[k] = pristine[k-1] + inserts of segment k-1; work[k] = pristine[k]
+    for (u32 k = 1; k < nseg; ++k) {
+      CopyJob cj{k == 1 ? nullptr : prist0 + words * (k - 1), segs[k].pristine, (u32)words};
+      serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cj); });
+      ScatterJob sj{c, (k - 1) * seg_bytes, k * seg_bytes, segs[k].pristine};
+      serial(8, 1, 256, [&] { lz77_table_scatter_kernel(&sj); });
+      CopyJob cw{segs[k].pristine, segs[k].work, (u32)words};
+      serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cw); });
+    }
+  }
+  std::vector<u32> seglist(nseg), joblist(1, 0);
+  for (u32 k = 0; k < nseg; ++k) seglist[k] = k;
+  g_s = SpecRun{segs.data(), seglist.data(), &J, args[4], cand, nseg};
+  Body sp = nullptr, se = nullptr, st = nullptr;
+  switch (args[4]) {
+    case 0: bodies<1>(cand, sp, se, st); break;
+    case 1: bodies<2>(cand, sp, se, st); break;
+    case 2: bodies<4>(cand, sp, se, st); break;
+    default: bodies<8>(cand, sp, se, st); break;
+  }
+  const char* e = nullptr;
+  gridDim = {nseg, 1, 1};
+  for (u32 k = 0; k < nseg && !e; ++k) e = wave(sp, k);
+  for (u32 k = 0; k < nseg && !e; ++k) e = wave(se, k);
+  g_s.list = joblist.data();
+  gridDim = {1, 1, 1};
+  if (!e) e = wave(st, 0);
+  if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+  std::vector<u32> segjob(nseg, 0);
+  serial(4, nseg * 2, 256, [&] { lz77_move_tokens_kernel(&J, segs.data(), segjob.data()); });
+  if (result[2]) return -2;
+  const u32 nt = result[0];
+  if (nt > cap) return -2;
+  for (u32 i = 0; i < nt; ++i) { tok[i] = J.tok_pos[i]; tok[cap + i] = J.tok_len[i]; tok[2 * (size_t)cap + i] = J.tok_off[i]; }
+  return (long)nt;
+}
+
+// ---- one wave per block, parsing and emitting in one go (lz77_direct_kernel) -------------------------------------------------
+namespace {
+template <int NB, bool CAND> void direct_body() { lz77_direct_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
+}
+// out: the code stream (out_cap bytes, zeroed by the caller).  Returns its length, < 0 on an emulation error, -2 on overflow.
+extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* table, int cand, u8* out, u32 out_cap, char* err, u32 err_cap) {
+  LzCfg c;
+  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
+  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
+  const u32 mmb = args[2] + 4;
+  c.upd_limit = n > mmb ? n - mmb : 0;
+  LzSegDev S;
+  memset(&S, 0, sizeof S);
+  S.c = c; S.x0 = 0; S.x1 = n; S.work = table; S.pristine = table;
+  u32 result[4] = {0, 0, 0, 0};
+  LzJobDev J;
+  memset(&J, 0, sizeof J);
+  J.in = in; J.n = n; J.rb = c.rb; J.nseg = 1; J.seg0 = 0; J.result = result; J.out = out; J.out_cap = out_cap;
+  u32 list0 = 0;
+  g_s = SpecRun{&S, &list0, &J, args[4], cand != 0, 1};
+  Body b = nullptr;
+  switch (args[4]) {
+    case 0: b = cand ? direct_body<1, true> : direct_body<1, false>; break;
+    case 1: b = cand ? direct_body<2, true> : direct_body<2, false>; break;
+    case 2: b = cand ? direct_body<4, true> : direct_body<4, false>; break;
+    default: b = cand ? direct_body<8, true> : direct_body<8, false>; break;
+  }
+  gridDim = {1, 1, 1};
+  const char* e = wave(b, 0);
+  if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+  if (result[2]) return -2;
+  return (long)result[1];
 }

@@ -66,3 +66,75 @@ def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(walk, args, cand)
         want = orc.lz77_encode(b, args, trace=True)[1]
         got = walk(b, args, cand)
         assert got == want, (name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole segment speculation of a block, kernel by kernel as encode_batch() launches them: table states (the copy and
+# scatter kernels) or a candidate table, lz77_spec_kernel and lz77_seam_kernel per segment, lz77_stitch_kernel,
+# lz77_move_tokens_kernel.  Segments of a few KiB put seams, swallowed segments and re-walks into small inputs.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def spec(walk, tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("spec") / "walk_emu.so")
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.spec_emu.restype = C.c_long
+    L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+
+    def run(b, args, seg, cand):
+        n = len(b)
+        ptr = None
+        if cand:
+            t = orc.lz77_cand(b, args)
+            raw = np.zeros(len(t) + 16, dtype=np.uint32)
+            off = (-(raw.ctypes.data // 4)) % 4
+            tab = raw[off:off + len(t)]
+            tab[:] = t
+            ptr = tab.ctypes.data
+        cap = n // 4 + 16
+        tok = np.zeros(3 * cap, dtype=np.uint32)
+        err = C.create_string_buffer(256)
+        r = L.spec_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), seg, ptr, tok.ctypes.data, cap, err, 256)
+        assert r >= 0, (r, err.value.decode())
+        return [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
+    return run
+
+
+@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
+@pytest.mark.parametrize("args,seg", [([4, 1, 5, 0, 3, 16], 4096), ([4, 1, 5, 0, 3, 16], 16384), ([0, 1, 4, 0, 1, 15], 4096), ([4, 1, 4, 0, 2, 16], 8192),
+                                      ([0, 1, 6, 0, 3, 17], 4096), ([4, 1, 5, 0, 0, 16], 8192)], ids=lambda a: ",".join(map(str, a)) if isinstance(a, list) else str(a))
+def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(spec, args, seg, cand):
+    inputs = _inputs()
+    inputs["seams"] = (datagen.text_like(5000, 11) * 3)[:14000] + bytes(9000) + datagen.text_like(7000, 12)   # matches across several segment edges, a swallowed segment
+    for name, b in inputs.items():
+        want = orc.lz77_encode(b, args, trace=True)[1]
+        got = spec(b, args, seg, cand)
+        assert got == want, (name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+
+
+@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
+@pytest.mark.parametrize("args", [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [5, 1, 4, 0, 2, 18], [6, 1, 6, 0, 3, 17]], ids=lambda a: ",".join(map(str, a)))
+def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_factory, args, cand):
+    """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
+    match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
+    so = str(tmp_path_factory.mktemp("direct") / "walk_emu.so")
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.direct_emu.restype = C.c_long
+    L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    for name, b in _inputs().items():
+        n = len(b)
+        words = (n << args[4]) if cand else (1 << args[5])
+        raw = np.zeros(words + 16, dtype=np.uint32)
+        off = (-(raw.ctypes.data // 4)) % 4
+        tab = raw[off:off + words]
+        if cand:
+            tab[:] = orc.lz77_cand(b, args)
+        cap = n + n // 8 + 1024
+        out = np.zeros(cap, dtype=np.uint8)
+        err = C.create_string_buffer(256)
+        r = L.direct_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, out.ctypes.data, cap, err, 256)
+        assert r >= 0, (name, r, err.value.decode())
+        assert bytes(out[:r]) == orc.lz77_encode(b, args), name

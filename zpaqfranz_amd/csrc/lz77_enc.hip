@@ -23,8 +23,8 @@
 //    bytes are OR-ed into the zeroed output in parallel (LSB-first, :6171-6186).
 // Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
 // n bytes: n read + r*n written (r = LZ ratio); the hash tables are implementation traffic.
-// tests/cpp/walk_emu.cpp compiles this file up to the end of lz_walk for the HOST (ZPQ_EMU_WALK_ONLY: 64 lanes as
-// fibres in lockstep, the wave intrinsics emulated) and checks the walk's tokens against the oracle on the CPU.
+// tests/cpp/walk_emu.cpp compiles this file up to the token-move kernel for the HOST (ZPQ_EMU_WALK_ONLY: 64 lanes as
+// fibres in lockstep, the wave intrinsics emulated) and checks the walk and the segment speculation against the oracle on the CPU.
 #ifndef ZPQ_EMU_WALK_ONLY
 #include <algorithm>
 #include <stdlib.h>
@@ -517,9 +517,6 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
   return -1;
 }
 
-#ifdef ZPQ_EMU_WALK_ONLY
-}  // namespace (host emulation: nothing behind lz_walk is compiled)
-#else
 
 // ---- table state at every segment start --------------------------------------------------------------
 struct CopyJob { const u32* src; u32* dst; u32 words; };   // src == nullptr: zero fill
@@ -715,6 +712,9 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
+#ifdef ZPQ_EMU_WALK_ONLY
+}  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled)
+#else
 // ---- bit costs ---------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lit_run_header_bits(u32 len) { return 3u + 2u * (u32)(lg32(len) - 1); }  // :6464-6476
 __device__ __forceinline__ u64 lit_gap_bits(u32 g) {
