@@ -17,12 +17,22 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ not found")
 
 
+_SO = [None]
+
+
+def _lib(tmp_path_factory):
+    """walk_emu.so, built once per test process"""
+    if _SO[0] is None:
+        so = str(tmp_path_factory.mktemp("walk_emu") / "walk_emu.so")
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
+                               os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
+        _SO[0] = C.CDLL(so)
+    return _SO[0]
+
+
 @pytest.fixture(scope="module")
 def walk(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("walk") / "walk_emu.so")
-    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
-    L = C.CDLL(so)
+    L = _lib(tmp_path_factory)
     L.walk_emu.restype = C.c_long
     L.walk_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
 
@@ -75,10 +85,7 @@ def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(walk, args, cand)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def spec(walk, tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("spec") / "walk_emu.so")
-    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
-    L = C.CDLL(so)
+    L = _lib(tmp_path_factory)
     L.spec_emu.restype = C.c_long
     L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
 
@@ -118,10 +125,7 @@ def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(spec, ar
 def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_factory, args, cand):
     """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
     match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
-    so = str(tmp_path_factory.mktemp("direct") / "walk_emu.so")
-    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
-                           os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
-    L = C.CDLL(so)
+    L = _lib(tmp_path_factory)
     L.direct_emu.restype = C.c_long
     L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     for name, b in _inputs().items():
