@@ -24,6 +24,7 @@ thread_local Dim g_tid, g_bid, g_gdim;
 #define ZPQ_CAND_BID_Y (g_bid.y)
 #define ZPQ_CAND_GDIM_X (g_gdim.x)
 #define ZPQ_CAND_GLOBAL
+#define ZPQ_CAND_ATOMIC_INC(p) ((*(p))++)
 #define __restrict__
 #include "lz77_cand.inc"
 
@@ -62,10 +63,10 @@ extern "C" int cand_host(const u8* in, const u64* in_off, const u32* n, u32 nblo
   for (u64 i = 0; i < total; ++i) { k1[i] = k0[idx[i]]; v1[i] = v0[idx[i]]; }
   const u32 grid = (u32)((total + 63) / 64);
   switch (args[4]) {
-    case 0: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<1>(jobs.data(), k1.data(), v1.data(), total); }); break;
-    case 1: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<2>(jobs.data(), k1.data(), v1.data(), total); }); break;
-    case 2: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<4>(jobs.data(), k1.data(), v1.data(), total); }); break;
-    default: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<8>(jobs.data(), k1.data(), v1.data(), total); }); break;
+    case 0: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<1>(jobs.data(), k1.data(), v1.data(), total, nullptr, 0, 0); }); break;
+    case 1: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<2>(jobs.data(), k1.data(), v1.data(), total, nullptr, 0, 0); }); break;
+    case 2: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<4>(jobs.data(), k1.data(), v1.data(), total, nullptr, 0, 0); }); break;
+    default: launch(grid, 1, 64, [&] { lz77_cand_sweep_kernel<8>(jobs.data(), k1.data(), v1.data(), total, nullptr, 0, 0); }); break;
   }
   return 0;
 }

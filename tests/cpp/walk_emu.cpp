@@ -98,6 +98,7 @@ template <class T> static inline T emu_shfl(T v, int src, int op) {
 #define __ballot(p) emu_ballot((p), __LINE__)
 #define __shfl(v, src) emu_shfl((v), (int)(src), __LINE__)
 #define __shfl_xor(v, m) emu_shfl((v), lane_id() ^ (int)(m), __LINE__)
+#define __shfl_up(v, d) emu_shfl((v), lane_id() >= (int)(d) ? lane_id() - (int)(d) : lane_id(), __LINE__)
 #define __builtin_amdgcn_readlane(v, l) emu_shfl((v), (int)(l), __LINE__)
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0, __LINE__)
 #define __builtin_amdgcn_wave_barrier() ((void)emu::rendezvous(0, __LINE__))
@@ -109,6 +110,8 @@ template <class T> static inline T emu_shfl(T v, int src, int op) {
 // serial stand-ins for the global atomics of the thread-independent kernels (one thread runs after the other)
 template <class T> static inline T emu_atomic_max(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 #define atomicMax(p, v) emu_atomic_max((p), (v))
+template <class T> static inline T emu_atomic_add(T* p, T v) { const T o = *p; *p = o + v; return o; }
+#define atomicAdd(p, v) emu_atomic_add((p), (v))
 // zpq_internal.h: the plain-launch half of the cooperative placement helpers (tab == nullptr)
 struct zpq_place { u32* queue; u32* tab; u32 n; u32 polite; };
 static inline u32 zpq_place_begin(const zpq_place& P, u32& key, bool& polite) { key = 0; polite = true; return blockIdx.x < P.n ? blockIdx.x : 0xffffffffu; }
@@ -286,4 +289,46 @@ extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* tabl
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   if (result[2]) return -2;
   return (long)result[1];
+}
+
+// ---- candidate table with the long-run hand-off: keys (thread-serial), a stable sort, sweep (thread-serial, runs longer than
+// klong queued), lz77_cand_sweep_long_kernel on emulated waves -- as cand_build() launches them ---------------------------
+namespace {
+struct LongRun { const CandJob* jobs; const u64* keys; const u32* vals; u64 total; const u32* q; u32 cap; };
+LongRun g_l;
+template <int NB> void long_body() { lz77_cand_sweep_long_kernel<NB>(g_l.jobs, g_l.keys, g_l.vals, g_l.total, g_l.q, g_l.cap); }
+}
+extern "C" long cand_long_emu(const u8* in, u32 n, const int32_t args[9], u32 klong, u32* cand, u32* nlong_out, char* err, u32 err_cap) {
+  CandJob J;
+  LzCfg& c = J.c;
+  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
+  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
+  const u32 mmb = args[2] + 4;
+  c.upd_limit = n > mmb ? n - mmb : 0;
+  J.pos0 = 0; J.cand = cand; J.lb = (u32)args[4]; J.pad = 0;
+  if (!n) return 0;
+  std::vector<u64> k0(n), k1(n);
+  std::vector<u32> v0(n), v1(n);
+  serial(5, 1, 256, [&] { lz77_cand_keys_kernel(&J, k0.data(), v0.data()); });
+  std::vector<u32> idx(n);
+  for (u32 i = 0; i < n; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return k0[a] < k0[b]; });
+  for (u32 i = 0; i < n; ++i) { k1[i] = k0[idx[i]]; v1[i] = v0[idx[i]]; }
+  const u32 cap = klong ? n / klong + 1 : 0;
+  std::vector<u32> q(2 + 2 * (size_t)cap + 2, 0);
+  const u32 grid = (n + 63) / 64;
+#define EMU_SWEEP(NBV) serial(grid, 1, 64, [&] { lz77_cand_sweep_kernel<NBV>(&J, k1.data(), v1.data(), (u64)n, q.data(), cap, klong); })
+  switch (args[4]) { case 0: EMU_SWEEP(1); break; case 1: EMU_SWEEP(2); break; case 2: EMU_SWEEP(4); break; default: EMU_SWEEP(8); break; }
+#undef EMU_SWEEP
+  if (nlong_out) *nlong_out = q[0];
+  g_l = LongRun{&J, k1.data(), v1.data(), (u64)n, q.data(), cap};
+  Body b = nullptr;
+  switch (args[4]) { case 0: b = long_body<1>; break; case 1: b = long_body<2>; break; case 2: b = long_body<4>; break; default: b = long_body<8>; break; }
+  const u32 waves = std::min<u32>(cap, 3);                   // fewer waves than runs: the stride loop is exercised too
+  gridDim = {waves, 1, 1};
+  for (u32 w = 0; w < waves; ++w) {
+    const char* e = wave(b, w);
+    if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+  }
+  return (long)n;
 }

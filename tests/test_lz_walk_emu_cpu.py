@@ -142,3 +142,28 @@ def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_fa
         r = L.direct_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, out.ctypes.data, cap, err, 256)
         assert r >= 0, (name, r, err.value.decode())
         assert bytes(out[:r]) == orc.lz77_encode(b, args), name
+
+
+@pytest.mark.parametrize("args", [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [4, 1, 5, 0, 0, 16], [4, 1, 4, 0, 2, 16]], ids=lambda a: ",".join(map(str, a)))
+def test_long_runs_swept_by_a_whole_wave_give_the_sequential_table(tmp_path_factory, args):
+    """Candidate tables with the long-run hand-off: keys and the sweep thread by thread, runs longer than klong queued and
+    swept by lz77_cand_sweep_long_kernel on emulated waves (pieces per lane, 'later write wins per slot' scanned over the
+    lanes, second sweep writing).  Small klong values put hundreds of runs through the wave form."""
+    L = _lib(tmp_path_factory)
+    L.cand_long_emu.restype = C.c_long
+    L.cand_long_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+    inputs = {"text": datagen.text_like(50000, 1), "runs": bytes(9000) + b"ab" * 6000 + datagen.random_bytes(500, 4), "mixed": datagen.mixed(30000, 3),
+              "tiny": b"abcabcabc", "one": b"x"}
+    seen_long = 0
+    for name, b in inputs.items():
+        want = orc.lz77_cand(b, args)
+        for klong in (0, 16, 100, 1000):
+            n = len(b)
+            cand = np.zeros(max(1, n << args[4]), dtype=np.uint32)
+            nl = C.c_uint32(0)
+            err = C.create_string_buffer(256)
+            r = L.cand_long_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), klong, cand.ctypes.data, C.byref(nl), err, 256)
+            assert r >= 0, (name, klong, err.value.decode())
+            assert np.array_equal(cand[: len(want)], want), (name, klong, nl.value)
+            seen_long += nl.value
+    assert seen_long > 300

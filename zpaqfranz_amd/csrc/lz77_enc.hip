@@ -51,6 +51,7 @@ constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB block
 #define ZPQ_CAND_BID_Y ((u32)blockIdx.y)
 #define ZPQ_CAND_GDIM_X ((u32)gridDim.x)
 #define ZPQ_CAND_GLOBAL __attribute__((address_space(1)))
+#define ZPQ_CAND_ATOMIC_INC(p) atomicAdd((p), 1u)
 #include "lz77_cand.inc"      // LzCfg, CandJob, lz77_cand_keys_kernel, lz77_cand_sweep_kernel (also compiled for the host by tests/cpp/cand_host.cpp)
 
 // per (block, segment)
@@ -556,6 +557,56 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
 // (the most frequent 5-gram of a 16 MiB block of the stand-in: ~150 k entries), the runs are independent.
 // (CandJob and the two kernels: lz77_cand.inc)
 
+// A long run (lz77_cand_sweep_kernel handed its start over) swept by a whole wave: the run is cut into 64 pieces; every
+// lane first sweeps its piece without writing, to learn which slots the piece overwrites and with what (the effect of a
+// piece on the group's words is "later write wins per slot", which composes); an exclusive scan over the lanes gives
+// every piece the words it starts from; then every lane sweeps its piece again, writing.
+template <int NB>
+__global__ __launch_bounds__(64) void lz77_cand_sweep_long_kernel(const CandJob* __restrict__ jobs, const u64* __restrict__ keys,
+                                                                  const u32* __restrict__ vals, u64 total, const u32* __restrict__ longq, u32 long_cap) {
+  const u32 lane = (u32)lane_id();
+  const u32 nlong = longq[0] < long_cap ? longq[0] : long_cap;
+  for (u32 r = blockIdx.x; r < nlong; r += gridDim.x) {
+    const u64 i0 = (u64)longq[2 + 2 * (size_t)r] | ((u64)longq[3 + 2 * (size_t)r] << 32);
+    const u64 g0 = keys[i0] >> 26;
+    // end of the run: first index in (i0, total] whose group differs (every lane does the same binary search)
+    u64 lo = i0, hi = total;                       // keys[lo] is in the run, hi is not (or is the end)
+    while (hi - lo > 1) {
+      const u64 mid = lo + ((hi - lo) >> 1);
+      if ((keys[mid] >> 26) == g0) lo = mid; else hi = mid;
+    }
+    const u64 end = hi, len = end - i0;
+    const u64 piece = (len + 63) / 64;
+    const u64 a = i0 + piece * lane < end ? i0 + piece * lane : end;
+    const u64 b = a + piece < end ? a + piece : end;
+    const CandJob J = jobs[(u32)(g0 >> 22)];
+    u32 v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = 0;
+    u32 has = 0;
+    cand_sweep_range<NB, false>(J, keys, vals, a, b, v, has);
+    // inclusive scan of (v, has) over the lanes: the higher lane's writes win
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 ph = __shfl_up(has, d);
+      u32 pv[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) pv[j] = __shfl_up(v[j], d);
+      if (lane >= (u32)d) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) v[j] = (has >> j) & 1u ? v[j] : pv[j];
+        has |= ph;
+      }
+    }
+    // exclusive: what the lanes below leave behind (nothing for lane 0: a run starts from an empty group)
+    u32 s[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const u32 x = __shfl_up(v[j], 1); s[j] = lane ? x : 0u; }
+    u32 dummy = 0;
+    cand_sweep_range<NB, true>(J, keys, vals, a, b, s, dummy);
+  }
+}
+
 // ---- speculative parse: one wave per segment ------------------------------------------------------------
 template <int NB, bool CAND = false>
 __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list, const zpq_place P) {
@@ -935,13 +986,27 @@ static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& 
     while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
     ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, st));
   }
+  // runs of more than kLong entries go to a queue in the (now free) first key array and get a wave each
+  constexpr u32 kLong = 4096;
+  u32 klong = kLong;
+  if (const char* e = getenv("ZPQ_LZ_CAND_LONG")) klong = (u32)strtoul(e, 0, 10);        // 0: no hand-off (tests)
+  u32* d_longq = (u32*)d_keys0;
+  const u32 long_cap = klong ? (u32)std::min<u64>(positions / klong + 1, (positions * 2 - 2) / 2) : 0;
+  ZPQ_HIP(ctx, hipMemsetAsync(d_longq, 0, 8, st));
   const unsigned sweep_grid = (unsigned)((positions + 63) / 64);
+  const unsigned long_grid = (unsigned)std::min<u64>((u64)long_cap, (u64)ctx->cu_count * 8);
+#define ZPQ_CAND_SWEEPS(NBV)                                                                                                              \
+  ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<NBV>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions, \
+             d_longq, long_cap, klong);                                                                                                   \
+  if (long_grid) ZPQ_LAUNCH(ctx, "lz77_cand_sweep_long_kernel", st, lz77_cand_sweep_long_kernel<NBV>, dim3(long_grid), dim3(64), d_cjobs, d_keys1, \
+                            d_vals1, positions, d_longq, long_cap)
   switch (cjobs[0].lb) {
-    case 0: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<1>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
-    case 1: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<2>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
-    case 2: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<4>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
-    default: ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<8>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions); break;
+    case 0: ZPQ_CAND_SWEEPS(1); break;
+    case 1: ZPQ_CAND_SWEEPS(2); break;
+    case 2: ZPQ_CAND_SWEEPS(4); break;
+    default: ZPQ_CAND_SWEEPS(8); break;
   }
+#undef ZPQ_CAND_SWEEPS
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
 }
