@@ -1,10 +1,7 @@
-// Test infrastructure: lz_walk -- the heart of the LZ77 hash-table parse, zpaqfranz_amd/csrc/lz77_enc.hip -- compiled for
-// the HOST and run as one emulated wave: 64 lanes are 64 fibres (ucontext) of one thread that take turns; every wave-level
-// operation (ballot, shuffle, readlane, wave barrier) is a rendezvous at which each lane deposits its value, yields, and
-// reads everybody's when its turn comes again.  Lanes of a real wave run in lockstep, so all of them reach the same
-// rendezvous in the same order; a lane that does not is reported (operation ids are compared).  What lockstep gives for
-// free on the GPU -- every lane's stores of a window are issued before any lane's loads of the next -- is a rendezvous
-// here too (ZPQ_WAIT_VMCNT0).  Built with the ROCm clang++ as a host compiler (address spaces, ext vectors).
+// Test infrastructure: the LZ77 hash-table parse kernels of zpaqfranz_amd/csrc/lz77_enc.hip compiled for the HOST and run as
+// emulated waves (simt_emu.h: 64 lanes = 64 fibres of one thread, every wave-level operation a rendezvous).  What lockstep
+// gives for free on the GPU -- every lane's stores of a window are issued before any lane's loads of the next -- is a
+// rendezvous here too (ZPQ_WAIT_VMCNT0).  Built with the ROCm clang++ as a host compiler (address spaces, ext vectors).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,54 +21,7 @@ typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 typedef u64 __attribute__((aligned(1))) u64_u;
 typedef u32 __attribute__((aligned(1))) u32_u;
 
-// ---- the emulated wave ---------------------------------------------------------------------------------------------
-namespace emu {
-constexpr int W = 64;
-ucontext_t g_main, g_ctx[W];
-int g_lane = 0;
-bool g_done[W];
-u64 g_buf[2][W];
-int g_op[2][W];
-u32 g_phase[W];
-const char* g_error = nullptr;
-void (*g_body)() = nullptr;
-
-inline void yield() { swapcontext(&g_ctx[g_lane], &g_main); }
-// deposits v, lets every other lane reach the same rendezvous, returns all 64 values
-inline const u64* rendezvous(u64 v, int op) {
-  const int me = g_lane, p = (int)(g_phase[me]++ & 1u);
-  g_buf[p][me] = v; g_op[p][me] = op;
-  yield();
-  for (int i = 0; i < W; ++i)
-    if (g_op[p][i] != op && !g_error) g_error = "lanes reached different wave operations (divergent intrinsic)";
-  return g_buf[p];
-}
-void trampoline() { g_body(); g_done[g_lane] = true; swapcontext(&g_ctx[g_lane], &g_main); }
-// runs body() on 64 lanes in lockstep; returns nullptr or an error text
-const char* run_wave(void (*body)()) {
-  static std::vector<char> stacks((size_t)W * (256 << 10));
-  g_body = body; g_error = nullptr;
-  for (int i = 0; i < W; ++i) {
-    g_done[i] = false; g_phase[i] = 0;
-    getcontext(&g_ctx[i]);
-    g_ctx[i].uc_stack.ss_sp = stacks.data() + (size_t)i * (256 << 10);
-    g_ctx[i].uc_stack.ss_size = 256 << 10;
-    g_ctx[i].uc_link = &g_main;
-    makecontext(&g_ctx[i], trampoline, 0);
-  }
-  for (;;) {
-    bool any = false;
-    for (int i = 0; i < W; ++i)
-      if (!g_done[i]) { any = true; g_lane = i; swapcontext(&g_main, &g_ctx[i]); }
-    if (!any) break;
-    bool all = true, none = true;
-    for (int i = 0; i < W; ++i) { all = all && g_done[i]; none = none && !g_done[i]; }
-    if (!all && !none && !g_error) g_error = "some lanes left the kernel while others wait at a wave operation";
-    if (g_error && !all) return g_error;      // (the fibres are abandoned)
-  }
-  return g_error;
-}
-}  // namespace emu
+#include "simt_emu.h"
 
 // ---- what lz77_enc.hip expects from the device environment ------------------------------------------------------------
 #define __device__
@@ -82,31 +32,21 @@ const char* run_wave(void (*body)()) {
 struct EmuDim { u32 x, y, z; };
 static EmuDim threadIdx, blockIdx, gridDim;
 static bool g_in_wave = false;
-static inline int lane_id() { return g_in_wave ? emu::g_lane : (int)(threadIdx.x & 63u); }
-static inline unsigned long long emu_ballot(bool p, int op) {
-  const u64* a = emu::rendezvous(p ? 1 : 0, op);
-  unsigned long long m = 0;
-  for (int i = 0; i < 64; ++i) m |= (unsigned long long)(a[i] & 1) << i;
-  return m;
-}
-template <class T> static inline T emu_shfl(T v, int src, int op) {
-  u64 bits = 0; memcpy(&bits, &v, sizeof v);
-  const u64* a = emu::rendezvous(bits, op);
-  T r; memcpy(&r, &a[src & 63], sizeof r);
-  return r;
-}
+static inline int lane_id() { return g_in_wave ? emu::lane() : (int)(threadIdx.x & 63u); }
+static inline unsigned long long emu_ballot(bool p, int op) { return emu::ballot(p, op); }
+template <class T> static inline T emu_shfl(T v, int src, int op) { return emu::shfl(v, src, op); }
 #define __ballot(p) emu_ballot((p), __LINE__)
 #define __shfl(v, src) emu_shfl((v), (int)(src), __LINE__)
 #define __shfl_xor(v, m) emu_shfl((v), lane_id() ^ (int)(m), __LINE__)
 #define __shfl_up(v, d) emu_shfl((v), lane_id() >= (int)(d) ? lane_id() - (int)(d) : lane_id(), __LINE__)
 #define __builtin_amdgcn_readlane(v, l) emu_shfl((v), (int)(l), __LINE__)
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0, __LINE__)
-#define __builtin_amdgcn_wave_barrier() ((void)emu::rendezvous(0, __LINE__))
+#define __builtin_amdgcn_wave_barrier() ((void)emu::wave_rendezvous(0, __LINE__))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #define __ATOMIC_RELAXED_HIP 0
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 0
-#define ZPQ_WAIT_VMCNT0 ((void)emu::rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
+#define ZPQ_WAIT_VMCNT0 ((void)emu::wave_rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
 // serial stand-ins for the global atomics of the thread-independent kernels (one thread runs after the other)
 template <class T> static inline T emu_atomic_max(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 #define atomicMax(p, v) emu_atomic_max((p), (v))
@@ -156,7 +96,7 @@ extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table,
     default: body = cand ? walk_body<8, true> : walk_body<8, false>; break;
   }
   g_in_wave = true;
-  const char* e = emu::run_wave(body);
+  const char* e = emu::run_block(body);
   g_in_wave = false;
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   return (long)g_w.ntok;
@@ -177,7 +117,7 @@ template <int NB> void bodies(bool cand, Body& sp, Body& se, Body& st) {
   if (cand) { sp = spec_body<NB, true>; se = seam_body<NB, true>; st = stitch_body<NB, true>; }
   else { sp = spec_body<NB, false>; se = seam_body<NB, false>; st = stitch_body<NB, false>; }
 }
-const char* wave(Body b, u32 bx) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_wave(b); g_in_wave = false; return e; }
+const char* wave(Body b, u32 bx) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_block(b); g_in_wave = false; return e; }
 template <class F> void serial(u32 gx, u32 gy, u32 threads, F&& f) {
   gridDim = {gx, gy, 1};
   for (u32 by = 0; by < gy; ++by) for (u32 bx = 0; bx < gx; ++bx) for (u32 t = 0; t < threads; ++t) { blockIdx = {bx, by, 0}; threadIdx = {t, 0, 0}; f(); }
