@@ -75,3 +75,15 @@ def test_candidate_table_equals_the_sequential_table(args):
                 d_in.free(); d_c.free()
     finally:
         eng.close()
+
+
+def test_own_radix_sort_under_the_suffix_array_and_the_candidate_tables():
+    """ZPQ_SORT=own: the hand-written radix sort (radix.hip) instead of rocPRIM -- the suffix-array tests (SA = the real
+    divsufsort) and the candidate-table test above must pass unchanged."""
+    e = dict(os.environ, ZPQ_SORT="own")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_sa.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=e, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", "candidate_table_equals"],
+                       capture_output=True, text=True, env=e, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]

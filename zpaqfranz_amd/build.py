@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libzpaqhip.so")
-SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "twins.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "cm_jit.hip", "config.hip", "e8e9.hip", "checksum.hip", "ibwt.hip"]
+SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "twins.hip", "radix.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "cm_jit.hip", "config.hip", "e8e9.hip", "checksum.hip", "ibwt.hip"]
 
 
 def needs_build():

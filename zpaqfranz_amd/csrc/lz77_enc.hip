@@ -984,6 +984,10 @@ static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& 
     size_t tb = temp_bytes;
     u32 end_bit = 48;
     while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
+    if (zpq_own_sort()) {
+      int rc = zpq_radix_sort_pairs(ctx, st, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, (u32*)d_tmp);
+      if (rc) return rc;
+    } else
     ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, st));
   }
   // runs of more than kLong entries go to a queue in the (now free) first key array and get a wave each
@@ -1040,6 +1044,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   const size_t cand_words = table_words;       // (candidate-table mode) the sort buffers sit behind the tables
   if (cand) {
     ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, cand_sort_temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)cand_positions, 0u, 64u, st));
+    cand_sort_temp = std::max(cand_sort_temp, zpq_radix_scratch_words((size_t)cand_positions) * 4);
     table_words = ((cand_words + 63) & ~(size_t)63) + (size_t)cand_positions * 6 + 64 + (cand_sort_temp + 3) / 4 + 64;
   }
   u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
@@ -1264,6 +1269,7 @@ extern "C" int zpq_lz77_cand_dev(zpq_ctx* ctx, const void* d_in, uint32_t n, con
   cj[0].pos0 = 0; cj[0].cand = d_cand; cj[0].lb = (u32)args[4]; cj[0].pad = 0;
   size_t temp = 0;
   ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, st));
+  temp = std::max(temp, zpq_radix_scratch_words((size_t)n) * 4);
   u8* buf = (u8*)zpq_scratch(ctx, 0, (size_t)n * 24 + temp + 1024);
   CandJob* d_cjobs = (CandJob*)zpq_scratch(ctx, 2, sizeof(CandJob) + 256);
   if (!buf || !d_cjobs) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "candidate table scratch");
