@@ -11,9 +11,10 @@
 //                      a wave owns a contiguous quarter of the tile and takes it 64 pairs at a time; lanes with equal
 //                      digits find each other with eight ballots, their rank is "pairs of my digit this wave has seen"
 //                      (a per-wave LDS counter, advanced by the first lane of each set) + "equal lanes below me"; the
-//                      waves' counters are then prefixed per digit, and a pair goes to
-//                      counts[digit][tile] + pairs of that digit in the waves before + rank.
-// Memory per pass: keys read twice, pairs written once (scattered by digit; runs of equal digits are contiguous).
+//                      waves' counters are then prefixed per digit; the tile is laid out sorted by digit in LDS (48 KiB)
+//                      and written from there, so neighbouring threads write neighbouring pairs of a digit's run to
+//                      counts[digit][tile] + (place in the run).
+// Memory per pass: keys read twice, pairs written once, in runs.
 #ifndef ZPQ_EMU_RADIX_ONLY
 #include <algorithm>
 #include <stdlib.h>
@@ -120,20 +121,39 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const u64* __restrict__
     rk[r] = pre + rin;
   }
   __syncthreads();
-  {   // pairs of digit t in the waves before each wave
-    u32 o = 0;
+  // pairs of digit t in the waves before each wave, and in the whole tile
+  u32 mine = 0;
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) { const u32 c = wcnt[q][t]; wcnt[q][t] = o; o += c; }
-  }
+  for (u32 q = 0; q < 4; ++q) { const u32 c = wcnt[q][t]; wcnt[q][t] = mine; mine += c; }
+  u32 all;
+  const u32 tstart = rs_block_exclusive(mine, &all);     // where digit t starts in the tile once it is sorted by digit
+  __shared__ u32 dstart[256];
+  dstart[t] = tstart;
   __syncthreads();
+  // the tile sorted by digit in LDS (ranks keep the input order inside a digit) ...
+  __shared__ u64 sk[kRsTile];
+  __shared__ u32 sv[kRsTile];
 #pragma unroll
   for (u32 r = 0; r < kRsItems; ++r) {
     const u64 idx = base + (u64)r * 64u + lane;
     if (idx < n) {
       const u32 d = (u32)(k[r] >> shift) & dmask;
-      const u64 dst = (u64)gbase[d] + wcnt[w][d] + rk[r];
-      keys_out[dst] = k[r];
-      vals_out[dst] = v[r];
+      const u32 at = dstart[d] + wcnt[w][d] + rk[r];
+      sk[at] = k[r]; sv[at] = v[r];
+    }
+  }
+  __syncthreads();
+  // ... goes out in that order: neighbouring threads write neighbouring pairs of a digit's run
+  const u32 count = all;                                 // pairs in this tile
+#pragma unroll
+  for (u32 i = 0; i < kRsItems; ++i) {
+    const u32 j = i * kRsThreads + t;
+    if (j < count) {
+      const u64 key = sk[j];
+      const u32 d = (u32)(key >> shift) & dmask;
+      const u64 dst = (u64)gbase[d] + (j - dstart[d]);
+      keys_out[dst] = key;
+      vals_out[dst] = sv[j];
     }
   }
 }
