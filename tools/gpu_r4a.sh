@@ -1,0 +1,27 @@
+# First GPU call of round 4 (prepared at the end of round 3, when the GPU minutes were spent): the experimental paths that were
+# written and verified on the CPU emulator only -- candidate tables for the LZ77 hash-table parse (ZPQ_LZ_CAND=1), the
+# hand-written radix sort (ZPQ_SORT=own) -- first their parity tests, then A/B timings with every result verified.
+R=$GRAFT_REPO_ROOT
+T=${1:-r04a}
+mkdir -p $R/gpurun_out
+cd $R
+export PYTHONUNBUFFERED=1
+S0=$(date +%s)
+el() { echo "[$(( $(date +%s) - S0 )) s] $*"; }
+ZPQ_TEST_EXPERIMENTAL=1 timeout 500 python -m pytest tests/test_gpu_lz_cand.py -x -q -p no:cacheprovider > gpurun_out/${T}_tests_experimental.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/${T}_tests_experimental.log; tail -15 gpurun_out/${T}_tests_experimental.log; el tests
+export ZPQ_BENCH_NO_PLAIN=1
+sw() { # label, env, args
+  local out; out=$(env $2 timeout 300 python bench.py --no-cpu-baseline $3 2>gpurun_out/${T}_last.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print(d['value'], d['ms_per_step'], d.get('ms_per_step_serial'), d.get('steps_in_flight'), {a:b for a,b in d.items() if a.startswith('verified')}, {a:k[a] for a in list(k)[:8]})" 2>&1 | tail -1)
+  echo "$1 | $2 | $3 | $out" | tee -a gpurun_out/${T}_sweep.txt; }
+: > gpurun_out/${T}_sweep.txt
+sw "headline default"            "X=1"                          "--workload silesia_x256_m1 --steps 24"
+sw "headline cand depth 6"       "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 24 --pipeline 6"
+sw "headline cand depth 10"      "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 40 --pipeline 10"
+sw "headline cand serial"        "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 4 --pipeline 1"
+sw "headline cand, own sort"     "ZPQ_LZ_CAND=1 ZPQ_SORT=own"   "--workload silesia_x256_m1 --steps 24 --pipeline 6"
+sw "dup8 default"                "X=1"                          "--workload dup8_m1"
+sw "dup8 cand"                   "ZPQ_LZ_CAND=1"                "--workload dup8_m1"
+sw "text_m2 default"             "X=1"                          "--workload text_m2"
+sw "text_m2 own sort"            "ZPQ_SORT=own"                 "--workload text_m2"
+el done
