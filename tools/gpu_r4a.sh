@@ -20,6 +20,9 @@ sw "headline cand depth 6"       "ZPQ_LZ_CAND=1"                "--workload sile
 sw "headline cand depth 10"      "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 40 --pipeline 10"
 sw "headline cand serial"        "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 4 --pipeline 1"
 sw "headline cand, own sort"     "ZPQ_LZ_CAND=1 ZPQ_SORT=own"   "--workload silesia_x256_m1 --steps 24 --pipeline 6"
+sw "every byte hashed, default"  "X=1"                          "--workload silesia_x256_m1 --steps 12 --no-twins"
+sw "  crossings all parked"      "ZPQ_FRAG_BUDGET=4096 ZPQ_FRAG_RESUME_WAVES=10" "--workload silesia_x256_m1 --steps 12 --no-twins"
+sw "  crossings parked at 64K"   "ZPQ_FRAG_BUDGET=65536 ZPQ_FRAG_RESUME_WAVES=6"  "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "dup8 default"                "X=1"                          "--workload dup8_m1"
 sw "dup8 cand"                   "ZPQ_LZ_CAND=1"                "--workload dup8_m1"
 sw "text_m2 default"             "X=1"                          "--workload text_m2"
