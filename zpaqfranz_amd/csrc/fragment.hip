@@ -21,10 +21,14 @@
 //     of zeros) is re-evaluated exactly by the wave-parallel evaluator below (64 bytes per step:
 //     in-window o1 forwarding through 64-bit LDS masks, affine-map scan for the hash).
 // Integer-only byte work; traffic = input read ~1.25x (crossing fragments); bound by VALU/LDS issue.
+// (tests/cpp/frag_emu.cpp compiles the kernels of this file for the host -- ZPQ_EMU_FRAGMENT_ONLY -- and runs them on the
+// fibre emulator against the oracle's cuts)
+#ifndef ZPQ_EMU_FRAGMENT_ONLY
 #include <algorithm>
 #include <stdlib.h>
 
 #include "zpq_internal.h"
+#endif
 
 namespace {
 
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(256) void twin_spread_kernel(u32 nfiles, const u32*
 
 }  // namespace
 
+#ifndef ZPQ_EMU_FRAGMENT_ONLY
 namespace {
 // files f with rep && rep[f] != f are twins of file rep[f] (twins.hip): they are not walked, their records are their
 // representative's moved by the distance between the two.  frag_base_out (may be null): per-file record prefix, nfiles + 1.
@@ -768,3 +773,4 @@ int zpq_fragment_sha1_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* f
 }
 
 }  // extern "C"
+#endif  // ZPQ_EMU_FRAGMENT_ONLY
