@@ -1336,19 +1336,23 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
       all_n += jobs[i].n;
     }
     if (ok) {
-      u32 cseg = 256u << 10;
-      if (const char* e = getenv("ZPQ_LZ_SEG")) cseg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));
-      else while ((u64)cseg * 4096 < all_n && cseg < (1u << 30)) cseg <<= 1;
       bool cdirect = false;
       if (const char* e = getenv("ZPQ_LZ_DIRECT")) cdirect = atoi(e) != 0;
+      // batches by memory (token lists sized for the smallest segments), then PER BATCH the segment size that puts about
+      // four waves on every SIMD: with hundreds of blocks a batch is ~100 of them (1.3 GB of tables each), and it is the
+      // batch that has to fill the chip
       size_t lo = 0;
       while (lo < njobs) {
         size_t hi = lo, bytes = 0;
+        u64 batch_n = 0;
         while (hi < njobs) {
-          const size_t bts = job_bytes_cand(jobs[hi], cseg, cdirect);
+          const size_t bts = job_bytes_cand(jobs[hi], 256u << 10, cdirect);
           if (hi > lo && bytes + bts > budget) break;
-          bytes += bts; ++hi;
+          bytes += bts; batch_n += jobs[hi].n; ++hi;
         }
+        u32 cseg = 256u << 10;
+        if (const char* e = getenv("ZPQ_LZ_SEG")) cseg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));
+        else while ((u64)cseg * 4096 < batch_n && cseg < (1u << 30)) cseg <<= 1;
         int rc = encode_batch(ctx, jobs, lo, hi, cdirect ? (1u << 30) : cseg, cdirect, true);
         if (rc) return rc;
         lo = hi;
