@@ -763,8 +763,9 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
-#ifdef ZPQ_EMU_WALK_ONLY
-}  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled)
+#if defined(ZPQ_EMU_WALK_ONLY) && !defined(ZPQ_EMU_FULL)
+}  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled.
+   //            tests/cpp/lz77_full_emu.cpp -- ZPQ_EMU_FULL -- takes the whole file, host code included, over a stand-in HIP runtime)
 #else
 // ---- bit costs ---------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lit_run_header_bits(u32 len) { return 3u + 2u * (u32)(lg32(len) - 1); }  // :6464-6476

@@ -15,7 +15,7 @@
 //                      and written from there, so neighbouring threads write neighbouring pairs of a digit's run to
 //                      counts[digit][tile] + (place in the run).
 // Memory per pass: keys read twice, pairs written once, in runs.
-#ifndef ZPQ_EMU_RADIX_ONLY
+#if !defined(ZPQ_EMU_RADIX_ONLY) && !defined(ZPQ_EMU_FULL)      // (the host emulations of tests/cpp bring their own vocabulary)
 #include <algorithm>
 #include <stdlib.h>
 
