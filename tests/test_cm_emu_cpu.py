@@ -1,0 +1,86 @@
+"""The run-time specialised context-mixing coder on the CPU.  For a block header cm_jit.hip GENERATES HIP source (lane masks,
+the dependent chain with constant lanes, HCOMP as straight-line code); on the GPU hiprtc compiles it.  Here the same text --
+zpq_cm_spec_source_text(), with one line changed: the v_writelane inline assembly becomes C -- is compiled for the host
+between tests/cpp/cm_emu_head.inc and cm_emu_tail.inc and run on the fibre emulator (simt_emu.h): a 16-wave workgroup, its
+LDS tables, DPP sums, readlanes, the queue.  The coded bytes must be the REFERENCE Predictor's (oracle/_ref), and decode
+back.  Covers every component type, the models of methods 3 / 4 / 5 and libzpaq's three built-in models."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cmconfigs
+import datagen
+import orc
+from zpaqfranz_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+pytestmark = [pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ not found"),
+              pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")]
+
+
+@pytest.fixture(scope="module")
+def env():
+    L = engine.load()
+    L.zpq_cm_spec_source_text.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_cm_tables.argtypes = [C.c_void_p] * 5
+    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    t = dict(sq=np.zeros(4096, dtype=np.uint16), st=np.zeros(32768, dtype=np.int16), dt=np.zeros(1024, dtype=np.int32), dt2=np.zeros(256, dtype=np.int32),
+             ns=np.zeros(1024, dtype=np.uint8))
+    assert L.zpq_cm_tables(t["sq"].ctypes.data, t["st"].ctypes.data, t["dt"].ctypes.data, t["dt2"].ctypes.data, t["ns"].ctypes.data) == 0
+    return L, t
+
+
+def build(L, header, path):
+    buf = C.create_string_buffer(1 << 20)
+    n = C.c_size_t()
+    assert L.zpq_cm_spec_source_text(header, len(header), buf, 1 << 20, C.byref(n)) == 0
+    src = buf.raw[: n.value].decode()
+    old, = [ln for ln in src.splitlines() if ln.startswith("#define ZWL(")]
+    src = src.replace(old, "#define ZWL(v, L, p) { const int zwl_ = __builtin_amdgcn_readfirstlane((int)(v)); if ((int)(threadIdx.x & 63) == (L)) p = (decltype(p))zwl_; }")
+    cpp = os.path.join(path, "cm_emu.cpp")
+    with open(cpp, "w") as f:
+        f.write(open(os.path.join(ROOT, "tests", "cpp", "cm_emu_head.inc")).read() + src + open(os.path.join(ROOT, "tests", "cpp", "cm_emu_tail.inc")).read())
+    so = os.path.join(path, "cm_emu.so")
+    subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-Wno-unused-value", "-I" + os.path.join(ROOT, "tests", "cpp"), cpp, "-o", so])
+    lib = C.CDLL(so)
+    lib.cm_emu.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+                           C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+    return lib
+
+
+def code(lib, t, header, data, encode, cap):
+    out = np.zeros(cap + 64, dtype=np.uint8)
+    res = (C.c_uint32 * 2)()
+    err = C.create_string_buffer(256)
+    rc = lib.cm_emu(header, t["sq"].ctypes.data, t["st"].ctypes.data, t["dt"].ctypes.data, t["dt2"].ctypes.data, t["ns"].ctypes.data, data + bytes(64), len(data),
+                    out.ctypes.data, cap, 1 if encode else 0, res, err, 256)
+    assert rc == 0, err.value.decode()
+    assert res[1] == 0, "status %d" % res[1]
+    return bytes(out[: res[0]])
+
+
+def _header(L, name):
+    if name in cmconfigs.ALL:
+        return engine.compile_config(cmconfigs.ALL[name], [0] * 9)[0]
+    if name.startswith("builtin"):
+        buf = C.create_string_buffer(512)
+        n = C.c_size_t(0)
+        assert L.zpq_builtin_model(int(name[-1]), buf, 512, C.byref(n)) == 0
+        return buf.raw[: n.value]
+    src, args = engine.make_config(engine.expand_method({"m4": "44", "m5": "54", "m3bwt": "x4,3ci1"}[name], b"x" * 1000))
+    return engine.compile_config(src, args)[0]
+
+
+@pytest.mark.parametrize("name,nbytes", [("order1_cm", 1500), ("mid", 800), ("alltypes", 800), ("m4", 800), ("m5", 400), ("builtin1", 1500), ("builtin3", 400), ("m3bwt", 1500)])
+def test_generated_kernel_on_the_emulator_codes_like_the_reference_predictor(env, tmp_path, name, nbytes):
+    L, t = env
+    h = _header(L, name)
+    lib = build(L, h, str(tmp_path))
+    for x in (b"\0" + datagen.text_like(nbytes, 1), b"\0" + datagen.binary_like(nbytes // 2, 2), b"\0", b""):
+        got = code(lib, t, h, x, True, len(x) * 2 + 4096)
+        assert got == orc.ref_cm_encode(h, x), (name, len(x))
+        assert code(lib, t, h, got, False, len(x) + 64) == x, (name, len(x))
