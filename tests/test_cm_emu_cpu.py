@@ -22,18 +22,6 @@ pytestmark = [pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++
               pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")]
 
 
-@pytest.fixture(scope="module")
-def env():
-    L = engine.load()
-    L.zpq_cm_spec_source_text.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.zpq_cm_tables.argtypes = [C.c_void_p] * 5
-    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
-    t = dict(sq=np.zeros(4096, dtype=np.uint16), st=np.zeros(32768, dtype=np.int16), dt=np.zeros(1024, dtype=np.int32), dt2=np.zeros(256, dtype=np.int32),
-             ns=np.zeros(1024, dtype=np.uint8))
-    assert L.zpq_cm_tables(t["sq"].ctypes.data, t["st"].ctypes.data, t["dt"].ctypes.data, t["dt2"].ctypes.data, t["ns"].ctypes.data) == 0
-    return L, t
-
-
 def build(L, header, path):
     buf = C.create_string_buffer(1 << 20)
     n = C.c_size_t()
@@ -75,12 +63,38 @@ def _header(L, name):
     return engine.compile_config(src, args)[0]
 
 
-@pytest.mark.parametrize("name,nbytes", [("order1_cm", 1500), ("mid", 800), ("alltypes", 800), ("m4", 800), ("m5", 400), ("builtin1", 1500), ("builtin3", 400), ("m3bwt", 1500)])
-def test_generated_kernel_on_the_emulator_codes_like_the_reference_predictor(env, tmp_path, name, nbytes):
-    L, t = env
-    h = _header(L, name)
-    lib = build(L, h, str(tmp_path))
-    for x in (b"\0" + datagen.text_like(nbytes, 1), b"\0" + datagen.binary_like(nbytes // 2, 2), b"\0", b""):
-        got = code(lib, t, h, x, True, len(x) * 2 + 4096)
-        assert got == orc.ref_cm_encode(h, x), (name, len(x))
-        assert code(lib, t, h, got, False, len(x) + 64) == x, (name, len(x))
+MODELS = [("order1_cm", 600), ("mid", 300), ("alltypes", 300), ("m4", 300), ("m5", 160), ("builtin1", 600), ("builtin3", 160), ("m3bwt", 600)]
+
+
+def _one_model(job):
+    """worker process: generate, compile, code four inputs, decode them back; returns a text on any difference"""
+    name, nbytes, path = job
+    L = engine.load()
+    L.zpq_cm_spec_source_text.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zpq_cm_tables.argtypes = [C.c_void_p] * 5
+    L.zpq_builtin_model.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    t = dict(sq=np.zeros(4096, dtype=np.uint16), st=np.zeros(32768, dtype=np.int16), dt=np.zeros(1024, dtype=np.int32), dt2=np.zeros(256, dtype=np.int32),
+             ns=np.zeros(1024, dtype=np.uint8))
+    L.zpq_cm_tables(t["sq"].ctypes.data, t["st"].ctypes.data, t["dt"].ctypes.data, t["dt2"].ctypes.data, t["ns"].ctypes.data)
+    try:
+        h = _header(L, name)
+        os.makedirs(path, exist_ok=True)
+        lib = build(L, h, path)
+        for x in (b"\0" + datagen.text_like(nbytes, 1), b"\0" + datagen.binary_like(nbytes // 2, 2), b"\0", b""):
+            got = code(lib, t, h, x, True, len(x) * 2 + 4096)
+            if got != orc.ref_cm_encode(h, x):
+                return "%s: %d bytes code differently from the reference Predictor" % (name, len(x))
+            if code(lib, t, h, got, False, len(x) + 64) != x:
+                return "%s: %d bytes do not decode back" % (name, len(x))
+    except Exception as ex:          # noqa: BLE001 -- reported by the parent
+        return "%s: %r" % (name, ex)
+    return None
+
+
+def test_generated_kernels_on_the_emulator_code_like_the_reference_predictor(tmp_path):
+    """one worker process per model (generate, compile, emulate), all at the same time"""
+    import multiprocessing as mp
+    jobs = [(name, n, str(tmp_path / name)) for name, n in MODELS]
+    with mp.get_context("fork").Pool(min(len(jobs), os.cpu_count() or 2)) as pool:
+        bad = [r for r in pool.map(_one_model, jobs) if r]
+    assert not bad, bad

@@ -50,20 +50,32 @@ def so(tmp_path_factory):
     return path
 
 
-A3 = [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [5, 1, 4, 0, 2, 16]]
+A3 = [[4, 1, 5, 0, 3, 15], [0, 1, 4, 0, 1, 14], [5, 1, 4, 0, 2, 15]]
 
 
-@pytest.mark.parametrize("env,scale,argsets,only", [
-    ({}, 3, A3[:2], None),                                                                 # the default: table states, 1 MiB segments (one per block here)
-    ({"ZPQ_LZ_SEG": "65536"}, 8, A3[:1], None),                                            # table states, several speculative segments
-    ({"ZPQ_LZ_DIRECT": "1"}, 3, A3[1:], None),                                             # one wave per block writes the stream itself
-    ({"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536"}, 8, A3, None),                            # candidate tables, speculative segments
-    ({"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, 6, A3, None),                             # candidate tables, one wave per block
-    ({"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_LZ_CAND_LONG": "50"}, 6, A3, None),  # ... long runs handed to whole waves
-    ({"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_SORT": "own"}, 2, A3[:1], ["mixed", "tiny"]),     # ... over the hand-written radix sort
-], ids=["default", "table-segments", "table-direct", "cand-segments", "cand-direct", "cand-long-runs", "cand-own-sort"])
-def test_the_encoder_entry_point_on_the_cpu_gives_the_oracles_stream(so, env, scale, argsets, only):
-    e = {k: v for k, v in os.environ.items() if not k.startswith("ZPQ_")}
-    e.update(env)
-    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "so": so, "scale": scale, "argsets": argsets, "only": only}], capture_output=True, text=True, env=e, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+SETTINGS = [
+    ("default", {}, 2, A3[:2], None),                                                                 # table states, 1 MiB segments (one per block here)
+    ("table-segments", {"ZPQ_LZ_SEG": "65536"}, 6, A3[:1], None),                                     # table states, several speculative segments
+    ("table-direct", {"ZPQ_LZ_DIRECT": "1"}, 2, A3[2:], None),                                        # one wave per block writes the stream itself
+    ("cand-segments", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536"}, 8, A3, None),                      # candidate tables, speculative segments
+    ("cand-direct", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, 6, A3, None),                         # candidate tables, one wave per block
+    ("cand-long-runs", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_LZ_CAND_LONG": "50"}, 6, A3, None),   # ... long runs handed to whole waves
+    ("cand-own-sort", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_SORT": "own"}, 2, A3[:1], ["mixed", "tiny"]),   # ... over the hand-written radix sort
+]
+
+
+def test_the_encoder_entry_point_on_the_cpu_gives_the_oracles_stream(so):
+    """every setting in a process of its own (the switches are read once per process), all of them at the same time"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(setting):
+        name, env, scale, argsets, only = setting
+        e = {k: v for k, v in os.environ.items() if not k.startswith("ZPQ_")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "so": so, "scale": scale, "argsets": argsets, "only": only}], capture_output=True, text=True, env=e,
+                           timeout=900)
+        return name, r.returncode, r.stdout[-1500:], r.stderr[-1500:]
+    with ThreadPoolExecutor(max_workers=min(len(SETTINGS), os.cpu_count() or 2)) as ex:
+        results = list(ex.map(one, SETTINGS))
+    bad = [r for r in results if r[1] != 0]
+    assert not bad, bad

@@ -30,13 +30,35 @@ def _lib(tmp_path_factory):
     return _SO[0]
 
 
-@pytest.fixture(scope="module")
-def walk(tmp_path_factory):
-    L = _lib(tmp_path_factory)
+def _inputs():
+    rng = np.random.default_rng(9)
+    unit = rng.integers(0, 256, size=9000, dtype=np.uint8).tobytes()
+    return {
+        "text": datagen.text_like(12000, 1),
+        "binary": datagen.binary_like(8000, 2),
+        "mixed": datagen.mixed(10000, 3),
+        "runs": bytes(4000) + b"ab" * 2500 + datagen.random_bytes(600, 4),            # very long matches: whole-wave compares
+        "long": unit + unit + unit[:100] + datagen.random_bytes(6000, 5) + unit,       # capped candidates, a literal run past 4096
+        "tiny": b"abcabcabcabc", "one": b"x", "empty": b"", "window": datagen.text_like(64, 7), "window+1": datagen.text_like(65, 8),
+    }
+
+
+ARGS = [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [4, 1, 4, 0, 2, 16], [5, 1, 6, 0, 0, 15]]
+
+
+def _pool_map(fn, jobs):
+    """the cases of a test in forked worker processes (each has its own emulator state; the harness is already loaded)"""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(len(jobs), os.cpu_count() or 2)) as pool:
+        return [r for r in pool.map(fn, jobs) if r]
+
+
+def _walk_case(job):
+    args, cand = job
+    L = _SO[0]
     L.walk_emu.restype = C.c_long
     L.walk_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
-
-    def run(b, args, cand):
+    for name, b in _inputs().items():
         n = len(b)
         words = (n << args[4]) if cand else (1 << args[5])
         raw = np.zeros(words + 16, dtype=np.uint32)
@@ -48,34 +70,19 @@ def walk(tmp_path_factory):
         tok = np.zeros(3 * cap, dtype=np.uint32)
         err = C.create_string_buffer(256)
         r = L.walk_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, tok.ctypes.data, cap, err, 256)
-        assert r >= 0, err.value.decode()
-        return [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
-    return run
-
-
-def _inputs():
-    rng = np.random.default_rng(9)
-    unit = rng.integers(0, 256, size=9000, dtype=np.uint8).tobytes()
-    return {
-        "text": datagen.text_like(24000, 1),
-        "binary": datagen.binary_like(16000, 2),
-        "mixed": datagen.mixed(20000, 3),
-        "runs": bytes(4000) + b"ab" * 2500 + datagen.random_bytes(600, 4),            # very long matches: whole-wave compares
-        "long": unit + unit + unit[:100] + datagen.random_bytes(6000, 5) + unit,       # capped candidates, a literal run past 4096
-        "tiny": b"abcabcabcabc", "one": b"x", "empty": b"", "window": datagen.text_like(64, 7), "window+1": datagen.text_like(65, 8),
-    }
-
-
-ARGS = [[4, 1, 5, 0, 3, 18], [0, 1, 4, 0, 1, 15], [4, 1, 4, 0, 2, 16], [0, 1, 6, 0, 3, 17], [4, 1, 5, 0, 0, 16], [5, 1, 4, 0, 2, 18]]
-
-
-@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
-@pytest.mark.parametrize("args", ARGS, ids=lambda a: ",".join(map(str, a)))
-def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(walk, args, cand):
-    for name, b in _inputs().items():
+        if r < 0:
+            return (args, cand, name, err.value.decode())
+        got = [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
         want = orc.lz77_encode(b, args, trace=True)[1]
-        got = walk(b, args, cand)
-        assert got == want, (name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+        if got != want:
+            return (args, cand, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+    return None
+
+
+def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(tmp_path_factory):
+    _lib(tmp_path_factory)
+    bad = _pool_map(_walk_case, [(a, c) for a in ARGS for c in (False, True)])
+    assert not bad, bad
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -83,13 +90,17 @@ def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(walk, args, cand)
 # scatter kernels) or a candidate table, lz77_spec_kernel and lz77_seam_kernel per segment, lz77_stitch_kernel,
 # lz77_move_tokens_kernel.  Segments of a few KiB put seams, swallowed segments and re-walks into small inputs.
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def spec(walk, tmp_path_factory):
-    L = _lib(tmp_path_factory)
+SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 6, 0, 2, 15], 16384), ([5, 1, 5, 0, 0, 14], 4096)]
+
+
+def _spec_case(job):
+    args, seg, cand = job
+    L = _SO[0]
     L.spec_emu.restype = C.c_long
     L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
-
-    def run(b, args, seg, cand):
+    inputs = _inputs()
+    inputs["seams"] = (datagen.text_like(5000, 11) * 3)[:14000] + bytes(9000) + datagen.text_like(5000, 12)   # matches across several segment edges, a swallowed segment
+    for name, b in inputs.items():
         n = len(b)
         ptr = None
         if cand:
@@ -103,29 +114,24 @@ def spec(walk, tmp_path_factory):
         tok = np.zeros(3 * cap, dtype=np.uint32)
         err = C.create_string_buffer(256)
         r = L.spec_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), seg, ptr, tok.ctypes.data, cap, err, 256)
-        assert r >= 0, (r, err.value.decode())
-        return [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
-    return run
-
-
-@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
-@pytest.mark.parametrize("args,seg", [([4, 1, 5, 0, 3, 16], 4096), ([4, 1, 5, 0, 3, 16], 16384), ([0, 1, 4, 0, 1, 15], 4096), ([4, 1, 4, 0, 2, 16], 8192),
-                                      ([0, 1, 6, 0, 3, 17], 4096), ([4, 1, 5, 0, 0, 16], 8192)], ids=lambda a: ",".join(map(str, a)) if isinstance(a, list) else str(a))
-def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(spec, args, seg, cand):
-    inputs = _inputs()
-    inputs["seams"] = (datagen.text_like(5000, 11) * 3)[:14000] + bytes(9000) + datagen.text_like(7000, 12)   # matches across several segment edges, a swallowed segment
-    for name, b in inputs.items():
+        if r < 0:
+            return (args, seg, cand, name, r, err.value.decode())
+        got = [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
         want = orc.lz77_encode(b, args, trace=True)[1]
-        got = spec(b, args, seg, cand)
-        assert got == want, (name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+        if got != want:
+            return (args, seg, cand, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+    return None
 
 
-@pytest.mark.parametrize("cand", [False, True], ids=["table", "candidates"])
-@pytest.mark.parametrize("args", [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [5, 1, 4, 0, 2, 18], [6, 1, 6, 0, 3, 17]], ids=lambda a: ",".join(map(str, a)))
-def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_factory, args, cand):
-    """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
-    match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
-    L = _lib(tmp_path_factory)
+def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(tmp_path_factory):
+    _lib(tmp_path_factory)
+    bad = _pool_map(_spec_case, [(a, sg, c) for a, sg in SPEC_CASES for c in (False, True)])
+    assert not bad, bad
+
+
+def _direct_case(job):
+    args, cand = job
+    L = _SO[0]
     L.direct_emu.restype = C.c_long
     L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     for name, b in _inputs().items():
@@ -140,16 +146,23 @@ def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_fa
         out = np.zeros(cap, dtype=np.uint8)
         err = C.create_string_buffer(256)
         r = L.direct_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, out.ctypes.data, cap, err, 256)
-        assert r >= 0, (name, r, err.value.decode())
-        assert bytes(out[:r]) == orc.lz77_encode(b, args), name
+        if r < 0:
+            return (args, cand, name, r, err.value.decode())
+        if bytes(out[:r]) != orc.lz77_encode(b, args):
+            return (args, cand, name, "stream differs")
+    return None
 
 
-@pytest.mark.parametrize("args", [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [4, 1, 5, 0, 0, 16], [4, 1, 4, 0, 2, 16]], ids=lambda a: ",".join(map(str, a)))
-def test_long_runs_swept_by_a_whole_wave_give_the_sequential_table(tmp_path_factory, args):
-    """Candidate tables with the long-run hand-off: keys and the sweep thread by thread, runs longer than klong queued and
-    swept by lz77_cand_sweep_long_kernel on emulated waves (pieces per lane, 'later write wins per slot' scanned over the
-    lanes, second sweep writing).  Small klong values put hundreds of runs through the wave form."""
-    L = _lib(tmp_path_factory)
+def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_factory):
+    """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
+    match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
+    _lib(tmp_path_factory)
+    bad = _pool_map(_direct_case, [(a, c) for a in ([4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]) for c in (False, True)])
+    assert not bad, bad
+
+
+def _long_case(args):
+    L = _SO[0]
     L.cand_long_emu.restype = C.c_long
     L.cand_long_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
     inputs = {"text": datagen.text_like(50000, 1), "runs": bytes(9000) + b"ab" * 6000 + datagen.random_bytes(500, 4), "mixed": datagen.mixed(30000, 3),
@@ -163,7 +176,19 @@ def test_long_runs_swept_by_a_whole_wave_give_the_sequential_table(tmp_path_fact
             nl = C.c_uint32(0)
             err = C.create_string_buffer(256)
             r = L.cand_long_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), klong, cand.ctypes.data, C.byref(nl), err, 256)
-            assert r >= 0, (name, klong, err.value.decode())
-            assert np.array_equal(cand[: len(want)], want), (name, klong, nl.value)
+            if r < 0:
+                return ("error", args, name, klong, err.value.decode())
+            if not np.array_equal(cand[: len(want)], want):
+                return ("differs", args, name, klong, nl.value)
             seen_long += nl.value
-    assert seen_long > 300
+    return ("ok", seen_long)
+
+
+def test_long_runs_swept_by_a_whole_wave_give_the_sequential_table(tmp_path_factory):
+    """Candidate tables with the long-run hand-off: keys and the sweep thread by thread, runs longer than klong queued and
+    swept by lz77_cand_sweep_long_kernel on emulated waves (pieces per lane, 'later write wins per slot' scanned over the
+    lanes, second sweep writing).  Small klong values put hundreds of runs through the wave form."""
+    _lib(tmp_path_factory)
+    res = _pool_map(_long_case, [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [4, 1, 5, 0, 0, 16]])
+    assert all(r[0] == "ok" for r in res), res
+    assert all(r[1] > 300 for r in res), res
