@@ -24,7 +24,7 @@ def _lib(tmp_path_factory):
     """walk_emu.so, built once per test process"""
     if _SO[0] is None:
         so = str(tmp_path_factory.mktemp("walk_emu") / "walk_emu.so")
-        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused"] + os.environ.get("EMU_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "zpaqfranz_amd", "csrc"),
                                os.path.join(ROOT, "tests", "cpp", "walk_emu.cpp"), "-o", so])
         _SO[0] = C.CDLL(so)
     return _SO[0]
