@@ -115,7 +115,13 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   return hipSuccess;
 }
 static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)6 << 30; *t = (size_t)16 << 30; return hipSuccess; }
-// device memory: host memory with a canary behind it (checked when it is freed)
+// device memory: host memory with a canary behind it (checked when it is freed); in the AddressSanitizer build the exact
+// size, so that the first byte behind an allocation is a red zone
+#if defined(EMU_ASAN)
+static inline hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+#else
 static inline hipError_t hipMalloc(void** p, size_t n) {
   char* b = (char*)aligned_alloc(256, ((n + 255) & ~(size_t)255) + 512);
   if (!b) return hipErrorOutOfMemory;
@@ -134,6 +140,7 @@ static inline hipError_t hipFree(void* p) {
   free(b);
   return hipSuccess;
 }
+#endif
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 EMU_VAR const char* g_emu_last_error_text;

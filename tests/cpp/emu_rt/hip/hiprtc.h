@@ -8,6 +8,11 @@
 
 #include "hip_runtime.h"
 
+#if defined(EMU_ASAN)
+#define EMU_ASAN_FLAGS " -fsanitize=address -shared-libasan -fno-omit-frame-pointer -g1 -DEMU_ASAN=1"
+#else
+#define EMU_ASAN_FLAGS ""
+#endif
 typedef int hiprtcResult;
 enum { HIPRTC_SUCCESS = 0, HIPRTC_ERROR_COMPILATION = 6 };
 struct EmuRtcProgram { std::string src, log, path; };
@@ -74,7 +79,7 @@ static inline hiprtcResult hiprtcCompileProgram(hiprtcProgram p, int, const char
   FILE* f = fopen(cpp.c_str(), "w");
   if (!f) { p->log = "cannot write " + cpp; return HIPRTC_ERROR_COMPILATION; }
   fputs(src.c_str(), f); fclose(f);
-  const std::string cmd = std::string(EMU_HOST_CXX) + " -O1 -std=c++17 -fPIC -shared -w -DEMU_EXTERN_STATE -I" + EMU_RT_DIR + " -include hip/hip_runtime.h " + cpp +
+  const std::string cmd = std::string(EMU_HOST_CXX) + " -O1 -std=c++17 -fPIC -shared -w -DEMU_EXTERN_STATE" EMU_ASAN_FLAGS " -I" + EMU_RT_DIR + " -include hip/hip_runtime.h " + cpp +
                           " -o " + tmpso + " " + self + " -Wl,-rpath," + self.substr(0, self.rfind('/')) + " > " + cpp + ".log 2>&1";
   const int rc = system(cmd.c_str());
   if (rc != 0) {

@@ -15,7 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "zpaqfranz_amd", "csrc")
 RT = os.path.join(ROOT, "tests", "cpp", "emu_rt")
-OUT = os.path.join(ROOT, "tests", "_emu")
+ASAN = os.environ.get("ZPQ_EMU_ASAN") == "1"       # AddressSanitizer build (tools/emu/asan.sh): every device allocation gets red zones
+OUT = os.path.join(ROOT, "tests", "_emu_asan" if ASAN else "_emu")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SO = os.path.join(OUT, "libzpaqhip.so")        # (the product's file names, in tests/_emu: the shim libraries link by name)
 
@@ -48,7 +49,8 @@ def _translate(text):
 
 
 def _flags():
-    return ["-O1", "-g0", "-std=c++17", "-fPIC", "-w", "-x", "c++", "-I" + RT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+    san = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1", "-DEMU_ASAN=1"] if ASAN else ["-g0"]
+    return san + ["-O1", "-std=c++17", "-fPIC", "-w", "-x", "c++", "-I" + RT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
             '-DEMU_HOST_CXX="%s"' % CLANG, '-DEMU_RT_DIR="%s"' % RT]
 
 
@@ -97,7 +99,7 @@ def build(verbose=False):
     if errs:
         raise RuntimeError("emulated build failed:\n" + "\n".join(errs))
     if jobs or not os.path.exists(SO):
-        subprocess.check_call([CLANG, "-shared", "-o", SO + ".tmp"] + objs + ["-ldl", "-lpthread"])
+        subprocess.check_call([CLANG, "-shared", "-o", SO + ".tmp"] + objs + ["-ldl", "-lpthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []))
         os.rename(SO + ".tmp", SO)
     # the host layers above the C ABI (zpaqfranz_amd/shim: plain C++), linked against the emulated engine
     shim = os.path.join(ROOT, "zpaqfranz_amd", "shim")

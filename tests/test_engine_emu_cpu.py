@@ -9,7 +9,7 @@ What this is: a logic check of every kernel and every host path of the engine at
 not: the memory system, real concurrency between workgroups, timing -- and it is never the product (zpaqfranz_amd loads
 libzpaqhip.so and fails without a gfx950 device).
 
-All GPU tests pass on the emulator except the five that need torch on a GPU (tools/emu/run_gpu_tests_on_cpu.sh runs
+All GPU tests pass on the emulator (the experimental paths' too) except the five that need torch on a GPU (tools/emu/run_gpu_tests_on_cpu.sh runs
 everything, ~25 minutes on 8 cores).  Here: those that finish in seconds -- the others are deselected by name below."""
 import os
 import subprocess
@@ -87,14 +87,15 @@ def emu_env():
 
 
 def run_file(job):
-    name, extra, timeout = job
+    name, extra, timeout = job[:3]
+    more_env = job[3] if len(job) > 3 else {}
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", name), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--durations=5"] + extra
     for d in NEEDS_TORCH + SLOW:
         if d.startswith(name + "::"):
             cmd += ["--deselect", "tests/" + d]
     t0 = time.time()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, env=emu_env(), timeout=timeout, cwd=ROOT)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(emu_env(), **more_env), timeout=timeout, cwd=ROOT)
         return name, r.returncode, time.time() - t0, r.stdout[-3000:] + r.stderr[-1500:]
     except subprocess.TimeoutExpired as e:
         return name, -1, time.time() - t0, "timeout: " + str(e.stdout)[-2000:]
@@ -109,6 +110,12 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
              ("test_gpu_parity.py", ["-k", "journaling or lz77"], 900),
              ("test_gpu_parity.py", ["-k", "not (fragmenter or sha or dedup or e8e9 or shim or journaling or lz77)"], 900),
              ("test_gpu_round2.py", ["-k", "shim or jidac or resident"], 900), ("test_gpu_round2.py", ["-k", "not (shim or jidac or resident)"], 900)]
+    # the experimental paths (off by default, not yet timed on hardware): candidate tables of the LZ77 parse through the real
+    # entry points, the hand-written radix sort under the suffix array and under the candidate tables
+    exp = {"ZPQ_TEST_EXPERIMENTAL": "1"}
+    jobs += [("test_gpu_lz_cand.py", ["-k", "sequential_table or direct"], 900, exp),
+             ("test_gpu_lz_cand.py", ["-k", "sequential_table"], 900, dict(exp, ZPQ_SORT="own")),
+             ("test_gpu_sa.py", ["-k", "suffix_array_equals_oracle or bwt_equals_oracle"], 900, {"ZPQ_SORT": "own"})]
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
         res = list(ex.map(run_file, jobs))
     report = "\n".join("%s rc=%d %.0f s: %s" % (n, rc, t, out.strip().splitlines()[-1] if out.strip() else "") for n, rc, t, out in res)
@@ -116,4 +123,4 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
     bad = [(n, rc, out) for n, rc, t, out in res if rc != 0]
     assert not bad, "\n\n".join("%s rc=%d\n%s" % b for b in bad)
     passed = sum(int(out.split(" passed")[0].split()[-1]) for _, _, _, out in res if " passed" in out)
-    assert passed >= 110, report
+    assert passed >= 150, report
