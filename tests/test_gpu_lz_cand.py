@@ -87,3 +87,35 @@ def test_own_radix_sort_under_the_suffix_array_and_the_candidate_tables():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", "candidate_table_equals"],
                        capture_output=True, text=True, env=e, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+ARCHIVE_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import datagen
+from zpaqfranz_amd import Engine, engine as E
+eng = Engine(0)
+shared = datagen.mixed(1 << 20, 91)
+files = [("v/a", datagen.text_like(700000, 92)), ("v/b", shared + datagen.binary_like(200000, 93)), ("v/c", shared), ("v/empty", b""),
+         ("v/d", datagen.random_bytes(300001, 94)), ("v/e", bytes(200000) + b"ab" * 40000)]
+out = []
+for method in ("14", "1", "x4,1,4,0,1,15", "2"):
+    arc, st = E.jidac_add(eng, b"", files, 20240101120000, method=method)
+    assert E.jidac_extract(eng, arc) == dict(files), method
+    out.append(hashlib.sha1(arc).hexdigest())
+print("ARCHIVES", " ".join(out))
+"""
+
+
+def test_journaling_add_gives_the_default_archive_under_every_experimental_switch():
+    """End to end through the shim (fragment, dedup, pack, compress, frame, index): with the candidate tables (both parse
+    modes) and with the hand-written sort the archive is the default path's, byte for byte, for -m1 family methods and -m2;
+    every archive is extracted again in the process that wrote it."""
+    def run(extra):
+        e = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", ARCHIVE_SCRIPT % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=1500)
+        assert r.returncode == 0, (extra, r.stdout[-1500:], r.stderr[-2500:])
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("ARCHIVES")][-1]
+    want = run({})
+    for extra in ({"ZPQ_LZ_CAND": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_SORT": "own"}, {"ZPQ_SORT": "own"}):
+        assert run(extra) == want, extra
