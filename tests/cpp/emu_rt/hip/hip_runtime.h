@@ -90,6 +90,10 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 template <class T> static inline hipError_t hipMemcpyFromSymbol(void* d, T* sym, size_t n) { memcpy(d, (const void*)sym, n); return hipSuccess; }
 template <class T> static inline hipError_t hipMemcpyToSymbol(T* sym, const void* s, size_t n) { memcpy((void*)sym, s, n); return hipSuccess; }
+template <class T> static inline hipError_t hipMemcpyToSymbolAsync(T* sym, const void* s, size_t n, size_t off, int, hipStream_t) {
+  if (getenv("EMU_TRACE")) fprintf(stderr, "[emu] %zu bytes to a device symbol, first word %u\n", n, n >= 4 ? *(const unsigned*)s : 0u);
+  memcpy((char*)sym + off, s, n); return hipSuccess;
+}
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }

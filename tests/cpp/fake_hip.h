@@ -68,6 +68,8 @@ static const char* g_emu_launch_error = nullptr;
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+template <class T> static inline hipError_t hipMemcpyToSymbolAsync(T* sym, const void* s, size_t n, size_t off, int, hipStream_t) { memcpy((char*)sym + off, s, n); return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return g_emu_launch_error ? hipErrorUnknown : hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return g_emu_launch_error ? g_emu_launch_error : "emulated HIP error"; }

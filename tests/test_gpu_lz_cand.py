@@ -38,8 +38,9 @@ sys.exit(1 if bad else 0)
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_SEG": "65536"}, {"ZPQ_LZ_SEG": "1048576"}],
-                         ids=["segments", "direct", "seg64k", "seg1m"])
+@pytest.mark.parametrize("env", [{}, {"ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_SEG": "65536"}, {"ZPQ_LZ_SEG": "1048576"},
+                                 {"ZPQ_LZ_CAND_PIPE": "1"}, {"ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_SEG": "65536"}],
+                         ids=["segments", "direct", "seg64k", "seg1m", "pipe", "pipe-direct", "pipe-seg64k"])
 def test_candidate_table_parse_equals_the_oracle(env):
     e = dict(os.environ, ZPQ_LZ_CAND="1", **env)
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, env=e, timeout=600)
@@ -117,5 +118,6 @@ def test_journaling_add_gives_the_default_archive_under_every_experimental_switc
         assert r.returncode == 0, (extra, r.stdout[-1500:], r.stderr[-2500:])
         return [ln for ln in r.stdout.splitlines() if ln.startswith("ARCHIVES")][-1]
     want = run({})
-    for extra in ({"ZPQ_LZ_CAND": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_SORT": "own"}, {"ZPQ_SORT": "own"}):
+    for extra in ({"ZPQ_LZ_CAND": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_SORT": "own"}, {"ZPQ_SORT": "own"},
+                  {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"}):
         assert run(extra) == want, extra

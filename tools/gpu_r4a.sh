@@ -8,7 +8,7 @@ cd $R
 export PYTHONUNBUFFERED=1
 S0=$(date +%s)
 el() { echo "[$(( $(date +%s) - S0 )) s] $*"; }
-ZPQ_TEST_EXPERIMENTAL=1 timeout 500 python -m pytest tests/test_gpu_lz_cand.py -x -q -p no:cacheprovider > gpurun_out/${T}_tests_experimental.log 2>&1
+ZPQ_TEST_EXPERIMENTAL=1 timeout 700 python -m pytest tests/test_gpu_lz_cand.py -x -q -p no:cacheprovider > gpurun_out/${T}_tests_experimental.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/${T}_tests_experimental.log; tail -15 gpurun_out/${T}_tests_experimental.log; el tests
 export ZPQ_BENCH_NO_PLAIN=1
 sw() { # label, env, args
@@ -19,12 +19,17 @@ sw "headline default"            "X=1"                          "--workload sile
 sw "headline cand depth 6"       "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "headline cand depth 10"      "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 40 --pipeline 10"
 sw "headline cand serial"        "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 4 --pipeline 1"
+sw "headline cand+pipe serial"   "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 4 --pipeline 1"
+sw "headline cand+pipe depth 6"  "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 24 --pipeline 6"
+sw "headline cand+pipe depth 10" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 40 --pipeline 10"
+sw "headline cand+pipe depth 16" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 48 --pipeline 16"
 sw "headline cand, own sort"     "ZPQ_LZ_CAND=1 ZPQ_SORT=own"   "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "every byte hashed, default"  "X=1"                          "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "  crossings all parked"      "ZPQ_FRAG_BUDGET=4096 ZPQ_FRAG_RESUME_WAVES=10" "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "  crossings parked at 64K"   "ZPQ_FRAG_BUDGET=65536 ZPQ_FRAG_RESUME_WAVES=6"  "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "dup8 default"                "X=1"                          "--workload dup8_m1"
 sw "dup8 cand"                   "ZPQ_LZ_CAND=1"                "--workload dup8_m1"
+sw "dup8 cand+pipe"              "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload dup8_m1"
 sw "text_m2 default"             "X=1"                          "--workload text_m2"
 sw "text_m2 own sort"            "ZPQ_SORT=own"                 "--workload text_m2"
 el done

@@ -518,6 +518,8 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
   return -1;
 }
 
+#include "lz77_pipe.inc"       // lz_walk_pipe (experimental: the candidate walk software-pipelined), lz_walk_sel
+
 
 // ---- table state at every segment start --------------------------------------------------------------
 struct CopyJob { const u32* src; u32* dst; u32 words; };   // src == nullptr: zero fill
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restric
     __builtin_amdgcn_wave_barrier();
     TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
     u32 cur = S.x0, lit = 0;
-    lz_walk<NB, false, CAND>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
+    if constexpr (CAND) lz_walk_sel<NB, false, true>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
+    else lz_walk<NB, false, false>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
     if (lane == 0) {
       S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
       S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
@@ -651,7 +654,8 @@ __global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restr
   bs.in = (__attribute__((address_space(1))) const u8*)J.in;
   bs.acc = 0; bs.accbits = 0; bs.bytepos = 0; bs.gap_start = 0; bs.rb = J.rb; bs.overflow = 0;
   u32 cur = 0, lit = 0;
-  lz_walk<NB, true, CAND>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
+  if constexpr (CAND) lz_walk_sel<NB, true, true>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
+  else lz_walk<NB, true, false>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
   const u32 bytes = bs.finish(J.n, lane);
   const unsigned long long ov = __ballot(bs.overflow != 0);
   if (lane == 0) { J.result[0] = sink.n; J.result[1] = bytes; J.result[2] = (ov != 0 || bytes > J.out_cap) ? 1u : 0u; }
@@ -679,7 +683,8 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
   if (cur == S.x0 && lit == 0) hit = -2;                           // in step from the first position
   else if (cur < S.x1) {
     SpecList sl{S.tpos, S.tlen, S.state[0], 0};
-    hit = lz_walk<NB, false, CAND>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+    if constexpr (CAND) hit = lz_walk_sel<NB, false, true>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+    else hit = lz_walk<NB, false, false>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
   }
   if (lane == 0) {
     S.seam[0] = sink.n < sink.cap ? sink.n : sink.cap;
@@ -737,7 +742,9 @@ __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restr
     // exact re-walk (rare: the previous segment never got back in step)
     SpecList sl{S.tpos, S.tlen, ns, 0};
     u32* table = k ? segs[J.seg0 + k - 1].work : S.work;
-    const int hit = lz_walk<NB, false, CAND>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    int hit;
+    if constexpr (CAND) hit = lz_walk_sel<NB, false, true>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    else hit = lz_walk<NB, false, false>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
     T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
     __builtin_amdgcn_wave_barrier();
     if (hit >= 0) { append(0, (u32)hit + 1, ns); cur = S.state[1]; lit = S.state[2]; }
@@ -1130,6 +1137,9 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     }
     int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)(d_tab + ((cand_words + 63) & ~(size_t)63)), cand_sort_temp);
     if (rc) return rc;
+    // which candidate walk the kernels use (lz77_pipe.inc): the switch lives in device memory, the plain kernels never read it
+    static const u32 pipe_on = [] { const char* e = getenv("ZPQ_LZ_CAND_PIPE"); return e && atoi(e) != 0 ? 1u : 0u; }();
+    ZPQ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lz_cand_pipe), &pipe_on, sizeof pipe_on, 0, hipMemcpyHostToDevice, st));
   }
   // 1. table states at the segment starts: pristine[k] = pristine[k-1] + inserts of segment k-1
   if (!cand) {
