@@ -116,6 +116,9 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
     jobs += [("test_gpu_lz_cand.py", ["-k", "sequential_table or direct"], 900, exp),
              ("test_gpu_lz_cand.py", ["-k", "sequential_table"], 900, dict(exp, ZPQ_SORT="own")),
              ("test_gpu_sa.py", ["-k", "suffix_array_equals_oracle or bwt_equals_oracle"], 900, {"ZPQ_SORT": "own"})]
+    # row (e): the journaling add sharded over two PROCESSES (gloo, world size 2), each with its own emulated engine, gives
+    # the single-GPU archive
+    jobs.append(("test_sharded_add.py", ["-k", "flags0 or flags2 or failing"], 900))
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
         res = list(ex.map(run_file, jobs))
     report = "\n".join("%s rc=%d %.0f s: %s" % (n, rc, t, out.strip().splitlines()[-1] if out.strip() else "") for n, rc, t, out in res)
