@@ -29,6 +29,7 @@ static inline EmuIdx emu_thread_idx() { return EmuIdx{(unsigned)emu::g_tid, 0, 0
 #define threadIdx (emu_thread_idx())
 #define warpSize 64
 #define __ballot(p) emu::ballot((p), __LINE__)
+#define __builtin_amdgcn_ballot_w64(p) emu::ballot((p), __LINE__)
 #define __any(p) emu::any((p), __LINE__)
 #define __all(p) emu::all((p), __LINE__)
 #define __shfl(v, src, ...) emu::shfl((v), (int)(src), __LINE__)

@@ -58,6 +58,7 @@ static inline unsigned long long emu_fnv64(const std::string& s) { unsigned long
 static inline std::string emu_self_path() { Dl_info i; return dladdr((void*)&emu_fnv64, &i) && i.dli_fname ? i.dli_fname : ""; }
 static inline hiprtcResult hiprtcCompileProgram(hiprtcProgram p, int, const char**) {
   std::string src = p->src;
+  if (getenv("EMU_TRACE")) fprintf(stderr, "[emu] hiprtc: %.60s ...\n", src.substr(0, src.find("\n#define ZH_LDS") == std::string::npos ? 60 : src.find("\n#define ZH_LDS")).c_str());
   // the one piece of AMD assembly in generated source: v_writelane (cm_spec_src.inc ZWL) -> the same effect in C
   {
     const size_t k = src.find("#define ZWL(");

@@ -27,7 +27,7 @@ def build(L, header, path):
     n = C.c_size_t()
     assert L.zpq_cm_spec_source_text(header, len(header), buf, 1 << 20, C.byref(n)) == 0
     src = buf.raw[: n.value].decode()
-    old, = [ln for ln in src.splitlines() if ln.startswith("#define ZWL(")]
+    old, = [ln for ln in src.splitlines() if ln.startswith("#define ZWL(") and "v_writelane" in ln]
     src = src.replace(old, "#define ZWL(v, L, p) { const int zwl_ = __builtin_amdgcn_readfirstlane((int)(v)); if ((int)(threadIdx.x & 63) == (L)) p = (decltype(p))zwl_; }")
     cpp = os.path.join(path, "cm_emu.cpp")
     with open(cpp, "w") as f:

@@ -8,7 +8,7 @@ cd $R
 export PYTHONUNBUFFERED=1
 S0=$(date +%s)
 el() { echo "[$(( $(date +%s) - S0 )) s] $*"; }
-ZPQ_TEST_EXPERIMENTAL=1 timeout 700 python -m pytest tests/test_gpu_lz_cand.py -x -q -p no:cacheprovider > gpurun_out/${T}_tests_experimental.log 2>&1
+ZPQ_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_lz_cand.py tests/test_gpu_cm_groups.py -x -q -p no:cacheprovider > gpurun_out/${T}_tests_experimental.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/${T}_tests_experimental.log; tail -15 gpurun_out/${T}_tests_experimental.log; el tests
 export ZPQ_BENCH_NO_PLAIN=1
 sw() { # label, env, args
@@ -30,6 +30,9 @@ sw "  crossings parked at 64K"   "ZPQ_FRAG_BUDGET=65536 ZPQ_FRAG_RESUME_WAVES=6"
 sw "dup8 default"                "X=1"                          "--workload dup8_m1"
 sw "dup8 cand"                   "ZPQ_LZ_CAND=1"                "--workload dup8_m1"
 sw "dup8 cand+pipe"              "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload dup8_m1"
+sw "cm_m5 default"               "X=1"                          "--workload cm_m5"
+sw "cm_m5 lane groups"           "ZPQ_CM_GROUPS=1"              "--workload cm_m5"
+sw "cm_m5 lane groups, 16 waves" "ZPQ_CM_GROUPS=1 ZPQ_CM_WAVES=16" "--workload cm_m5"
 sw "text_m2 default"             "X=1"                          "--workload text_m2"
 sw "text_m2 own sort"            "ZPQ_SORT=own"                 "--workload text_m2"
 el done

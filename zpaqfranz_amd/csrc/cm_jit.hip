@@ -180,8 +180,31 @@ struct zpq_cm_spec {
   hipModule_t mod;
   hipFunction_t enc, dec;
   u32 waves;          // ZW the module was compiled for (workgroup = waves * 64 threads at most)
+  u32 groups;         // blocks per wave (1 unless ZPQ_CM_GROUPS)
   bool h_lds;
 };
+
+// EXPERIMENTAL (ZPQ_CM_GROUPS=1; verified on the CPU emulator only): lanes per block when a wave codes several blocks at once --
+// the next power of two above the component count; an SSE stage keeps its 32-entry row across 32 lanes.  64 = one block per wave.
+// Every block keeps its H[] in LDS (hh <= 10) beside the 86 KiB of tables, so the blocks per compute unit are bounded
+// whatever the grouping: groups are only made as long as eight waves (two per SIMD) still fit.
+static u32 group_stride(u32 n, u32 nsse, u32 hh) {
+  static const bool on = [] { const char* e = getenv("ZPQ_CM_GROUPS"); return e && atoi(e) != 0; }();
+  if (!on) return 64;
+  u32 zs = 2;
+  while (zs < n) zs <<= 1;
+  if (nsse && zs < 32) zs = 32;
+  if (hh <= 10) while (zs < 64 && (160u * 1024u - 1024u - 88064u) / ((64u / zs) * (4u << hh)) < 8u) zs <<= 1;
+  return zs > 64 ? 64 : zs;
+}
+
+// waves per workgroup the kernels are compiled for: 16 (128 registers per lane); 8 where more registers are needed -- the
+// one-bit-ahead values (ZPQ_CM_SPEC), several blocks per wave (every wave-uniform value becomes a register per lane; the
+// blocks per compute unit stay what they were with two blocks per wave)
+static u32 spec_waves(u32 zs) {
+  if (const char* e = getenv("ZPQ_CM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return (u32)v; }
+  return getenv("ZPQ_CM_SPEC") || zs < 64 ? 8 : 16;
+}
 
 // The generated source for one header (also used by the build-time cache warmer and the tests).
 int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* why) {
@@ -238,11 +261,13 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   flush_group();
   if (nmix > 8 || nsse > 4) { *why = "more mixers / SSE stages than the wave coder keeps in registers"; return ZPQ_ERR_METHOD; }
   const bool h_lds = P.hh <= 10;
-  // waves per workgroup: the tables (86 KiB) are shared, H[] is per wave; one workgroup per compute unit
-  u32 waves = getenv("ZPQ_CM_SPEC") ? 8 : 16;      // (the one-bit-ahead values need the registers of a 512-thread bound)
-  while (waves > 1 && 88064u + (h_lds ? waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
+  const u32 zs = group_stride(P.n, nsse, P.hh);            // lanes per block (64: one block per wave)
+  // waves per workgroup: the tables (86 KiB) are shared, H[] is per block; one workgroup per compute unit
+  u32 waves = spec_waves(zs);
+  while (waves > 1 && 88064u + (h_lds ? waves * (64u / zs) * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
   std::string s;
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
+  if (zs != 64) s += "#define ZS " + itos(zs) + "\n";
   s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
   s += "#define ZGUARD (1u << 26)\n";
   if (getenv("ZPQ_CM_PROGRESS")) s += "#define ZPROGRESS 1\n";
@@ -255,7 +280,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   // for a 100 KB block, 448 against 400 ms for 2048 blocks): the ~80 instructions it adds per bit cost more than the
   // waits it removes -- most of a bit's waiting is LDS latency on the dependent chain, not the round of loads.  Kept
   // behind ZPQ_CM_SPEC=1 for tuning.
-  s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") ? "1" : "0") + "\n";
+  s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") && zs == 64 ? "1" : "0") + "\n";
   // ZPQ_CM_PRE_LATE=1: the second nibble's bucket is fetched when the nibble is known (one line per component and
   // nibble) instead of both candidates one bit early (two lines): less memory traffic, one exposed round trip per byte
   s += std::string("#define ZPRE_LATE ") + (getenv("ZPQ_CM_PRE_LATE") ? "1" : "0") + "\n";
@@ -327,8 +352,13 @@ int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out) {
     return zpq_fail(ctx, ZPQ_ERR_HIP, "specialised coder: kernels missing from the module");
   }
   k->h_lds = P.hh <= 10;
-  k->waves = getenv("ZPQ_CM_SPEC") ? 8 : 16;
-  while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
+  {
+    u32 nsse = 0;
+    for (const std::vector<u8>& c : P.comps) nsse += c[0] == SSE;
+    k->groups = 64u / group_stride(P.n, nsse, P.hh);
+  }
+  k->waves = spec_waves(64u / k->groups);
+  while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * k->groups * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
   std::lock_guard<std::mutex> lk(g_mu);
   auto ins = g_mods.insert({{ctx->device, key}, k});
   if (!ins.second) { (void)hipModuleUnload(k->mod); delete k; }
@@ -343,10 +373,11 @@ int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void*
   // one workgroup per compute unit (the tables fill more than half of its LDS); as many waves per workgroup as it
   // takes to seat every block, at most what the module was compiled for
   const u32 cus = (u32)ctx->cu_count;
-  u32 w = (njobs + cus - 1) / cus;
+  const u32 seats = (njobs + k->groups - 1) / k->groups;      // waves' worth of blocks
+  u32 w = (seats + cus - 1) / cus;
   if (w < 1) w = 1;
   if (w > k->waves) w = k->waves;
-  u32 grid = (njobs + w - 1) / w;
+  u32 grid = (seats + w - 1) / w;
   if (grid > cus) grid = cus;
   void* args[] = {(void*)&d_jobs, (void*)&njobs, (void*)&d_counter, (void*)&d_tables};
   ZpqProfScope prof(ctx, encode ? "cm_spec_encode" : "cm_spec_decode", st);
