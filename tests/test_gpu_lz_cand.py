@@ -119,5 +119,6 @@ def test_journaling_add_gives_the_default_archive_under_every_experimental_switc
         return [ln for ln in r.stdout.splitlines() if ln.startswith("ARCHIVES")][-1]
     want = run({})
     for extra in ({"ZPQ_LZ_CAND": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_SORT": "own"}, {"ZPQ_SORT": "own"},
-                  {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"}):
+                  {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1"}, {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"},
+                  {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_SHARED_SORT": "1"}):
         assert run(extra) == want, extra

@@ -62,6 +62,7 @@ SETTINGS = [
     ("cand-long-runs", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_LZ_CAND_LONG": "50"}, 6, A3, None),   # ... long runs handed to whole waves
     ("cand-pipe-segments", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_SEG": "65536"}, 8, A3, None),   # the candidate walk software-pipelined (lz77_pipe.inc)
     ("cand-pipe-direct", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"}, 6, A3, None),
+    ("cand-shared-sort-arena", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_SHARED_SORT": "1", "ZPQ_LZ_SEG": "65536"}, 4, A3[:2], None),
     ("cand-own-sort", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_SORT": "own"}, 2, A3[:1], ["mixed", "tiny"]),   # ... over the hand-written radix sort
 ]
 

@@ -23,6 +23,8 @@ sw "headline cand+pipe serial"   "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload 
 sw "headline cand+pipe depth 6"  "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "headline cand+pipe depth 10" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 40 --pipeline 10"
 sw "headline cand+pipe depth 16" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 48 --pipeline 16"
+sw "headline cand+pipe, shared sort arena, depth 16" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1 ZPQ_LZ_CAND_SHARED_SORT=1" "--workload silesia_x256_m1 --steps 48 --pipeline 16"
+sw "headline cand+pipe, shared sort arena, depth 24" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1 ZPQ_LZ_CAND_SHARED_SORT=1" "--workload silesia_x256_m1 --steps 72 --pipeline 24"
 sw "headline cand, own sort"     "ZPQ_LZ_CAND=1 ZPQ_SORT=own"   "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "every byte hashed, default"  "X=1"                          "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "  crossings all parked"      "ZPQ_FRAG_BUDGET=4096 ZPQ_FRAG_RESUME_WAVES=10" "--workload silesia_x256_m1 --steps 12 --no-twins"

@@ -27,6 +27,7 @@
 // fibres in lockstep, the wave intrinsics emulated) and checks the walk and the segment speculation against the oracle on the CPU.
 #ifndef ZPQ_EMU_WALK_ONLY
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
 
 #include <rocprim/device/device_radix_sort.hpp>     // (only the experimental candidate-table path sorts)
@@ -973,6 +974,15 @@ static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
 // Candidate tables of a batch: keys of every position, one sort, one sweep.  `buf` holds two key and two value arrays
 // (24 bytes per position) followed by `temp_bytes` of temporary storage for the sort; every job's `cand` pointer must have
 // room for n << lb words.
+// EXPERIMENTAL (ZPQ_LZ_CAND_SHARED_SORT=1, with ZPQ_LZ_CAND=1): keys, values and the sort's temporary -- 24+ bytes per position,
+// 5 GB for a job of the headline -- are needed from the keys kernel to the end of the sweep only, a few milliseconds of
+// chip-filling kernels that gain nothing from overlapping with another job's.  One arena per DEVICE then serves every
+// context of the process instead of one per context (13 -> 8 GB per job in flight): a user makes its stream wait for the
+// event the previous user recorded behind its sweep, enqueues, records the event anew.
+struct CandArena { std::mutex mu; void* buf = nullptr; size_t cap = 0; hipEvent_t last = nullptr; };
+static CandArena g_cand_arena[64];
+static bool cand_shared_sort() { static const bool on = [] { const char* e = getenv("ZPQ_LZ_CAND_SHARED_SORT"); return e && atoi(e) != 0; }(); return on; }
+
 static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& cjobs, CandJob* d_cjobs, u64 positions, u32 max_n, u8* buf,
                       size_t temp_bytes) {
   const size_t nj = cjobs.size();
@@ -1053,7 +1063,8 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   if (cand) {
     ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, cand_sort_temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)cand_positions, 0u, 64u, st));
     cand_sort_temp = std::max(cand_sort_temp, zpq_radix_scratch_words((size_t)cand_positions) * 4);
-    table_words = ((cand_words + 63) & ~(size_t)63) + (size_t)cand_positions * 6 + 64 + (cand_sort_temp + 3) / 4 + 64;
+    table_words = ((cand_words + 63) & ~(size_t)63) + 64;
+    if (!cand_shared_sort()) table_words += (size_t)cand_positions * 6 + 64 + (cand_sort_temp + 3) / 4;
   }
   u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
   u32* d_tok = (u32*)zpq_scratch(ctx, 1, tok_words * 4 + 256);
@@ -1135,8 +1146,27 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       Cj.c = hs[hj[i].seg0].c; Cj.pos0 = pos0; Cj.cand = hs[hj[i].seg0].work; Cj.lb = (u32)jobs[lo + i].args[4]; Cj.pad = 0;
       pos0 += jobs[lo + i].n;
     }
-    int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)(d_tab + ((cand_words + 63) & ~(size_t)63)), cand_sort_temp);
-    if (rc) return rc;
+    if (cand_shared_sort() && ctx->device >= 0 && ctx->device < 64) {
+      CandArena& A = g_cand_arena[ctx->device];
+      std::lock_guard<std::mutex> lk(A.mu);
+      const size_t need = (size_t)cand_positions * 24 + 512 + cand_sort_temp + 256;
+      if (A.cap < need) {
+        if (A.last) ZPQ_HIP(ctx, hipEventSynchronize(A.last));        // nobody is still sorting in the old arena
+        if (A.buf) (void)hipFree(A.buf);
+        A.buf = nullptr; A.cap = 0;
+        const size_t cap = need + need / 8;
+        if (hipMalloc(&A.buf, cap) != hipSuccess) { A.buf = nullptr; return zpq_fail(ctx, ZPQ_ERR_NOMEM, "candidate sort arena (%zu MiB)", cap >> 20); }
+        A.cap = cap;
+      }
+      if (!A.last) ZPQ_HIP(ctx, hipEventCreateWithFlags(&A.last, hipEventDisableTiming));
+      else ZPQ_HIP(ctx, hipStreamWaitEvent(st, A.last, 0));
+      const int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)A.buf, cand_sort_temp);
+      if (rc) return rc;
+      ZPQ_HIP(ctx, hipEventRecord(A.last, st));
+    } else {
+      int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)(d_tab + ((cand_words + 63) & ~(size_t)63)), cand_sort_temp);
+      if (rc) return rc;
+    }
     // which candidate walk the kernels use (lz77_pipe.inc): the switch lives in device memory, the plain kernels never read it
     static const u32 pipe_on = [] { const char* e = getenv("ZPQ_LZ_CAND_PIPE"); return e && atoi(e) != 0 ? 1u : 0u; }();
     ZPQ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lz_cand_pipe), &pipe_on, sizeof pipe_on, 0, hipMemcpyHostToDevice, st));
