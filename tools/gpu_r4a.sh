@@ -15,16 +15,20 @@ sw() { # label, env, args
   local out; out=$(env $2 timeout 300 python bench.py --no-cpu-baseline $3 2>gpurun_out/${T}_last.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print(d['value'], d['ms_per_step'], d.get('ms_per_step_serial'), d.get('steps_in_flight'), {a:b for a,b in d.items() if a.startswith('verified')}, {a:k[a] for a in list(k)[:8]})" 2>&1 | tail -1)
   echo "$1 | $2 | $3 | $out" | tee -a gpurun_out/${T}_sweep.txt; }
 : > gpurun_out/${T}_sweep.txt
+# (most informative first: the call may be cut short)
 sw "headline default"            "X=1"                          "--workload silesia_x256_m1 --steps 24"
-sw "headline cand depth 6"       "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 24 --pipeline 6"
-sw "headline cand depth 10"      "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 40 --pipeline 10"
-sw "headline cand serial"        "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 4 --pipeline 1"
-sw "headline cand+pipe serial"   "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 4 --pipeline 1"
 sw "headline cand+pipe depth 6"  "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "headline cand+pipe depth 10" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 40 --pipeline 10"
 sw "headline cand+pipe depth 16" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 48 --pipeline 16"
+sw "headline cand depth 6"       "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "headline cand+pipe, shared sort arena, depth 16" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1 ZPQ_LZ_CAND_SHARED_SORT=1" "--workload silesia_x256_m1 --steps 48 --pipeline 16"
 sw "headline cand+pipe, shared sort arena, depth 24" "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1 ZPQ_LZ_CAND_SHARED_SORT=1" "--workload silesia_x256_m1 --steps 72 --pipeline 24"
+sw "cm_m5 default"               "X=1"                          "--workload cm_m5"
+sw "cm_m5 lane groups"           "ZPQ_CM_GROUPS=1"              "--workload cm_m5"
+sw "cm_m5 lane groups, 16 waves" "ZPQ_CM_GROUPS=1 ZPQ_CM_WAVES=16" "--workload cm_m5"
+sw "headline cand serial"        "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 4 --pipeline 1"
+sw "headline cand+pipe serial"   "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload silesia_x256_m1 --steps 4 --pipeline 1"
+sw "headline cand depth 10"      "ZPQ_LZ_CAND=1"                "--workload silesia_x256_m1 --steps 40 --pipeline 10"
 sw "headline cand, own sort"     "ZPQ_LZ_CAND=1 ZPQ_SORT=own"   "--workload silesia_x256_m1 --steps 24 --pipeline 6"
 sw "every byte hashed, default"  "X=1"                          "--workload silesia_x256_m1 --steps 12 --no-twins"
 sw "  crossings all parked"      "ZPQ_FRAG_BUDGET=4096 ZPQ_FRAG_RESUME_WAVES=10" "--workload silesia_x256_m1 --steps 12 --no-twins"
@@ -32,9 +36,6 @@ sw "  crossings parked at 64K"   "ZPQ_FRAG_BUDGET=65536 ZPQ_FRAG_RESUME_WAVES=6"
 sw "dup8 default"                "X=1"                          "--workload dup8_m1"
 sw "dup8 cand"                   "ZPQ_LZ_CAND=1"                "--workload dup8_m1"
 sw "dup8 cand+pipe"              "ZPQ_LZ_CAND=1 ZPQ_LZ_CAND_PIPE=1" "--workload dup8_m1"
-sw "cm_m5 default"               "X=1"                          "--workload cm_m5"
-sw "cm_m5 lane groups"           "ZPQ_CM_GROUPS=1"              "--workload cm_m5"
-sw "cm_m5 lane groups, 16 waves" "ZPQ_CM_GROUPS=1 ZPQ_CM_WAVES=16" "--workload cm_m5"
 sw "text_m2 default"             "X=1"                          "--workload text_m2"
 sw "text_m2 own sort"            "ZPQ_SORT=own"                 "--workload text_m2"
 el done
