@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "zpaqfranz_amd", "csrc")
 RT = os.path.join(ROOT, "tests", "cpp", "emu_rt")
 ASAN = os.environ.get("ZPQ_EMU_ASAN") == "1"       # AddressSanitizer build (tools/emu/asan.sh): every device allocation gets red zones
-OUT = os.path.join(ROOT, "tests", "_emu_asan" if ASAN else "_emu")
+COUNT = os.environ.get("ZPQ_EMU_COUNT") == "1"     # event counters of the LZ77 walk compiled in (tools/emu/lz_walk_counts.py)
+OUT = os.path.join(ROOT, "tests", "_emu_asan" if ASAN else "_emu_count" if COUNT else "_emu")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SO = os.path.join(OUT, "libzpaqhip.so")        # (the product's file names, in tests/_emu: the shim libraries link by name)
 
@@ -50,6 +51,8 @@ def _translate(text):
 
 def _flags():
     san = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1", "-DEMU_ASAN=1"] if ASAN else ["-g0"]
+    if COUNT:
+        san = san + ["-DZPQ_LZ_COUNT=1"]
     return san + ["-O1", "-std=c++17", "-fPIC", "-w", "-x", "c++", "-I" + RT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
             '-DEMU_HOST_CXX="%s"' % CLANG, '-DEMU_RT_DIR="%s"' % RT]
 

@@ -124,11 +124,22 @@ __device__ __forceinline__ u32 byte32(const u32x4& lo, const u32x4& hi, u32 idx)
   return ((w & 4 ? b : a) >> ((idx & 3) * 8)) & 255u;
 }
 
+// event counters of the walk (tools/emu/lz_walk_counts.py builds the emulated engine with -DZPQ_LZ_COUNT): [0] windows looked
+// up, [1] windows that only insert, [2] tokens, [3] tokens re-evaluated exactly (a candidate reached the 32-byte cap),
+// [4] extension rounds of those, [5] whole-wave compare rounds, [6] pipeline restarts, [7] windows of the pipelined walk
+#ifdef ZPQ_LZ_COUNT
+__device__ unsigned long long g_lzcount[8];
+#define LZ_C(i) ((void)(lane_id() == 0 ? g_lzcount[i] += 1 : 0ull))
+extern "C" void zpq_debug_lzcount(unsigned long long out[8], int reset) { for (int i = 0; i < 8; ++i) { out[i] = g_lzcount[i]; if (reset) g_lzcount[i] = 0; } }
+#else
+#define LZ_C(i) ((void)0)
+#endif
 // Whole-wave compare for long matches: 512 bytes per step.  All arguments wave-uniform.
 __device__ __forceinline__ u32 coop_match_len(g_cu8* in, u32 p, u32 q, u32 limit, u32 from = 0) {
   const u32 lane = (u32)lane_id();
   u32 base = from;
   while (base < limit) {
+    LZ_C(5);
     u32 o = base + lane * 8;
     u64 x = o < limit ? (load8(in + p + o) ^ load8(in + q + o)) : 1ull;
     unsigned long long m = __ballot(x != 0);
@@ -285,6 +296,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
     const u32 val = (q << C.checkbits) | (b3 & mask);                      // :6436
     const u32 grp = h & ~C.bucket;
     const bool look = inb && cur < wend;   // windows swallowed by a match only insert
+    LZ_C(cur < wend ? 0 : 1);
 
     LZ_T(0);
     u32 ent[NB];
@@ -417,6 +429,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
         // candidates at once (64/NB lanes each, 8 bytes per lane and step), anything still
         // unresolved after 4 steps by whole-wave compares.
         const u32 i = cur;
+        LZ_C(3);
         const u32 lim_i = n - i < kMaxMatch ? n - i : kMaxMatch;
         u32 xp[NB], xl[NB];
 #pragma unroll
@@ -429,6 +442,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
           for (int k = 0; k < NB; ++k) if (g == (u32)k) { myp = xp[k]; open = xp[k] != kNoCand && xl[k] == kCap && kCap < lim_i; }
           u32 found = 0xffffffffu;                   // exact length once known (per candidate group)
           for (u32 step = 0; step < 4 && __ballot(open); ++step) {
+            LZ_C(4);
             const u32 o = kCap + step * 8 * W + 8 * sub;
             u32 mine = 0xffffffffu;
             if (open) {
@@ -477,6 +491,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
         tlen = f ? l1 : l0; toff = f ? o1 : o0;
       }
       if (tlen) {
+        LZ_C(2);
         if (DIRECT) bits->match(cur, tlen, toff, lane);
         else if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
         ++sink.n;
