@@ -10,7 +10,8 @@ not: the memory system, real concurrency between workgroups, timing -- and it is
 libzpaqhip.so and fails without a gfx950 device).
 
 All GPU tests pass on the emulator (the experimental paths' too) except the five that need torch on a GPU (tools/emu/run_gpu_tests_on_cpu.sh runs
-everything, ~25 minutes on 8 cores).  Here: those that finish in seconds -- the others are deselected by name below."""
+everything, ~25 minutes on 8 cores).  Here: those that finish in seconds -- the others are deselected by name below -- plus
+the experimental switches' own tests and the two-process sharded add (about 170 tests, ~2 minutes on 8 cores)."""
 import os
 import subprocess
 import sys
