@@ -757,7 +757,7 @@ def main_text_m2(a, rank, world, local, dev):
                "suffix_array_ms_per_step": round(sa_ms, 2),
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                "roofline": roof(dom) if dom else None,
-               "roofline_all": [roof(k) for k in sorted((k for k in kern if k in alg), key=lambda k: -kern[k][1])]}
+               **({"roofline_all": [roof(k) for k in sorted((k for k in kern if k in alg), key=lambda k: -kern[k][1])]} if a.roofline_all else {})}
         if world == 1 and not a.no_verify:
             # every block back through the device decoder (stored SHA-1 checked), bytes compared with the input
             framed, p_out = [], 0
@@ -921,6 +921,42 @@ def main_cm_m5(a, rank, world, local, dev):
     eng.close()
 
 
+def compact_line(d, top=6):
+    """A nested workload's JSON line cut down to what a reader of the ONE line needs (the driver's record keeps only the
+    tail of a long line): the contract keys, the verification flags, the dominant kernel's roofline and the CPU baseline.
+    The full line goes to stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_serial", "steps_in_flight", "scaling", "dtype",
+            "data", "input_GBps", "output_GBps", "input_MBps", "sha256_mismatches", "error", "rc", "skipped", "wall_s")
+    out = {k: d[k] for k in keep if k in d}
+    out.update({k: v for k, v in d.items() if k.startswith("verified") or k.endswith("_failures") or k == "method_expansion_checked"})
+    if "config" in d:
+        out["config"] = {k: v for k, v in d["config"].items() if k in ("workload", "input_bytes", "files", "blocks", "method", "ratio", "unique_bytes", "out_bytes")}
+    for rk in ("roofline", "roofline_chip_filling"):
+        r = d.get(rk)
+        if r:
+            out[rk] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "waves") if k in r}
+    if d.get("roofline_end_to_end"):
+        out["roofline_end_to_end"] = {k: d["roofline_end_to_end"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_step")}
+    if d.get("kernels_ms_per_step"):
+        out["kernels_ms_per_step"] = dict(list(d["kernels_ms_per_step"].items())[:top])
+    cb = d.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
+    for k in ("blake3_verify", "no_fold", "every_byte_hashed"):
+        if isinstance(d.get(k), dict):
+            out[k] = {kk: vv for kk, vv in d[k].items() if kk != "note"}
+    return out
+
+
+def summary_row(d):
+    """[value, ms_per_step, verified, roofline.frac, cpu_baseline.value] of one workload line"""
+    if "value" not in d:
+        return [None, None, False, None, None]
+    flags = [v for k, v in d.items() if k.startswith("verified") and isinstance(v, bool)]
+    return [d.get("value"), d.get("ms_per_step"), bool(flags) and all(flags), (d.get("roofline") or {}).get("frac"),
+            (d.get("cpu_baseline") or {}).get("value")]
+
+
 def run_other_workloads(a):
     """dup8_m1 (config 4 at 1-GPU size), extract_m1 (config 5), text_m2 (config 3) and cm_m5 (context-mixing stress), each
     as `bench.py --workload X` in a fresh process with its default size; returns {workload: its JSON line or an error}."""
@@ -934,8 +970,9 @@ def run_other_workloads(a):
             out[w] = {"skipped": "time budget for the nested workloads used up"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--gpus", "1"]
-        if a.no_cpu_baseline:
-            cmd.append("--no-cpu-baseline")
+        for flag, on in (("--no-cpu-baseline", a.no_cpu_baseline), ("--no-verify", a.no_verify)):
+            if on:
+                cmd.append(flag)
         t0 = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
@@ -948,6 +985,19 @@ def run_other_workloads(a):
         except subprocess.TimeoutExpired:
             out[w] = {"error": "timed out after %.0f s" % left}
     return out
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (what the driver's torch.distributed.run
+    command line does), pass their output through and leave with their return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def cpu_baseline(mode, argv, blobs):
@@ -989,9 +1039,15 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every corpus member (debug only)")
     ap.add_argument("--pipeline", type=int, default=None, help="steps in flight (each on its own engine context); 1 = strictly serial")
     ap.add_argument("--shared-corpus", action="store_true",
-                    help="multi-GPU, strong scaling: ONE Silesia x copies corpus split by file range across the ranks (rank r holds copies "
-                         "[r*copies/N, (r+1)*copies/N)): every fragment of ranks > 0 duplicates one of rank 0, the global first-occurrence "
-                         "exchange carries the whole dedup; the stitched archive equals the single-GPU one")
+                    help="multi-GPU, strong scaling (the DEFAULT with more than one rank: BASELINE's metric is ONE Silesia x256 on 1/2/4/8 "
+                         "GPUs): one corpus split by file range across the ranks (rank r holds copies [r*copies/N, (r+1)*copies/N)): every "
+                         "fragment of ranks > 0 duplicates one of rank 0, the global first-occurrence exchange carries the whole dedup; the "
+                         "stitched archive equals the single-GPU one")
+    ap.add_argument("--own-corpus", action="store_true",
+                    help="multi-GPU, weak scaling: every rank owns a corpus of its own (different seed), N times the single-GPU job")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="test only (runs without a GPU): the ranks meet over gloo, agree on the world size and rank 0 prints a line with n_gpus")
+    ap.add_argument("--roofline-all", action="store_true", help="also print the roofline block of every timed kernel (long)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); gloo runs the collectives through the host: functional test only")
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses GPU 0 (with --dist-backend gloo)")
     ap.add_argument("--force-collectives", action="store_true", help="single rank: run the multi-rank code path (RCCL all-gathers with world size 1)")
@@ -1010,8 +1066,23 @@ def main():
     if os.environ.get("ZPQ_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack and exit if the run takes too long
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["ZPQ_BENCH_WATCHDOG"]), exit=True)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                 # N ranks under torch.distributed.run; does not return
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): the line would carry the wrong n_gpus" % (a.gpus, world))
+    if a.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([1 << rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"n_gpus": dist.get_world_size(), "ranks_seen": int(t.item()), "rendezvous_only": True,
+                              "scaling": "weak" if a.own_corpus else "strong"}))
+        dist.destroy_process_group()
+        return
     if run_all and world == 1 and not a.force_collectives:
         # every workload in its own process (its own HIP context: what one leaves in HBM never shrinks the batches of the
         # next), this process only stitches their JSON lines: the headline stays config 2, the rest nests under "workloads"
@@ -1034,8 +1105,25 @@ def main():
             sys.stderr.write(r.stderr[-2000:])
             raise SystemExit("the headline workload failed (rc %d)" % r.returncode)
         res = json.loads(lines[-1])
-        res["workloads"] = run_other_workloads(a)
+        others = run_other_workloads(a)
+        for w, d in others.items():                     # the full lines: stderr (the ONE stdout line stays short enough to be read whole)
+            sys.stderr.write("[bench.py] %s: %s\n" % (w, json.dumps(d)))
+        # order matters to a reader who only sees the END of the line: details first, then the headline's own roofline /
+        # cpu_baseline, the every-byte-hashed figure and one row per workload
+        tail = {k: res.pop(k) for k in ("roofline_chip_filling", "roofline_longest_chain", "roofline_end_to_end", "roofline", "cpu_baseline",
+                                         "every_byte_hashed") if k in res}
+        res["workloads"] = {w: compact_line(d) for w, d in others.items()}
+        res.update(tail)
+        if "every_byte_hashed" in res:
+            res["value_every_byte_hashed"] = res["every_byte_hashed"]["value"]
+        res["workloads_summary"] = {"columns": ["value", "ms_per_step", "verified", "roofline.frac", "cpu_baseline.value"],
+                                    res["config"]["workload"]: summary_row(res), **{w: summary_row(d) for w, d in others.items()}}
+        failed = [w for w, d in others.items() if "value" not in d]
+        if failed:
+            res["failed_workloads"] = failed
         print(json.dumps(res))
+        if failed:
+            raise SystemExit("bench.py: nested workload(s) failed or were skipped: " + ", ".join(failed))
         return
     if a.same_device:
         local = 0
@@ -1061,14 +1149,13 @@ def main():
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
     # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6: six by default
-    # (multi-rank runs keep three: every step in flight adds three collective sections to the fixed order, and that depth
-    # is the one exercised over RCCL)
+    # (multi-rank runs too: every step in flight adds three collective sections to the one fixed order, CollectiveOrder)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 3 if multi else 6, "dup8_m1": 1, "extract_m1": 4}[a.workload])
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 6, "dup8_m1": 1, "extract_m1": 4}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
-    shared = a.shared_corpus and a.workload == "silesia_x256_m1"
+    shared = a.workload == "silesia_x256_m1" and (a.shared_corpus or (world > 1 and not a.own_corpus))
     corpus = datagen.silesia_like(seed=0 if shared else rank, scale=a.scale)
     if a.workload == "dup8_m1":
         layout = dup8_layout(dev, corpus, a.units, a.dup, rank)
@@ -1253,16 +1340,18 @@ def main():
                 r["waves"] = int(waves[k])
                 r["note"] = "serial chain(s): %d waves of 1024 SIMDs; one instruction per ~4 cycles per wave" % waves[k]
             return r
-        # the headline roofline is the chip-filling kernel with the most GPU time per step -- what bounds a pipelined step; the
-        # serial chains (a few waves: block checksums, LZ77 segments) bound one job's latency and are hidden by the jobs in
-        # flight: the longest of them is reported as roofline_longest_chain (it was `roofline` up to round 3's first profile)
+        # `roofline` is the kernel with the most GPU time per step, whatever its wave count (on the folded corpus that is a
+        # serial chain of a few waves: block checksums or LZ77 segments -- what bounds one job's latency); the chip-filling
+        # kernel with the most time is reported beside it as roofline_chip_filling
         simds = 1024
         fill = [k for k in kern if alg.get(k) and waves.get(k, simds) >= simds]
         chains = [k for k in kern if alg.get(k) and waves.get(k, simds) < simds]
-        dom = max(fill, key=lambda k: kern[k][1], default=None)
+        dom = max((k for k in kern if alg.get(k)), key=lambda k: kern[k][1], default=None)
         roof_dom = roof(dom) if dom else None
+        dom_fill = max(fill, key=lambda k: kern[k][1], default=None)
+        roof_fill = roof(dom_fill) if dom_fill else None
         roof_chain = roof(max(chains, key=lambda k: kern[k][1])) if chains else None
-        roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r]
+        roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r] if a.roofline_all else None
         e2e = alg_step / 1e9 / sec
         res = {"metric": metric, "value": round(out_bytes / 1e6 / sec, 3),
                "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(sec * 1e3, 3),
@@ -1276,7 +1365,8 @@ def main():
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
                "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof_dom, "roofline_longest_chain": roof_chain, "roofline_all": roof_all,
+               "roofline": roof_dom, "roofline_chip_filling": roof_fill, "roofline_longest_chain": roof_chain,
+               **({"roofline_all": roof_all} if roof_all else {}),
                "roofline_end_to_end": {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 5),
                                        "algorithmic_bytes_per_step": int(alg_step),
                                        "note": "whole step: SURVEY 8(d) algorithmic bytes (input once + unique + output; extract: r + 1 + 1) / ms_per_step; the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}

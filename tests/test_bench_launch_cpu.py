@@ -1,0 +1,50 @@
+"""bench.py's launcher and line shaping, without a GPU: `--gpus N` outside torchrun starts N ranks itself and the line
+carries n_gpus = N; a launcher that started another number of ranks is refused; the nested workload lines are cut down
+and summarised so that the END of the one JSON line shows every workload."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return e
+
+
+def test_gpus_2_starts_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 3 and line["scaling"] == "strong"
+
+
+def test_world_size_other_than_gpus_is_refused():
+    e = _env(); e.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode != 0 and "n_gpus" in r.stderr
+
+
+def test_nested_lines_are_compact_and_summarised():
+    sys.path.insert(0, ROOT)
+    import bench
+    full = {"metric": "m", "value": 12.5, "unit": "MB/s", "ms_per_step": 80.0, "verified_all_blocks": True, "verified_dedup": True,
+            "identity": "x" * 500, "roofline_all": [{"kernel": "k"}] * 40,
+            "kernels_ms_per_step": {"k%d" % i: float(100 - i) for i in range(30)},
+            "roofline": {"bound": "hbm", "kernel": "sha1_chain_kernel", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.000125,
+                         "traffic": None, "avg_launch_ms": 215.0, "note": "y" * 300},
+            "cpu_baseline": {"value": 6.1, "unit": "MB/s", "cores": 16, "kind": "reference", "sample": "whole job", "extra": list(range(100))},
+            "config": {"workload": "w", "input_bytes": 1, "fragments": 2}}
+    c = bench.compact_line(full)
+    assert len(json.dumps(c)) < 1200
+    assert c["value"] == 12.5 and c["roofline"]["kernel"] == "sha1_chain_kernel" and "note" not in c["roofline"]
+    assert len(c["kernels_ms_per_step"]) == 6 and c["cpu_baseline"]["kind"] == "reference"
+    assert bench.summary_row(full) == [12.5, 80.0, True, 0.000125, 6.1]
+    assert bench.summary_row({"error": "boom", "rc": 1}) == [None, None, False, None, None]
+    bad = dict(full, verified_dedup=False)
+    assert bench.summary_row(bad)[2] is False

@@ -623,7 +623,7 @@ def test_two_rank_add_is_bit_identical_to_serial(tmp_path):
     out = str(tmp_path / "two_rank.bin")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--copies", "2",
-           "--scale", "0.05", "--dist-backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-verify", "--dump-archive", out]
+           "--scale", "0.05", "--dist-backend", "gloo", "--same-device", "--own-corpus", "--no-cpu-baseline", "--no-verify", "--dump-archive", out]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     got = open(out, "rb").read()
@@ -665,8 +665,8 @@ def test_two_rank_shared_corpus_equals_the_single_gpu_archive(tmp_path):
     common = ["--steps", "1", "--warmup", "1", "--copies", "4", "--scale", "0.05", "--no-cpu-baseline", "--no-verify", "--workload", "silesia_x256_m1"]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-archive", one] + common, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--shared-corpus", "--dump-archive", two] + common
+    # no launcher in front: `bench.py --gpus 2` starts its two ranks itself, and one corpus split over the ranks is the default
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--dump-archive", two] + common
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
