@@ -91,6 +91,7 @@ static inline hiprtcResult hiprtcCompileProgram(hiprtcProgram p, int, const char
   unlink(cpp.c_str()); unlink((cpp + ".log").c_str());
   return HIPRTC_SUCCESS;
 }
+static inline hiprtcResult hiprtcVersion(int* major, int* minor) { *major = 0; *minor = 0; return HIPRTC_SUCCESS; }
 static inline hiprtcResult hiprtcGetProgramLogSize(hiprtcProgram p, size_t* n) { *n = p->log.size() + 1; return HIPRTC_SUCCESS; }
 static inline hiprtcResult hiprtcGetProgramLog(hiprtcProgram p, char* out) { memcpy(out, p->log.c_str(), p->log.size() + 1); return HIPRTC_SUCCESS; }
 static inline hiprtcResult hiprtcGetCodeSize(hiprtcProgram p, size_t* n) { *n = p->path.size() + 1; return HIPRTC_SUCCESS; }

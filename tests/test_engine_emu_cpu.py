@@ -117,10 +117,6 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
     jobs += [("test_gpu_lz_cand.py", ["-k", "sequential_table or direct"], 900, exp),
              ("test_gpu_lz_cand.py", ["-k", "sequential_table"], 900, dict(exp, ZPQ_SORT="own")),
              ("test_gpu_sa.py", ["-k", "suffix_array_equals_oracle or bwt_equals_oracle"], 900, {"ZPQ_SORT": "own"})]
-    # ... and several blocks per wave in the generated context-mixing coder (cm_spec_src.inc, ZS < 64)
-    jobs += [("test_gpu_cm_spec.py", ["-k", "hcomp or (builtin and 1)"], 900, {"ZPQ_CM_GROUPS": "1"}),
-             ("test_gpu_parity.py", ["-k", "cm_encode_decode or cm_decode_fixture or decompress_generic"], 900, {"ZPQ_CM_GROUPS": "1"}),
-             ("test_gpu_m3.py", ["-k", "hostile or fragment_statistics"], 900, {"ZPQ_CM_GROUPS": "1"})]
     # row (e): the journaling add sharded over two PROCESSES (gloo, world size 2), each with its own emulated engine, gives
     # the single-GPU archive
     jobs.append(("test_sharded_add.py", ["-k", "flags0 or flags2 or failing"], 900))

@@ -1098,7 +1098,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
       if (it == by_header.end()) {
         zpq_cm_spec* sk = nullptr;
         int g = -1;
-        if (zpq_cm_spec_get(ctx, ph[i], &sk) == ZPQ_OK && sk) { g = (int)gk.size(); gk.push_back(sk); members.emplace_back(); }
+        if (zpq_cm_spec_get(ctx, ph[i], encode != 0, &sk) == ZPQ_OK && sk) { g = (int)gk.size(); gk.push_back(sk); members.emplace_back(); }
         else {
           static bool warned = false;
           if (!warned) { warned = true; fprintf(stderr, "[zpaqhip] specialised context-mixing coder unavailable (%s): generic kernel used\n", ctx->err.c_str()); }

@@ -4,8 +4,11 @@
 // This is the engine's counterpart of libzpaq's two x86 JITs (ZPAQL::assemble ZSFX/libzpaq.cpp:2709-3488,
 // Predictor::assemble_p :3489-4261); like them it changes speed only: the semantics are the interpreters'
 // (ZPAQL::run0 :1033-1254, Predictor::predict0/update0 :1846-2058), and tests compare with those.
-// Code objects are cached per process and, keyed by a hash of the generated source, on disk next to the library
-// (zpaqfranz_amd/jit_cache, or $ZPQ_JIT_CACHE), so that a header is compiled once per installation.
+// Code objects are cached per process (keyed by the generated source text itself) and on disk next to the library
+// (zpaqfranz_amd/jit_cache, or $ZPQ_JIT_CACHE; a file carries its source and is used only if that is the one asked for,
+// the directory only if nobody but its owner can write to it), so that a header this library generates itself is
+// compiled once per installation.  What an archive brings -- foreign headers, post-processor programs -- is compiled
+// within a per-process budget, never written to disk, and beyond the budget coded by the interpreter-driven kernels.
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
@@ -122,57 +125,105 @@ std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pc
   }
   std::string out = std::string("ZDEV void ") + fname + "(const u32 input, ZVm& z, g_u8* const M, g_u32* const R, const zh_ptr H" +
                     (is_pcomp ? ", g_u8* const zout, const u32 zcap, u32& zop" : "") + ") {\n";
-  out += "  u32 a = input, b = z.b, c = z.c, d = z.d, f = z.f, t = 0, guard = 0; (void)t; (void)guard;\n";
+  // backward jumps are counted: HCOMP per call (one byte), a post-processor over the whole segment (z.g, limit z.lim)
+  out += std::string("  u32 a = input, b = z.b, c = z.c, d = z.d, f = z.f, t = 0, guard = ") + (is_pcomp ? "z.g" : "0") + "; (void)t; (void)guard;\n";
   out += n ? "  goto L0;\n" : "  goto Lerr;\n";
   for (auto& kv : stmt) out += "L" + itos(kv.first) + ": " + kv.second + "\n";
-  out += "Lerr: z.err = 1;\nLend: z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;\n}\n";
+  out += std::string("Lerr: z.err = 1;\nLend: z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;") + (is_pcomp ? " z.g = guard;" : "") + "\n}\n";
   return out;
 }
 
-u64 fnv64(const std::string& s) {
-  u64 h = 1469598103934665603ull;
+u64 fnv64(const std::string& s, u64 h = 1469598103934665603ull) {
   for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
   return h;
 }
 
-std::string cache_dir() {
-  const char* e = getenv("ZPQ_JIT_CACHE");
-  if (e && *e) return e;
-  Dl_info di;
-  if (dladdr((const void*)&fnv64, &di) && di.dli_fname) {
-    std::string p = di.dli_fname;
-    const size_t k = p.rfind('/');
-    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
-  }
-  return "/tmp/zpq_jit_cache";
+int env_int(const char* name, int def) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : def;
 }
 
-bool read_file(const std::string& path, std::vector<char>& out) {
+// A cache directory is used only if it belongs to this user (or root) and nobody else can write to it: a code object
+// read from it is executed on the GPU.  No fallback under /tmp: without a safe directory there is no on-disk cache.
+bool dir_is_safe(const std::string& dir, bool create) {
+  struct stat st;
+  if (lstat(dir.c_str(), &st) != 0) {
+    if (!create || mkdir(dir.c_str(), 0700) != 0 || lstat(dir.c_str(), &st) != 0) return false;
+  }
+  if (!S_ISDIR(st.st_mode)) return false;
+  if (st.st_uid != geteuid() && st.st_uid != 0) return false;
+  return (st.st_mode & 022) == 0;
+}
+
+std::string cache_dir() {
+  if (getenv("ZPQ_JIT_NOCACHE")) return "";
+  std::string dir;
+  const char* e = getenv("ZPQ_JIT_CACHE");
+  if (e && *e) dir = e;
+  else {
+    Dl_info di;
+    if (!dladdr((const void*)&env_int, &di) || !di.dli_fname) return "";
+    const std::string p = di.dli_fname;
+    const size_t k = p.rfind('/');
+    dir = (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/jit_cache";
+  }
+  return dir_is_safe(dir, true) ? dir : "";
+}
+
+// Cache file = magic, length of the source, the source text itself, the code object: a file is used only if its source
+// is byte for byte the one asked for (the name is a hash; names can collide, contents cannot), and only if it belongs to
+// this user or root.
+const char kMagic[8] = {'Z', 'P', 'Q', 'J', 'I', 'T', '2', '\n'};
+
+bool read_cached(const std::string& path, const std::string& src, std::vector<char>& code) {
+  struct stat st;
+  if (lstat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || (st.st_uid != geteuid() && st.st_uid != 0) || (st.st_mode & 022)) return false;
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  const long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out.resize(n > 0 ? (size_t)n : 0);
-  const bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  bool ok = false;
+  char magic[8];
+  u64 n = 0;
+  std::string have;
+  if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, kMagic, 8) && fread(&n, 8, 1, f) == 1 && n == src.size()) {
+    have.resize(n);
+    const u64 rest = (u64)st.st_size - 16 - n;
+    if (fread(&have[0], 1, n, f) == n && have == src && (u64)st.st_size > 16 + n) {
+      code.resize(rest);
+      ok = fread(code.data(), 1, rest, f) == rest;
+    }
+  }
   fclose(f);
   return ok;
 }
 
-void write_file_atomic(const std::string& dir, const std::string& path, const std::vector<char>& data) {
-  (void)mkdir(dir.c_str(), 0755);
+void write_cached(const std::string& path, const std::string& src, const std::vector<char>& code) {
   const std::string tmp = path + ".tmp" + itos((long long)getpid());
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;
-  const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+  const u64 n = src.size();
+  const bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&n, 8, 1, f) == 1 && fwrite(src.data(), 1, n, f) == n &&
+                  fwrite(code.data(), 1, code.size(), f) == code.size();
   fclose(f);
-  if (ok) (void)rename(tmp.c_str(), path.c_str()); else (void)unlink(tmp.c_str());
+  if (ok) { (void)chmod(tmp.c_str(), 0644); (void)rename(tmp.c_str(), path.c_str()); } else (void)unlink(tmp.c_str());
 }
 
-struct Compiled { std::vector<char> code; std::string log; };
-std::mutex g_mu;
-std::map<u64, Compiled> g_code;                        // source hash -> code object (any device: all gfx950)
-std::map<std::pair<int, u64>, zpq_cm_spec*> g_mods;    // (device, source hash) -> loaded module
+std::string cache_name(const std::string& src) {
+  // what the file holds also depends on the compiler: its version is part of the name
+  int maj = 0, min = 0;
+  (void)hiprtcVersion(&maj, &min);
+  char name[96];
+  snprintf(name, sizeof name, "/cm_%016llx%016llx_%d_%d.hsaco", (unsigned long long)fnv64(src),
+           (unsigned long long)fnv64(src, 0x9e3779b97f4a7c15ull ^ src.size()), maj, min);
+  return name;
+}
+
+struct Compiled { std::vector<char> code; };
+std::mutex g_mu;                                        // the maps below
+std::mutex g_compile_mu;                                // one hiprtc compile at a time; g_mu is NOT held meanwhile
+std::map<std::string, Compiled> g_code;                 // source text -> code object (any device: all gfx950)
+std::map<std::pair<int, std::string>, zpq_cm_spec*> g_mods;    // (device, source text) -> loaded module
+int g_fresh = 0;                                        // compiles this process has paid for (cache hits do not count)
+size_t modules_loaded();
 
 }  // namespace
 
@@ -180,30 +231,14 @@ struct zpq_cm_spec {
   hipModule_t mod;
   hipFunction_t enc, dec;
   u32 waves;          // ZW the module was compiled for (workgroup = waves * 64 threads at most)
-  u32 groups;         // blocks per wave (1 unless ZPQ_CM_GROUPS)
   bool h_lds;
 };
 
-// EXPERIMENTAL (ZPQ_CM_GROUPS=1; verified on the CPU emulator only): lanes per block when a wave codes several blocks at once --
-// the next power of two above the component count; an SSE stage keeps its 32-entry row across 32 lanes.  64 = one block per wave.
-// Every block keeps its H[] in LDS (hh <= 10) beside the 86 KiB of tables, so the blocks per compute unit are bounded
-// whatever the grouping: groups are only made as long as eight waves (two per SIMD) still fit.
-static u32 group_stride(u32 n, u32 nsse, u32 hh) {
-  static const bool on = [] { const char* e = getenv("ZPQ_CM_GROUPS"); return e && atoi(e) != 0; }();
-  if (!on) return 64;
-  u32 zs = 2;
-  while (zs < n) zs <<= 1;
-  if (nsse && zs < 32) zs = 32;
-  if (hh <= 10) while (zs < 64 && (160u * 1024u - 1024u - 88064u) / ((64u / zs) * (4u << hh)) < 8u) zs <<= 1;
-  return zs > 64 ? 64 : zs;
-}
-
 // waves per workgroup the kernels are compiled for: 16 (128 registers per lane); 8 where more registers are needed -- the
-// one-bit-ahead values (ZPQ_CM_SPEC), several blocks per wave (every wave-uniform value becomes a register per lane; the
-// blocks per compute unit stay what they were with two blocks per wave)
-static u32 spec_waves(u32 zs) {
+// one-bit-ahead values (ZPQ_CM_SPEC)
+static u32 spec_waves() {
   if (const char* e = getenv("ZPQ_CM_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return (u32)v; }
-  return getenv("ZPQ_CM_SPEC") || zs < 64 ? 8 : 16;
+  return getenv("ZPQ_CM_SPEC") ? 8 : 16;
 }
 
 // The generated source for one header (also used by the build-time cache warmer and the tests).
@@ -261,15 +296,14 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   flush_group();
   if (nmix > 8 || nsse > 4) { *why = "more mixers / SSE stages than the wave coder keeps in registers"; return ZPQ_ERR_METHOD; }
   const bool h_lds = P.hh <= 10;
-  const u32 zs = group_stride(P.n, nsse, P.hh);            // lanes per block (64: one block per wave)
   // waves per workgroup: the tables (86 KiB) are shared, H[] is per block; one workgroup per compute unit
-  u32 waves = spec_waves(zs);
-  while (waves > 1 && 88064u + (h_lds ? waves * (64u / zs) * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
+  u32 waves = spec_waves();
+  while (waves > 1 && 88064u + (h_lds ? waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) waves >>= 1;
   std::string s;
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
-  if (zs != 64) s += "#define ZS " + itos(zs) + "\n";
   s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
-  s += "#define ZGUARD (1u << 26)\n";
+  s += "#define ZGUARD (1u << 16)\n";        // backward jumps HCOMP may take per byte
+
   if (getenv("ZPQ_CM_PROGRESS")) s += "#define ZPROGRESS 1\n";
   static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
   for (int t = 1; t <= 9; ++t) s += std::string("#define ZM_") + names[t] + " " + hex64(mask[t]) + "\n";
@@ -280,7 +314,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   // for a 100 KB block, 448 against 400 ms for 2048 blocks): the ~80 instructions it adds per bit cost more than the
   // waits it removes -- most of a bit's waiting is LDS latency on the dependent chain, not the round of loads.  Kept
   // behind ZPQ_CM_SPEC=1 for tuning.
-  s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") && zs == 64 ? "1" : "0") + "\n";
+  s += std::string("#define ZSPEC ") + (getenv("ZPQ_CM_SPEC") ? "1" : "0") + "\n";
   // ZPQ_CM_PRE_LATE=1: the second nibble's bucket is fetched when the nibble is known (one line per component and
   // nibble) instead of both candidates one bit early (two lines): less memory traffic, one exposed round trip per byte
   s += std::string("#define ZPRE_LATE ") + (getenv("ZPQ_CM_PRE_LATE") ? "1" : "0") + "\n";
@@ -293,57 +327,77 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   return ZPQ_OK;
 }
 
-// Compiles (or fetches from the caches) the code object for a source text.
-static int compile_source(zpq_ctx* ctx, const std::string& src, u64 key, const Compiled** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_code.find(key);
-  if (it != g_code.end()) { *out = &it->second; return ZPQ_OK; }
+// Compiles (or fetches from the caches) the code object for a source text.  Headers and post-processor programs come
+// out of archives, so the work an input can cause is bounded: a process compiles at most ZPQ_JIT_MAX_COMPILES (64)
+// sources it did not find in a cache and keeps at most ZPQ_JIT_MAX_MODULES (128) code objects / loaded modules; beyond
+// that the caller gets an error and codes those blocks with the interpreter-driven kernels (cm.hip), which need no
+// compiler.  `persist`: write the code object to the on-disk cache -- only for sources this library made from its OWN
+// configurations (compress side, build-time warm-up); what a foreign archive brought is kept in memory only.
+static int compile_source(zpq_ctx* ctx, const std::string& src, bool persist, const Compiled** out) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_code.find(src);
+    if (it != g_code.end()) { *out = &it->second; return ZPQ_OK; }
+    if (g_code.size() >= (size_t)env_int("ZPQ_JIT_MAX_MODULES", 128))
+      return zpq_fail(ctx, ZPQ_ERR_METHOD, "run-time compiled kernels: limit of %d code objects reached (ZPQ_JIT_MAX_MODULES)", env_int("ZPQ_JIT_MAX_MODULES", 128));
+  }
+  std::lock_guard<std::mutex> ck(g_compile_mu);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);              // another thread may have compiled it while this one waited
+    auto it = g_code.find(src);
+    if (it != g_code.end()) { *out = &it->second; return ZPQ_OK; }
+  }
   Compiled c;
   const std::string dir = cache_dir();
-  char name[64];
-  snprintf(name, sizeof name, "/cm_%016llx.hsaco", (unsigned long long)key);
-  const std::string path = dir + name;
-  if (!getenv("ZPQ_JIT_NOCACHE") && read_file(path, c.code)) {
-    *out = &(g_code[key] = std::move(c));
+  const std::string path = dir.empty() ? std::string() : dir + cache_name(src);
+  if (!path.empty() && read_cached(path, src, c.code)) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    *out = &(g_code[src] = std::move(c));
     return ZPQ_OK;
   }
+  if (g_fresh >= env_int("ZPQ_JIT_MAX_COMPILES", 64))
+    return zpq_fail(ctx, ZPQ_ERR_METHOD, "run-time compiled kernels: limit of %d compilations per process reached (ZPQ_JIT_MAX_COMPILES)", env_int("ZPQ_JIT_MAX_COMPILES", 64));
+  ++g_fresh;
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "cm_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return zpq_fail(ctx, ZPQ_ERR_HIP, "hiprtcCreateProgram failed");
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label", "-Wno-unused-variable"};
   const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
-  size_t ls = 0;
-  (void)hiprtcGetProgramLogSize(prog, &ls);
-  if (ls > 1) { c.log.resize(ls); (void)hiprtcGetProgramLog(prog, &c.log[0]); }
   if (r != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    std::string log;
+    (void)hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) { log.resize(ls); (void)hiprtcGetProgramLog(prog, &log[0]); }
     (void)hiprtcDestroyProgram(&prog);
-    if (getenv("ZPQ_JIT_DUMP")) { FILE* f = fopen("/tmp/zpq_cm_failed.hip", "w"); if (f) { fputs(src.c_str(), f); fclose(f); } }
-    fprintf(stderr, "[zpaqhip] hiprtc failed on the generated context-mixing kernel (%s):\n%.4000s\n", hiprtcGetErrorString(r), c.log.c_str());
-    return zpq_fail(ctx, ZPQ_ERR_HIP, "hiprtc: %s: %.400s", hiprtcGetErrorString(r), c.log.c_str());
+    if (const char* d = getenv("ZPQ_JIT_DUMP")) { FILE* f = fopen(d, "w"); if (f) { fputs(src.c_str(), f); fclose(f); } }
+    fprintf(stderr, "[zpaqhip] hiprtc failed on a generated kernel (%s):\n%.4000s\n", hiprtcGetErrorString(r), log.c_str());
+    return zpq_fail(ctx, ZPQ_ERR_HIP, "hiprtc: %s: %.400s", hiprtcGetErrorString(r), log.c_str());
   }
   size_t cs = 0;
   (void)hiprtcGetCodeSize(prog, &cs);
   c.code.resize(cs);
   (void)hiprtcGetCode(prog, c.code.data());
   (void)hiprtcDestroyProgram(&prog);
-  if (!getenv("ZPQ_JIT_NOCACHE")) write_file_atomic(dir, path, c.code);
-  *out = &(g_code[key] = std::move(c));
+  if (persist && !path.empty()) write_cached(path, src, c.code);
+  std::lock_guard<std::mutex> lk(g_mu);
+  *out = &(g_code[src] = std::move(c));
   return ZPQ_OK;
 }
 
-int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out) {
+int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, bool own_config, zpq_cm_spec** out) {
   *out = nullptr;
   std::string src, why;
   int rc = zpq_cm_spec_source(P, &src, &why);
   if (rc) return zpq_fail(ctx, rc, "specialised coder: %s", why.c_str());
-  const u64 key = fnv64(src);
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_mods.find({ctx->device, key});
+    auto it = g_mods.find({ctx->device, src});
     if (it != g_mods.end()) { *out = it->second; return ZPQ_OK; }
+    if (modules_loaded() >= (size_t)env_int("ZPQ_JIT_MAX_MODULES", 128))
+      return zpq_fail(ctx, ZPQ_ERR_METHOD, "run-time compiled kernels: limit of loaded modules reached (ZPQ_JIT_MAX_MODULES)");
   }
   const Compiled* c = nullptr;
-  rc = compile_source(ctx, src, key, &c);
+  rc = compile_source(ctx, src, own_config, &c);
   if (rc) return rc;
   zpq_cm_spec* k = new zpq_cm_spec();
   if (hipModuleLoadData(&k->mod, c->code.data()) != hipSuccess) { delete k; return zpq_fail(ctx, ZPQ_ERR_HIP, "hipModuleLoadData failed for the specialised coder"); }
@@ -352,15 +406,10 @@ int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out) {
     return zpq_fail(ctx, ZPQ_ERR_HIP, "specialised coder: kernels missing from the module");
   }
   k->h_lds = P.hh <= 10;
-  {
-    u32 nsse = 0;
-    for (const std::vector<u8>& c : P.comps) nsse += c[0] == SSE;
-    k->groups = 64u / group_stride(P.n, nsse, P.hh);
-  }
-  k->waves = spec_waves(64u / k->groups);
-  while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * k->groups * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
+  k->waves = spec_waves();
+  while (k->waves > 1 && 88064u + (k->h_lds ? k->waves * (4u << P.hh) : 0u) > 160u * 1024u - 1024u) k->waves >>= 1;
   std::lock_guard<std::mutex> lk(g_mu);
-  auto ins = g_mods.insert({{ctx->device, key}, k});
+  auto ins = g_mods.insert({{ctx->device, src}, k});
   if (!ins.second) { (void)hipModuleUnload(k->mod); delete k; }
   *out = ins.first->second;
   return ZPQ_OK;
@@ -373,7 +422,7 @@ int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void*
   // one workgroup per compute unit (the tables fill more than half of its LDS); as many waves per workgroup as it
   // takes to seat every block, at most what the module was compiled for
   const u32 cus = (u32)ctx->cu_count;
-  const u32 seats = (njobs + k->groups - 1) / k->groups;      // waves' worth of blocks
+  const u32 seats = njobs;                                    // one wave per block
   u32 w = (seats + cus - 1) / cus;
   if (w < 1) w = 1;
   if (w > k->waves) w = k->waves;
@@ -396,11 +445,14 @@ typedef unsigned char u8; typedef unsigned short u16; typedef unsigned int u32; 
 typedef ZGA u32 g_u32; typedef ZGA u8 g_u8;
 typedef g_u32* zh_ptr;
 #define ZDEV __device__ inline __attribute__((always_inline))
-struct ZVm { u32 a, b, c, d, f, err; };
+struct ZVm { u32 a, b, c, d, f, err, g, lim; };
 //@@PCOMP@@
 extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n, u8* out, u32 cap, u32* H, u8* M, u32* R, u32* result) {
   if (threadIdx.x) return;
-  ZVm z = {0, 0, 0, 0, 0, 0};
+  // budget of backward jumps for the WHOLE segment (a program that spins is a format error, not a hung GPU): what the
+  // post-processors in use need is a small multiple of the bytes they read and write
+  const u64 lim = (1ull << 22) + 64ull * ((u64)n + (u64)cap);
+  ZVm z = {0, 0, 0, 0, 0, 0, 0, lim > 0x7fffffffull ? 0x7fffffffu : (u32)lim};
   u32 op = 0;
   const g_u8* gin = (const g_u8*)in;
   for (u32 i = 0; i < n && !z.err; ++i) z_pcomp(gin[i], z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
@@ -411,34 +463,36 @@ extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n,
 )ZPQSRC";
 
 struct PcompMod { hipModule_t mod; hipFunction_t fn; };
-std::map<std::pair<int, u64>, PcompMod> g_pmods;
+std::map<std::pair<int, std::string>, PcompMod> g_pmods;
+size_t modules_loaded() { return g_mods.size() + g_pmods.size(); }       // under g_mu
 }  // namespace
 
 // Runs pcomp[0..psize) over d_in[0..n) on the device; H, M, R are zeroed device arrays of 2^ph words, 2^pm bytes, 256 words.
 int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize, u32 ph, u32 pm, const u8* d_in, u32 n, u8* d_out, u32 out_cap,
                        u32* d_H, u8* d_M, u32* d_R, u32* d_result) {
   std::vector<u8> code(pcomp, pcomp + psize);
-  std::string src = "#define ZHMASK " + itos((1u << ph) - 1) + "u\n#define ZMMASK " + itos((1u << pm) - 1) + "u\n#define ZGUARD 0x7fffffffu\n";
+  std::string src = "#define ZHMASK " + itos((1u << ph) - 1) + "u\n#define ZMMASK " + itos((1u << pm) - 1) + "u\n#define ZGUARD z.lim\n";
   std::string body = kPcompSrc;
   const std::string marker = "//@@PCOMP@@";
   body.replace(body.find(marker), marker.size(), gen_zpaql(code, "z_pcomp", true));
   src += body;
-  const u64 key = fnv64(src);
   PcompMod pmod;
   bool have = false;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_pmods.find({ctx->device, key});
+    auto it = g_pmods.find({ctx->device, src});
     if (it != g_pmods.end()) { pmod = it->second; have = true; }
+    else if (modules_loaded() >= (size_t)env_int("ZPQ_JIT_MAX_MODULES", 128))
+      return zpq_fail(ctx, ZPQ_ERR_METHOD, "run-time compiled kernels: limit of loaded modules reached (ZPQ_JIT_MAX_MODULES)");
   }
   if (!have) {
     const Compiled* c = nullptr;
-    int rc = compile_source(ctx, src, key, &c);
+    int rc = compile_source(ctx, src, false, &c);        // a post-processor out of an archive: never written to disk
     if (rc) return rc;
     if (hipModuleLoadData(&pmod.mod, c->code.data()) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_HIP, "hipModuleLoadData failed for a translated post-processor");
     if (hipModuleGetFunction(&pmod.fn, pmod.mod, "pcomp_spec") != hipSuccess) { (void)hipModuleUnload(pmod.mod); return zpq_fail(ctx, ZPQ_ERR_HIP, "translated post-processor: kernel missing"); }
     std::lock_guard<std::mutex> lk(g_mu);
-    auto ins = g_pmods.insert({{ctx->device, key}, pmod});
+    auto ins = g_pmods.insert({{ctx->device, src}, pmod});
     if (!ins.second) { (void)hipModuleUnload(pmod.mod); pmod = ins.first->second; }
   }
   void* args[] = {(void*)&d_in, (void*)&n, (void*)&d_out, (void*)&out_cap, (void*)&d_H, (void*)&d_M, (void*)&d_R, (void*)&d_result};
@@ -457,7 +511,7 @@ extern "C" int zpq_cm_precompile(const uint8_t* header, uint32_t header_len) {
   rc = zpq_cm_spec_source(P, &src, &why);
   if (rc) return rc;
   const Compiled* c = nullptr;
-  return compile_source(nullptr, src, fnv64(src), &c);
+  return compile_source(nullptr, src, true, &c);
 }
 
 // Diagnostic: the generated source text for a header (tests compile and inspect it).

@@ -184,7 +184,7 @@ struct zpq_cm_header {
 int zpq_cm_parse_header(zpq_ctx* ctx, const u8* h, u32 len, zpq_cm_header& P);
 struct zpq_cm_spec;                     // kernels compiled for one header on one device
 int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* why);
-int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, zpq_cm_spec** out);
+int zpq_cm_spec_get(zpq_ctx* ctx, const zpq_cm_header& P, bool own_config, zpq_cm_spec** out);
 u32 zpq_cm_spec_waves(const zpq_cm_spec* k);
 int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void* d_jobs, u32 njobs, u32* d_counter, const void* d_tables,
                        int encode);
