@@ -44,7 +44,8 @@ static inline EmuIdx emu_thread_idx() { return EmuIdx{(unsigned)emu::g_tid, 0, 0
 #define __builtin_amdgcn_s_waitcnt(x) ((void)emu::wave_rendezvous(0, __LINE__))       /* lockstep: everybody's memory operations up to here, then on */
 #define EMU_WAIT_VMCNT0 ((void)emu::wave_rendezvous(0, __LINE__))
 #define __builtin_amdgcn_fence(...) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
+// a sleeping wave lets the others run: a spin loop that waits for ANOTHER wave of the workgroup must let that wave's fibres have their turn
+#define __builtin_amdgcn_s_sleep(x) ((void)(emu::g_active ? (emu::to_main(), 0) : 0))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) (0u)
 #define __syncthreads() emu::block_barrier(__LINE__)
@@ -57,6 +58,7 @@ static inline EmuIdx emu_thread_idx() { return EmuIdx{(unsigned)emu::g_tid, 0, 0
 #define __HIP_MEMORY_SCOPE_AGENT 2
 #define __HIP_MEMORY_SCOPE_SYSTEM 3
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)

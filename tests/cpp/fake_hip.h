@@ -50,6 +50,10 @@ static inline int lane_id() { return emu::lane(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __syncthreads() emu::block_barrier(__LINE__)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+#define __builtin_amdgcn_s_sleep(x) ((void)(emu::g_active ? (emu::to_main(), 0) : 0))      /* a sleeping wave lets the other waves of the workgroup run */
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 0
 #define ZPQ_WAIT_VMCNT0 ((void)emu::wave_rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
 template <class T, class V> static inline T emu_atomic_add(T* p, V v) { const T o = *p; *p = o + (T)v; return o; }

@@ -44,8 +44,15 @@ template <class T> static inline T emu_shfl(T v, int src, int op) { return emu::
 #define __builtin_amdgcn_wave_barrier() ((void)emu::wave_rendezvous(0, __LINE__))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), __ATOMIC_RELAXED)
 #define __ATOMIC_RELAXED_HIP 0
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 0
+#define __syncthreads() emu::block_barrier(__LINE__)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+#define __builtin_amdgcn_s_sleep(x) ((void)(emu::g_active ? (emu::to_main(), 0) : 0))      /* a sleeping wave lets the other wave of the workgroup run */
+#define LZ_DUO_TID() ((u32)emu::g_tid)                 /* lz77_duo.inc: two-wave workgroups (threadIdx is not per fibre in this harness) */
+#define LZ_DUO_WAVE_ID() ((u32)emu::wave())
 #define ZPQ_WAIT_VMCNT0 ((void)emu::wave_rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
 // serial stand-ins for the global atomics of the thread-independent kernels (one thread runs after the other)
 template <class T> static inline T emu_atomic_max(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
@@ -109,15 +116,17 @@ extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table,
 namespace {
 struct SpecRun { const LzSegDev* segs; const u32* list; const LzJobDev* jobs; int nb; bool cand; u32 nseg; };
 SpecRun g_s;
+bool g_duo = false;                          // two waves per segment / block on one table (lz77_duo.inc): walk_emu_duo()
 template <int NB, bool CAND> void spec_body() { lz77_spec_kernel<NB, CAND>(g_s.segs, g_s.list, zpq_place{nullptr, nullptr, g_s.nseg, 0}); }
+template <int NB> void spec2_body() { lz77_spec2_kernel<NB, 8>(g_s.segs, g_s.list); }
 template <int NB, bool CAND> void seam_body() { lz77_seam_kernel<NB, CAND>(g_s.segs, g_s.list); }
 template <int NB, bool CAND> void stitch_body() { lz77_stitch_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
 typedef void (*Body)();
 template <int NB> void bodies(bool cand, Body& sp, Body& se, Body& st) {
   if (cand) { sp = spec_body<NB, true>; se = seam_body<NB, true>; st = stitch_body<NB, true>; }
-  else { sp = spec_body<NB, false>; se = seam_body<NB, false>; st = stitch_body<NB, false>; }
+  else { sp = g_duo ? spec2_body<NB> : spec_body<NB, false>; se = seam_body<NB, false>; st = stitch_body<NB, false>; }
 }
-const char* wave(Body b, u32 bx) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_block(b); g_in_wave = false; return e; }
+const char* wave(Body b, u32 bx, int threads = 64) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_block(b, threads); g_in_wave = false; return e; }
 template <class F> void serial(u32 gx, u32 gy, u32 threads, F&& f) {
   gridDim = {gx, gy, 1};
   for (u32 by = 0; by < gy; ++by) for (u32 bx = 0; bx < gx; ++bx) for (u32 t = 0; t < threads; ++t) { blockIdx = {bx, by, 0}; threadIdx = {t, 0, 0}; f(); }
@@ -182,7 +191,7 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
   }
   const char* e = nullptr;
   gridDim = {nseg, 1, 1};
-  for (u32 k = 0; k < nseg && !e; ++k) e = wave(sp, k);
+  for (u32 k = 0; k < nseg && !e; ++k) e = wave(sp, k, g_duo && !cand ? 128 : 64);
   for (u32 k = 0; k < nseg && !e; ++k) e = wave(se, k);
   g_s.list = joblist.data();
   gridDim = {1, 1, 1};
@@ -200,7 +209,9 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
 // ---- one wave per block, parsing and emitting in one go (lz77_direct_kernel) -------------------------------------------------
 namespace {
 template <int NB, bool CAND> void direct_body() { lz77_direct_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
+template <int NB> void direct2_body() { lz77_direct2_kernel<NB, 14>(g_s.jobs, g_s.segs, g_s.list); }
 }
+extern "C" void walk_emu_duo(int on) { g_duo = on != 0; }
 // out: the code stream (out_cap bytes, zeroed by the caller).  Returns its length, < 0 on an emulation error, -2 on overflow.
 extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* table, int cand, u8* out, u32 out_cap, char* err, u32 err_cap) {
   LzCfg c;
@@ -219,13 +230,13 @@ extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* tabl
   g_s = SpecRun{&S, &list0, &J, args[4], cand != 0, 1};
   Body b = nullptr;
   switch (args[4]) {
-    case 0: b = cand ? direct_body<1, true> : direct_body<1, false>; break;
-    case 1: b = cand ? direct_body<2, true> : direct_body<2, false>; break;
-    case 2: b = cand ? direct_body<4, true> : direct_body<4, false>; break;
-    default: b = cand ? direct_body<8, true> : direct_body<8, false>; break;
+    case 0: b = cand ? direct_body<1, true> : g_duo ? direct2_body<1> : direct_body<1, false>; break;
+    case 1: b = cand ? direct_body<2, true> : g_duo ? direct2_body<2> : direct_body<2, false>; break;
+    case 2: b = cand ? direct_body<4, true> : g_duo ? direct2_body<4> : direct_body<4, false>; break;
+    default: b = cand ? direct_body<8, true> : g_duo ? direct2_body<8> : direct_body<8, false>; break;
   }
   gridDim = {1, 1, 1};
-  const char* e = wave(b, 0);
+  const char* e = wave(b, 0, g_duo && !cand ? 128 : 64);
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   if (result[2]) return -2;
   return (long)result[1];

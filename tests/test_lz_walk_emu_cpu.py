@@ -96,6 +96,8 @@ SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 
 def _spec_case(job):
     args, seg, cand = job
     L = _SO[0]
+    L.walk_emu_duo(1 if cand == 2 else 0)          # 2: the table walk as two waves per segment (lz77_duo.inc)
+    cand = cand == 1
     L.spec_emu.restype = C.c_long
     L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     inputs = _inputs()
@@ -125,13 +127,15 @@ def _spec_case(job):
 
 def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(tmp_path_factory):
     _lib(tmp_path_factory)
-    bad = _pool_map(_spec_case, [(a, sg, c) for a, sg in SPEC_CASES for c in (False, True)])
+    bad = _pool_map(_spec_case, [(a, sg, c) for a, sg in SPEC_CASES for c in (0, 1, 2)])
     assert not bad, bad
 
 
 def _direct_case(job):
     args, cand = job
     L = _SO[0]
+    L.walk_emu_duo(1 if cand == 2 else 0)
+    cand = cand == 1
     L.direct_emu.restype = C.c_long
     L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     for name, b in _inputs().items():
@@ -157,7 +161,7 @@ def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_fa
     """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
     match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
     _lib(tmp_path_factory)
-    bad = _pool_map(_direct_case, [(a, c) for a in ([4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]) for c in (False, True)])
+    bad = _pool_map(_direct_case, [(a, c) for a in ([4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]) for c in (0, 1, 2)])
     assert not bad, bad
 
 

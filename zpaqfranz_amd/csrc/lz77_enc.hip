@@ -786,6 +786,8 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
+#include "lz77_duo.inc"        // two waves per block on one table: lz77_spec2_kernel, lz77_direct2_kernel
+
 #if defined(ZPQ_EMU_WALK_ONLY) && !defined(ZPQ_EMU_FULL)
 }  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled.
    //            tests/cpp/lz77_full_emu.cpp -- ZPQ_EMU_FULL -- takes the whole file, host code included, over a stand-in HIP runtime)
@@ -919,6 +921,11 @@ __global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev*
 extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 64 + 64; }   // level 2 spends a byte per 64 literals, level 1 15 bits per 4096
 
 #ifdef ZPQ_LZ_PROFILE
+extern "C" int zpq_debug_lzprof2(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzprof2), 128) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzprof2), z, 128); }
+  return 0;
+}
 extern "C" int zpq_debug_lzprof(unsigned long long out[8], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzprof), 64) != hipSuccess) return -1;
   if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzprof), z, 64); }
@@ -1046,6 +1053,25 @@ static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& 
 #undef ZPQ_CAND_SWEEPS
   ZPQ_HIP(ctx, hipGetLastError());
   return ZPQ_OK;
+}
+
+// Two-wave kernels (lz77_duo.inc).  Ring depth: 14 windows (30 KB of LDS per workgroup at -m1: five workgroups per compute
+// unit) while the launch itself leaves room for the launches of other contexts beside it, 8 (18 KB) otherwise.  Deeper
+// rings bought nothing once the producer had its fast path for swallowed windows (56: 1620 ms, 14: 1627 ms for a 16 MiB
+// block), and a ring of 56 -- one workgroup per unit -- made six jobs in flight queue for the LDS (127 against 109 ms per step).
+static int duo_ring(const zpq_ctx* ctx, size_t workgroups) {
+  const size_t per_cu = (workgroups + (size_t)ctx->cu_count - 1) / (size_t)std::max(1, ctx->cu_count);
+  return per_cu <= 2 ? 14 : 8;
+}
+template <int NB>
+static void launch_spec2(zpq_ctx* ctx, hipStream_t st, dim3 grid, int R, const LzSegDev* d_segs, const u32* sl) {
+  if (R >= 14) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec2_kernel<NB, 14>), grid, dim3(128), d_segs, sl);
+  else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec2_kernel<NB, 8>), grid, dim3(128), d_segs, sl);
+}
+template <int NB>
+static void launch_direct2(zpq_ctx* ctx, hipStream_t st, dim3 grid, int R, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
+  if (R >= 14) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct2_kernel<NB, 14>), grid, dim3(128), d_jobs, d_segs, jl);
+  else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct2_kernel<NB, 8>), grid, dim3(128), d_jobs, d_segs, jl);
 }
 
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
@@ -1231,11 +1257,25 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  // two waves per block / segment on one table (lz77_duo.inc); ZPQ_LZ_DUO=0: the one-wave walk
+  static const bool duo = [] { const char* e = getenv("ZPQ_LZ_DUO"); return !(e && atoi(e) == 0); }();
+  static const int ring_env = [] { const char* e = getenv("ZPQ_LZ_RING"); return e ? atoi(e) : 0; }();      // (tests: force a ring depth -- 8 or 14)
   if (direct) {
     for (int nb = 0; nb <= 3; ++nb) {
       if (!rng[nb].jn) continue;
       dim3 gj((unsigned)rng[nb].jn), blk(64);
       const u32* jl = d_lists + rng[nb].joff;
+      if (duo && !cand) {
+        const int R = ring_env ? ring_env : duo_ring(ctx, rng[nb].jn);
+        switch (nb) {
+          case 0: launch_direct2<1>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
+          case 1: launch_direct2<2>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
+          case 2: launch_direct2<4>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
+          default: launch_direct2<8>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
+        }
+        ZPQ_HIP(ctx, hipGetLastError());
+        continue;
+      }
       switch (nb) {
         case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<1, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
         case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<2, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
@@ -1268,6 +1308,27 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
         PL.queue = counter; PL.tab = tab; PL.polite = (u32)(2 * rng[nb].sn + 64);
         gs = dim3((unsigned)(3 * rng[nb].sn + 64));
       }
+    }
+    if (duo && !cand) {
+      const dim3 g2((unsigned)rng[nb].sn), b2(128);
+      const int R = ring_env ? ring_env : duo_ring(ctx, rng[nb].sn);
+      (void)b2;
+      switch (nb) {
+        case 0: launch_spec2<1>(ctx, st, g2, R, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, g2, blk, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+        case 1: launch_spec2<2>(ctx, st, g2, R, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, g2, blk, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+        case 2: launch_spec2<4>(ctx, st, g2, R, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, g2, blk, d_segs, sl);
+                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+        default: launch_spec2<8>(ctx, st, g2, R, d_segs, sl);
+                 ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, g2, blk, d_segs, sl);
+                 ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+      }
+      ZPQ_HIP(ctx, hipGetLastError());
+      continue;
     }
     switch (nb) {
       case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<1, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
