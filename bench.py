@@ -1301,13 +1301,7 @@ def main():
                    # member bytes streamed once + the representatives they are compared with (cache resident after the first touch)
                    "twin_compare_kernel": tw["compared_bytes"] + (walked if tw["compared_bytes"] else 0), "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
                    "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
-            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": -(-ub // (1 << 20)), "lz77_direct_kernel": st["blocks"]}
-            if os.environ.get("ZPQ_LZ_CAND"):
-                # experimental candidate-table parse: per unique byte a 12-byte (key, value) pair is written, sorted
-                # (read + written once at least) and swept into 8 candidate words, which the parse then reads once
-                ubr = ub // max(1, world)
-                alg.update({"lz77_cand_keys_kernel": 13 * ubr, "lz77_cand_sort": 24 * ubr, "lz77_cand_sweep_kernel": 44 * ubr,
-                            "lz77_spec_kernel": 33 * ubr + out_bytes // max(1, world), "lz77_direct_kernel": 33 * ubr + out_bytes // max(1, world)})
+            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": 3 * -(-ub // (2 << 20)), "lz77_direct_kernel": 3 * st["blocks"]}     # three waves per segment / block
             if tw["twin_bytes"]:
                 # what is left after the fold is walked by a handful of waves (one lane per 256 KiB segment / per fragment)
                 seg_b = max(256 << 10, walked // 158720)

@@ -183,10 +183,6 @@ typedef struct zpq_lz77_job {
 } zpq_lz77_job;
 size_t zpq_lz77_bound(size_t n);
 int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs);
-/* EXPERIMENTAL (round 3, not yet run on hardware; ZPQ_LZ_CAND=1 makes zpq_lz77_encode_dev parse from such tables): the
- * candidate table of one block for the hash-table finder -- d_cand[q * (bucket+1) + k] = the word LZBuffer's search at
- * position q reads from ht[h1 ^ k] (ZSFX/libzpaq.cpp:6396-6397), i.e. the table as of q.  n << args[4] words. */
-int zpq_lz77_cand_dev(zpq_ctx* ctx, const void* d_in, uint32_t n, const int32_t args[9], uint32_t* d_cand);
 /* Inverse (what the level-1 PCOMP does): d_in/n = code stream, rb = max(args[0]-4,0).  With bit 31 of rb set the stream
  * holds LZBuffer's byte-aligned codes (level 2, ZSFX/libzpaq.cpp:6221-6224) and the low byte of rb is the minimum match
  * length (args[2]): what the level-2 post-processor of methods 3 and 4 undoes. */

@@ -276,70 +276,6 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
   return (long)v.size();
 }
 
-// The same parse with every table lookup answered in advance (checks the candidate-table formulation of
-// zpaqfranz_amd/csrc/lz77_enc.hip on the CPU): orc_lz77_cand fills cand[q*(bucket+1)+k] = ht[h1 ^ k] as LZBuffer's
-// search at q would read it -- every position is inserted whatever the parse decides (:6432-6447), so the table as of q
-// is a function of the data -- and orc_lz77_encode_cand parses from cand alone, touching no table.
-extern "C" long orc_lz77_cand(const U8* in, long n_, const int args[9], U32* cand) {
-  const U32 n = (U32)n_;
-  if (args[3] != 0 || args[6] != 0 || (args[1] & 3) != 1 || args[5] - args[0] >= 21 || args[2] < 4) return -10;
-  const int checkbits = 12 - args[0];
-  const U32 htsize = 1u << args[5], minMatch = args[2], bucket = (1u << args[4]) - 1, minMatchBoth = minMatch + 4;
-  const int shift1 = (args[5] - 1) / minMatch + 1;
-  const U32 mask = (1u << checkbits) - 1;
-  std::vector<U32> ht(htsize, 0);
-  U32 h1 = 0;
-  for (U32 i = 0; i < n; ++i) {
-    for (U32 k = 0; k <= bucket; ++k) cand[(size_t)i * (bucket + 1) + k] = ht[h1 ^ k];
-    if (i + minMatchBoth < n) {
-      U32 ih = ((i * 1234547u) >> 19) & bucket;
-      ht[h1 ^ ih] = (i << checkbits) | (in[i + 3] & mask);
-      h1 = (((h1 * 5) << shift1) + (in[i + minMatch] + 1) * 123456791u) & (htsize - 1);
-    }
-  }
-  return n;
-}
-
-extern "C" long orc_lz77_encode_cand(const U8* in, long n_, const int args[9], const U32* cand, U8* out, long cap) {
-  const U32 n = (U32)n_;
-  if (args[3] != 0 || args[6] != 0 || (args[1] & 3) != 1 || args[5] - args[0] >= 21 || args[2] < 4) return -10;
-  const int checkbits = 12 - args[0];
-  const U32 minMatch = args[2], maxMatch = (1u << 14) * 3, maxLiteral = (1u << 14) / 4, bucket = (1u << args[4]) - 1;
-  const int rb = args[0] > 4 ? args[0] - 4 : 0;
-  const U32 mask = (1u << checkbits) - 1;
-  std::vector<U8> v; v.reserve(n / 2 + 16);
-  BitSink bs(v);
-  U32 i = 0, lit = 0;
-  while (i < n) {
-    U32 blen = minMatch - 1, bp = 0; int bscore = 0;
-    for (U32 k = 0; k <= bucket; ++k) {
-      U32 p = cand[(size_t)i * (bucket + 1) + k];
-      if (p && i + 3 < n && (p & mask) == (in[i + 3] & mask)) {
-        p >>= checkbits;
-        if (p < i && i + blen <= n && in[p + blen - 1] == in[i + blen - 1]) {
-          U32 l = 0;
-          while (i + l < n && l < maxMatch && in[p + l] == in[i + l]) ++l;
-          int score = (int)(l * 8) - lg(i - p) - 2 * (lit > 0) - 11;
-          if (score > bscore) blen = l, bp = p, bscore = score;
-        }
-      }
-      if (blen >= 128) break;
-    }
-    const U32 off = i - bp;
-    if (off > 0 && bscore > 0 && blen >= minMatch) {
-      emit_literals(bs, in, i, lit); lit = 0;
-      emit_match(bs, blen, off, rb);
-    } else { blen = 1; ++lit; }
-    i += blen;
-    if (lit >= maxLiteral) { emit_literals(bs, in, i, lit); lit = 0; }
-  }
-  emit_literals(bs, in, n, lit);
-  bs.flush();
-  if ((long)v.size() > cap) return -2;
-  if (!v.empty()) memcpy(out, v.data(), v.size());
-  return (long)v.size();
-}
-
 // ------------------------------------------------------------------------------------------
 // Suffix array.  The reference calls divsufsort (ZSFX/libzpaq.cpp:6047-6072, body :4334-6040); the
 // suffix array of a string is unique, so any correct construction is a restatement of its RESULT.

@@ -130,11 +130,8 @@ static inline u32 zpq_place_begin(const zpq_place& P, u32& key, bool& polite) { 
 static inline u32 zpq_place_next(const zpq_place&, u32, bool) { return 0xffffffffu; }
 static inline bool zpq_place_enabled() { return false; }
 static inline u32* zpq_simd_table(zpq_ctx*) { return nullptr; }
-static inline bool zpq_own_sort() { const char* e = getenv("ZPQ_SORT"); return e && !strcmp(e, "own"); }
 int zpq_lz77_sa_encode(zpq_ctx*, zpq_lz77_job*, const size_t*, size_t);
 int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
-size_t zpq_radix_scratch_words(size_t n);
-int zpq_radix_sort_pairs(zpq_ctx* ctx, hipStream_t st, u64* keys_in, u64* keys_out, u32* vals_in, u32* vals_out, size_t n, u32 begin_bit, u32 end_bit, u32* scratch);
 
 // ---- rocPRIM: what the engine calls, by std::stable_sort ----------------------------------------------------------------------
 namespace rocprim {

@@ -1,12 +1,11 @@
-// Test infrastructure: zpq_lz77_encode_dev() -- host code and every kernel of zpaqfranz_amd/csrc/lz77_enc.hip (and radix.hip) --
-// on the CPU, over fake_hip.h.  The environment selects the path exactly as on the GPU (ZPQ_LZ_CAND, ZPQ_LZ_SEG,
-// ZPQ_LZ_DIRECT, ZPQ_SORT); the switches are read once per process, so tests run one process per setting.
+// Test infrastructure: zpq_lz77_encode_dev() -- host code and every kernel of zpaqfranz_amd/csrc/lz77_enc.hip -- on the CPU, over
+// fake_hip.h.  The environment selects the path exactly as on the GPU (ZPQ_LZ_SEG, ZPQ_LZ_DIRECT); the switches are read once
+// per process, so tests run one process per setting.
 #include "fake_hip.h"
 
 #define ZPQ_EMU_WALK_ONLY      // (skips the real headers)
 #define ZPQ_EMU_FULL           // (... but keeps everything behind the parse kernels)
 #include "lz77_enc.hip"
-#include "radix.hip"
 
 int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job*, const size_t*, size_t) { return zpq_fail(ctx, ZPQ_ERR_METHOD, "suffix-array jobs are not part of this emulation"); }
 

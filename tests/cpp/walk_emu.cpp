@@ -70,37 +70,41 @@ struct zpq_lzjob_dev {                       // (zpq_internal.h; only named by a
 #define ZPQ_EMU_WALK_ONLY
 #include "lz77_enc.hip"
 
-// ---- one wave walks a whole block ------------------------------------------------------------------------------------------
+// ---- one wave walks a whole block (lz_walk: what the seam and stitch kernels call) ----------------------------------------
 namespace {
-struct WalkArgs { LzCfg c; u32* table; int nb; bool cand; u32* tpos; u32* tlen; u32* toff; u32 tcap; u32 ntok; u32 end_cur, end_lit; };
+struct WalkArgs { LzCfg c; u32* table; u32* tpos; u32* tlen; u32* toff; u32 tcap; u32 ntok; u32 end_cur, end_lit; };
 WalkArgs g_w;
 unsigned long long g_T[256];
 
-template <int NB, bool CAND>
+template <int NB>
 void walk_body() {
   TokSink sink{g_w.tpos, g_w.tlen, g_w.toff, g_w.tcap, 0};
   u32 cur = 0, lit = 0;
-  lz_walk<NB, false, CAND>(g_w.c, g_w.table, 0, g_w.c.n, cur, lit, sink, nullptr, g_T);
+  lz_walk<NB, false>(g_w.c, g_w.table, 0, g_w.c.n, cur, lit, sink, nullptr, g_T);
   if (lane_id() == 0) { g_w.ntok = sink.n; g_w.end_cur = cur; g_w.end_lit = lit; }
 }
-}  // namespace
-
-// in: n bytes + >= 64 readable bytes behind; table: zeroed hash table of 2^args[5] words (cand == 0) or the candidate table
-// of n << args[4] words (cand != 0), 16-byte aligned.  tok: 3 * cap words (pos | len | off).  Returns the token count, or < 0.
-extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table, int cand, u32* tok, u32 cap, char* err, u32 err_cap) {
-  LzCfg& c = g_w.c;
+LzCfg make_cfg(const u8* in, u32 n, const int32_t args[9]) {
+  LzCfg c;
   c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
   c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
   const u32 mmb = args[2] + 4;
   c.upd_limit = n > mmb ? n - mmb : 0;
-  g_w.table = table; g_w.cand = cand != 0; g_w.tpos = tok; g_w.tlen = tok + cap; g_w.toff = tok + 2 * (size_t)cap; g_w.tcap = cap; g_w.ntok = 0;
+  return c;
+}
+}  // namespace
+
+// in: n bytes + >= 64 readable bytes behind; table: zeroed hash table of 2^args[5] words, 16-byte aligned.
+// tok: 3 * cap words (pos | len | off).  Returns the token count, or < 0.
+extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table, u32* tok, u32 cap, char* err, u32 err_cap) {
+  g_w.c = make_cfg(in, n, args);
+  g_w.table = table; g_w.tpos = tok; g_w.tlen = tok + cap; g_w.toff = tok + 2 * (size_t)cap; g_w.tcap = cap; g_w.ntok = 0;
   memset(g_T, 0, sizeof g_T);
   void (*body)() = nullptr;
   switch (args[4]) {
-    case 0: body = cand ? walk_body<1, true> : walk_body<1, false>; break;
-    case 1: body = cand ? walk_body<2, true> : walk_body<2, false>; break;
-    case 2: body = cand ? walk_body<4, true> : walk_body<4, false>; break;
-    default: body = cand ? walk_body<8, true> : walk_body<8, false>; break;
+    case 0: body = walk_body<1>; break;
+    case 1: body = walk_body<2>; break;
+    case 2: body = walk_body<4>; break;
+    default: body = walk_body<8>; break;
   }
   g_in_wave = true;
   const char* e = emu::run_block(body);
@@ -110,22 +114,17 @@ extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table,
 }
 
 // ---- the segment speculation of one block, as encode_batch() lays it out -----------------------------------------------------
-// table states (copy + scatter kernels) or a candidate table, then lz77_spec_kernel per segment, lz77_seam_kernel per
-// segment, lz77_stitch_kernel, lz77_move_tokens_kernel: the kernels themselves, 64-thread ones as emulated waves, the
-// thread-independent ones thread by thread.
+// table states (copy + scatter kernels), then lz77_spec3_kernel per segment (a workgroup of three waves: producer | evaluator |
+// chain, lz77_duo.inc), lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel: the kernels themselves,
+// the wave kernels as emulated waves, the thread-independent ones thread by thread.
 namespace {
-struct SpecRun { const LzSegDev* segs; const u32* list; const LzJobDev* jobs; int nb; bool cand; u32 nseg; };
+struct SpecRun { const LzSegDev* segs; const u32* list; const LzJobDev* jobs; u32 nseg; };
 SpecRun g_s;
-bool g_duo = false;                          // two waves per segment / block on one table (lz77_duo.inc): walk_emu_duo()
-template <int NB, bool CAND> void spec_body() { lz77_spec_kernel<NB, CAND>(g_s.segs, g_s.list, zpq_place{nullptr, nullptr, g_s.nseg, 0}); }
-template <int NB> void spec2_body() { lz77_spec2_kernel<NB, 8>(g_s.segs, g_s.list); }
-template <int NB, bool CAND> void seam_body() { lz77_seam_kernel<NB, CAND>(g_s.segs, g_s.list); }
-template <int NB, bool CAND> void stitch_body() { lz77_stitch_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
+template <int NB> void spec_body() { lz77_spec3_kernel<NB>(g_s.segs, g_s.list); }
+template <int NB> void seam_body() { lz77_seam_kernel<NB>(g_s.segs, g_s.list); }
+template <int NB> void stitch_body() { lz77_stitch_kernel<NB>(g_s.jobs, g_s.segs, g_s.list); }
 typedef void (*Body)();
-template <int NB> void bodies(bool cand, Body& sp, Body& se, Body& st) {
-  if (cand) { sp = spec_body<NB, true>; se = seam_body<NB, true>; st = stitch_body<NB, true>; }
-  else { sp = g_duo ? spec2_body<NB> : spec_body<NB, false>; se = seam_body<NB, false>; st = stitch_body<NB, false>; }
-}
+template <int NB> void bodies(Body& sp, Body& se, Body& st) { sp = spec_body<NB>; se = seam_body<NB>; st = stitch_body<NB>; }
 const char* wave(Body b, u32 bx, int threads = 64) { blockIdx = {bx, 0, 0}; g_in_wave = true; const char* e = emu::run_block(b, threads); g_in_wave = false; return e; }
 template <class F> void serial(u32 gx, u32 gy, u32 threads, F&& f) {
   gridDim = {gx, gy, 1};
@@ -133,21 +132,14 @@ template <class F> void serial(u32 gx, u32 gy, u32 threads, F&& f) {
 }
 }  // namespace
 
-// cand_table: null (table states are built here, as the copy / scatter kernels build them) or the block's candidate table.
 // tok: 3 * cap words (pos | len | off) of the final list.  Returns the token count, < 0 on an emulation error, -2 on overflow.
-extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_bytes, u32* cand_table, u32* tok, u32 cap, char* err, u32 err_cap) {
-  LzCfg c;
-  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
-  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
-  const u32 mmb = args[2] + 4;
-  c.upd_limit = n > mmb ? n - mmb : 0;
-  const bool cand = cand_table != nullptr;
+extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_bytes, u32* tok, u32 cap, char* err, u32 err_cap) {
+  const LzCfg c = make_cfg(in, n, args);
   const u32 nseg = std::max<u32>(1, (u32)(((u64)n + seg_bytes - 1) / seg_bytes));
   const size_t words = (size_t)1 << args[5];
   const u32 mmt = (u32)(args[2] >= 4 ? args[2] : 4);
-  std::vector<u32> tables;                      // work[0..nseg-1], pristine[1..nseg-1]
-  if (!cand) tables.assign(words * (2 * (size_t)nseg - 1) + 16, 0);
-  u32* tab0 = cand ? cand_table : (u32*)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
+  std::vector<u32> tables(words * (2 * (size_t)nseg - 1) + 16, 0);                      // work[0..nseg-1], pristine[1..nseg-1]
+  u32* tab0 = (u32*)(((uintptr_t)tables.data() + 15) & ~(uintptr_t)15);
   u32* prist0 = tab0 + words * nseg - words;
   const u32 fcap = n / mmt + 3;
   std::vector<u32> ftok((size_t)fcap * 4, 0), state((size_t)nseg * 12, 0), plan((size_t)nseg * 8, 0), result(4, 0);
@@ -160,8 +152,8 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
   for (u32 k = 0; k < nseg; ++k) {
     LzSegDev& S = segs[k];
     S.c = c; S.x0 = k * seg_bytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + seg_bytes, n);
-    S.work = cand ? tab0 : tab0 + words * k;
-    S.pristine = cand ? tab0 : k ? prist0 + words * k : nullptr;
+    S.work = tab0 + words * k;
+    S.pristine = k ? prist0 + words * k : nullptr;
     const u32 scap = (S.x1 - S.x0) / mmt + 3;
     lists[2 * k].assign((size_t)scap * 3, 0);
     S.tpos = lists[2 * k].data(); S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap - 1;
@@ -169,29 +161,27 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
     else { S.qpos = S.tpos; S.qlen = S.tlen; S.qoff = S.toff; }
     S.state = state.data() + 12 * (size_t)k; S.seam = S.state + 4;
   }
-  if (!cand) {            // table states: pristine[k] = pristine[k-1] + inserts of segment k-1; work[k] = pristine[k]
-    for (u32 k = 1; k < nseg; ++k) {
-      CopyJob cj{k == 1 ? nullptr : prist0 + words * (k - 1), segs[k].pristine, (u32)words};
-      serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cj); });
-      ScatterJob sj{c, (k - 1) * seg_bytes, k * seg_bytes, segs[k].pristine};
-      serial(8, 1, 256, [&] { lz77_table_scatter_kernel(&sj); });
-      CopyJob cw{segs[k].pristine, segs[k].work, (u32)words};
-      serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cw); });
-    }
+  for (u32 k = 1; k < nseg; ++k) {      // table states: pristine[k] = pristine[k-1] + inserts of segment k-1; work[k] = pristine[k]
+    CopyJob cj{k == 1 ? nullptr : prist0 + words * (k - 1), segs[k].pristine, (u32)words};
+    serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cj); });
+    ScatterJob sj{c, (k - 1) * seg_bytes, k * seg_bytes, segs[k].pristine};
+    serial(8, 1, 256, [&] { lz77_table_scatter_kernel(&sj); });
+    CopyJob cw{segs[k].pristine, segs[k].work, (u32)words};
+    serial(8, 1, 256, [&] { lz77_table_copy_kernel(&cw); });
   }
   std::vector<u32> seglist(nseg), joblist(1, 0);
   for (u32 k = 0; k < nseg; ++k) seglist[k] = k;
-  g_s = SpecRun{segs.data(), seglist.data(), &J, args[4], cand, nseg};
+  g_s = SpecRun{segs.data(), seglist.data(), &J, nseg};
   Body sp = nullptr, se = nullptr, st = nullptr;
   switch (args[4]) {
-    case 0: bodies<1>(cand, sp, se, st); break;
-    case 1: bodies<2>(cand, sp, se, st); break;
-    case 2: bodies<4>(cand, sp, se, st); break;
-    default: bodies<8>(cand, sp, se, st); break;
+    case 0: bodies<1>(sp, se, st); break;
+    case 1: bodies<2>(sp, se, st); break;
+    case 2: bodies<4>(sp, se, st); break;
+    default: bodies<8>(sp, se, st); break;
   }
   const char* e = nullptr;
   gridDim = {nseg, 1, 1};
-  for (u32 k = 0; k < nseg && !e; ++k) e = wave(sp, k, g_duo && !cand ? 128 : 64);
+  for (u32 k = 0; k < nseg && !e; ++k) e = wave(sp, k, 192);
   for (u32 k = 0; k < nseg && !e; ++k) e = wave(se, k);
   g_s.list = joblist.data();
   gridDim = {1, 1, 1};
@@ -206,80 +196,31 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
   return (long)nt;
 }
 
-// ---- one wave per block, parsing and emitting in one go (lz77_direct_kernel) -------------------------------------------------
+// ---- one workgroup per block, parsing and emitting in one go (lz77_direct3_kernel) -------------------------------------------
 namespace {
-template <int NB, bool CAND> void direct_body() { lz77_direct_kernel<NB, CAND>(g_s.jobs, g_s.segs, g_s.list); }
-template <int NB> void direct2_body() { lz77_direct2_kernel<NB, 14>(g_s.jobs, g_s.segs, g_s.list); }
+template <int NB> void direct_body() { lz77_direct3_kernel<NB>(g_s.jobs, g_s.segs, g_s.list); }
 }
-extern "C" void walk_emu_duo(int on) { g_duo = on != 0; }
 // out: the code stream (out_cap bytes, zeroed by the caller).  Returns its length, < 0 on an emulation error, -2 on overflow.
-extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* table, int cand, u8* out, u32 out_cap, char* err, u32 err_cap) {
-  LzCfg c;
-  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
-  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
-  const u32 mmb = args[2] + 4;
-  c.upd_limit = n > mmb ? n - mmb : 0;
+extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* table, u8* out, u32 out_cap, char* err, u32 err_cap) {
   LzSegDev S;
   memset(&S, 0, sizeof S);
-  S.c = c; S.x0 = 0; S.x1 = n; S.work = table; S.pristine = table;
+  S.c = make_cfg(in, n, args); S.x0 = 0; S.x1 = n; S.work = table; S.pristine = table;
   u32 result[4] = {0, 0, 0, 0};
   LzJobDev J;
   memset(&J, 0, sizeof J);
-  J.in = in; J.n = n; J.rb = c.rb; J.nseg = 1; J.seg0 = 0; J.result = result; J.out = out; J.out_cap = out_cap;
+  J.in = in; J.n = n; J.rb = S.c.rb; J.nseg = 1; J.seg0 = 0; J.result = result; J.out = out; J.out_cap = out_cap;
   u32 list0 = 0;
-  g_s = SpecRun{&S, &list0, &J, args[4], cand != 0, 1};
+  g_s = SpecRun{&S, &list0, &J, 1};
   Body b = nullptr;
   switch (args[4]) {
-    case 0: b = cand ? direct_body<1, true> : g_duo ? direct2_body<1> : direct_body<1, false>; break;
-    case 1: b = cand ? direct_body<2, true> : g_duo ? direct2_body<2> : direct_body<2, false>; break;
-    case 2: b = cand ? direct_body<4, true> : g_duo ? direct2_body<4> : direct_body<4, false>; break;
-    default: b = cand ? direct_body<8, true> : g_duo ? direct2_body<8> : direct_body<8, false>; break;
+    case 0: b = direct_body<1>; break;
+    case 1: b = direct_body<2>; break;
+    case 2: b = direct_body<4>; break;
+    default: b = direct_body<8>; break;
   }
   gridDim = {1, 1, 1};
-  const char* e = wave(b, 0, g_duo && !cand ? 128 : 64);
+  const char* e = wave(b, 0, 192);
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   if (result[2]) return -2;
   return (long)result[1];
-}
-
-// ---- candidate table with the long-run hand-off: keys (thread-serial), a stable sort, sweep (thread-serial, runs longer than
-// klong queued), lz77_cand_sweep_long_kernel on emulated waves -- as cand_build() launches them ---------------------------
-namespace {
-struct LongRun { const CandJob* jobs; const u64* keys; const u32* vals; u64 total; const u32* q; u32 cap; };
-LongRun g_l;
-template <int NB> void long_body() { lz77_cand_sweep_long_kernel<NB>(g_l.jobs, g_l.keys, g_l.vals, g_l.total, g_l.q, g_l.cap); }
-}
-extern "C" long cand_long_emu(const u8* in, u32 n, const int32_t args[9], u32 klong, u32* cand, u32* nlong_out, char* err, u32 err_cap) {
-  CandJob J;
-  LzCfg& c = J.c;
-  c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
-  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
-  const u32 mmb = args[2] + 4;
-  c.upd_limit = n > mmb ? n - mmb : 0;
-  J.pos0 = 0; J.cand = cand; J.lb = (u32)args[4]; J.pad = 0;
-  if (!n) return 0;
-  std::vector<u64> k0(n), k1(n);
-  std::vector<u32> v0(n), v1(n);
-  serial(5, 1, 256, [&] { lz77_cand_keys_kernel(&J, k0.data(), v0.data()); });
-  std::vector<u32> idx(n);
-  for (u32 i = 0; i < n; ++i) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return k0[a] < k0[b]; });
-  for (u32 i = 0; i < n; ++i) { k1[i] = k0[idx[i]]; v1[i] = v0[idx[i]]; }
-  const u32 cap = klong ? n / klong + 1 : 0;
-  std::vector<u32> q(2 + 2 * (size_t)cap + 2, 0);
-  const u32 grid = (n + 63) / 64;
-#define EMU_SWEEP(NBV) serial(grid, 1, 64, [&] { lz77_cand_sweep_kernel<NBV>(&J, k1.data(), v1.data(), (u64)n, q.data(), cap, klong); })
-  switch (args[4]) { case 0: EMU_SWEEP(1); break; case 1: EMU_SWEEP(2); break; case 2: EMU_SWEEP(4); break; default: EMU_SWEEP(8); break; }
-#undef EMU_SWEEP
-  if (nlong_out) *nlong_out = q[0];
-  g_l = LongRun{&J, k1.data(), v1.data(), (u64)n, q.data(), cap};
-  Body b = nullptr;
-  switch (args[4]) { case 0: b = long_body<1>; break; case 1: b = long_body<2>; break; case 2: b = long_body<4>; break; default: b = long_body<8>; break; }
-  const u32 waves = std::min<u32>(cap, 3);                   // fewer waves than runs: the stride loop is exercised too
-  gridDim = {waves, 1, 1};
-  for (u32 w = 0; w < waves; ++w) {
-    const char* e = wave(b, w);
-    if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
-  }
-  return (long)n;
 }

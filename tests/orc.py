@@ -19,7 +19,7 @@ def _build():
 
 _L = C.CDLL(_build())
 _u8p = C.POINTER(C.c_ubyte)
-for name in ("orc_suffix_array", "orc_bwt_encode", "orc_lz77_sa_encode", "orc_lz77_sa_decisions", "orc_chunk", "orc_lz77_encode", "orc_lz77_cand", "orc_lz77_encode_cand", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
+for name in ("orc_suffix_array", "orc_bwt_encode", "orc_lz77_sa_encode", "orc_lz77_sa_decisions", "orc_chunk", "orc_lz77_encode", "orc_lz77_decode", "orc_compress_block", "orc_decompress_block", "orc_fragment_and_hash"):
     getattr(_L, name).restype = C.c_long
 
 
@@ -110,27 +110,6 @@ def lz77_encode(b, args, trace=False):
     if trace:
         t = [(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]) for i in range(nt.value)]
         return bytes(out[:r]), t
-    return bytes(out[:r])
-
-
-def lz77_cand(b, args):
-    """cand[q*(bucket+1)+k] = the table word LZBuffer's search at q reads from ht[h1 ^ k] (numpy uint32 array)"""
-    import numpy as np
-    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
-    cand = np.zeros(max(1, len(b) << args[4]), dtype=np.uint32)
-    r = _L.orc_lz77_cand(_buf(b), C.c_long(len(b)), a, cand.ctypes.data_as(C.POINTER(C.c_uint32)))
-    if r < 0:
-        raise RuntimeError("orc_lz77_cand failed: %d" % r)
-    return cand[: len(b) << args[4]]
-
-
-def lz77_encode_from_cand(b, args, cand):
-    a = (C.c_int * 9)(*(list(args) + [0] * 9)[:9])
-    cap = len(b) + len(b) // 8 + 1024
-    out = (C.c_ubyte * cap)()
-    r = _L.orc_lz77_encode_cand(_buf(b), C.c_long(len(b)), a, cand.ctypes.data_as(C.POINTER(C.c_uint32)), out, C.c_long(cap))
-    if r < 0:
-        raise RuntimeError("orc_lz77_encode_cand failed: %d" % r)
     return bytes(out[:r])
 
 

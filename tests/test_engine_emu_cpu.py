@@ -111,12 +111,6 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
              ("test_gpu_parity.py", ["-k", "journaling or lz77"], 900),
              ("test_gpu_parity.py", ["-k", "not (fragmenter or sha or dedup or e8e9 or shim or journaling or lz77)"], 900),
              ("test_gpu_round2.py", ["-k", "shim or jidac or resident"], 900), ("test_gpu_round2.py", ["-k", "not (shim or jidac or resident)"], 900)]
-    # the experimental paths (off by default, not yet timed on hardware): candidate tables of the LZ77 parse through the real
-    # entry points, the hand-written radix sort under the suffix array and under the candidate tables
-    exp = {"ZPQ_TEST_EXPERIMENTAL": "1"}
-    jobs += [("test_gpu_lz_cand.py", ["-k", "sequential_table or direct"], 900, exp),
-             ("test_gpu_lz_cand.py", ["-k", "sequential_table"], 900, dict(exp, ZPQ_SORT="own")),
-             ("test_gpu_sa.py", ["-k", "suffix_array_equals_oracle or bwt_equals_oracle"], 900, {"ZPQ_SORT": "own"})]
     # row (e): the journaling add sharded over two PROCESSES (gloo, world size 2), each with its own emulated engine, gives
     # the single-GPU archive
     jobs.append(("test_sharded_add.py", ["-k", "flags0 or flags2 or failing"], 900))
@@ -127,4 +121,4 @@ def test_the_gpu_test_files_pass_on_the_emulated_engine():
     bad = [(n, rc, out) for n, rc, t, out in res if rc != 0]
     assert not bad, "\n\n".join("%s rc=%d\n%s" % b for b in bad)
     passed = sum(int(out.split(" passed")[0].split()[-1]) for _, _, _, out in res if " passed" in out)
-    assert passed >= 140, report
+    assert passed >= 115, report

@@ -54,18 +54,9 @@ A3 = [[4, 1, 5, 0, 3, 15], [0, 1, 4, 0, 1, 14], [5, 1, 4, 0, 2, 15]]
 
 
 SETTINGS = [
-    ("default", {}, 2, A3[:2], None),                                                                 # table states, 1 MiB segments (one per block here)
-    ("table-segments", {"ZPQ_LZ_SEG": "65536"}, 6, A3[:1], None),                                     # table states, several speculative segments
-    ("table-direct", {"ZPQ_LZ_DIRECT": "1"}, 2, A3[2:], None),                                        # one workgroup per block writes the stream itself
-    ("table-segments-one-wave", {"ZPQ_LZ_SEG": "65536", "ZPQ_LZ_DUO": "0"}, 6, A3[:1], None),         # (the three above: two waves per segment / block, lz77_duo.inc; these two: the one-wave walk)
-    ("table-direct-one-wave", {"ZPQ_LZ_DIRECT": "1", "ZPQ_LZ_DUO": "0"}, 2, A3[2:], None),
-    ("cand-segments", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536"}, 8, A3, None),                      # candidate tables, speculative segments
-    ("cand-direct", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_DIRECT": "1"}, 6, A3, None),                         # candidate tables, one wave per block
-    ("cand-long-runs", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_LZ_CAND_LONG": "50"}, 6, A3, None),   # ... long runs handed to whole waves
-    ("cand-pipe-segments", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_SEG": "65536"}, 8, A3, None),   # the candidate walk software-pipelined (lz77_pipe.inc)
-    ("cand-pipe-direct", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_PIPE": "1", "ZPQ_LZ_DIRECT": "1"}, 6, A3, None),
-    ("cand-shared-sort-arena", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_CAND_SHARED_SORT": "1", "ZPQ_LZ_SEG": "65536"}, 4, A3[:2], None),
-    ("cand-own-sort", {"ZPQ_LZ_CAND": "1", "ZPQ_LZ_SEG": "65536", "ZPQ_SORT": "own"}, 2, A3[:1], ["mixed", "tiny"]),   # ... over the hand-written radix sort
+    ("default", {}, 2, A3[:2], None),                                                                 # table states, 2 MiB segments (one per block here)
+    ("table-segments", {"ZPQ_LZ_SEG": "65536"}, 6, A3, None),                                         # table states, several speculative segments
+    ("table-direct", {"ZPQ_LZ_DIRECT": "1"}, 4, A3, None),                                            # one workgroup per block writes the stream itself
 ]
 
 

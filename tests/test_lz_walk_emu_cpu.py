@@ -1,7 +1,8 @@
-"""lz_walk -- the heart of the LZ77 hash-table parse (zpaqfranz_amd/csrc/lz77_enc.hip) -- run on the CPU: tests/cpp/walk_emu.cpp
-compiles THE DEVICE SOURCE for the host and runs it as one emulated wave (64 lanes as fibres in lockstep, the wave-level
-operations as rendezvous).  Its tokens must be the oracle's, both in the table form the GPU runs by default and in the
-experimental candidate-table form (ZPQ_LZ_CAND).  Needs the ROCm clang++ (address spaces, ext vectors) as a host compiler."""
+"""The LZ77 hash-table parse (zpaqfranz_amd/csrc/lz77_enc.hip, lz77_duo.inc) run on the CPU: tests/cpp/walk_emu.cpp compiles
+THE DEVICE SOURCE for the host and runs it as emulated waves (64 lanes as fibres in lockstep, the wave-level operations as
+rendezvous; the three waves of a parse workgroup -- producer | evaluator | chain -- as 192 fibres whose spin loops yield to
+each other).  Tokens and code streams must be the oracle's.  Needs the ROCm clang++ (address spaces, ext vectors) as a
+host compiler."""
 import ctypes as C
 import os
 import subprocess
@@ -53,146 +54,97 @@ def _pool_map(fn, jobs):
         return [r for r in pool.map(fn, jobs) if r]
 
 
-def _walk_case(job):
-    args, cand = job
+def _walk_case(args):
     L = _SO[0]
     L.walk_emu.restype = C.c_long
-    L.walk_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.walk_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     for name, b in _inputs().items():
         n = len(b)
-        words = (n << args[4]) if cand else (1 << args[5])
+        words = 1 << args[5]
         raw = np.zeros(words + 16, dtype=np.uint32)
         off = (-(raw.ctypes.data // 4)) % 4                      # 16-byte aligned view
         tab = raw[off:off + words]
-        if cand:
-            tab[:] = orc.lz77_cand(b, args)
         cap = n // 4 + 16
         tok = np.zeros(3 * cap, dtype=np.uint32)
         err = C.create_string_buffer(256)
-        r = L.walk_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, tok.ctypes.data, cap, err, 256)
+        r = L.walk_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, tok.ctypes.data, cap, err, 256)
         if r < 0:
-            return (args, cand, name, err.value.decode())
+            return (args, name, err.value.decode())
         got = [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
         want = orc.lz77_encode(b, args, trace=True)[1]
         if got != want:
-            return (args, cand, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+            return (args, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
     return None
 
 
 def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(tmp_path_factory):
+    """lz_walk, the one-wave walk (what the seam and stitch kernels call)"""
     _lib(tmp_path_factory)
-    bad = _pool_map(_walk_case, [(a, c) for a in ARGS for c in (False, True)])
+    bad = _pool_map(_walk_case, ARGS)
     assert not bad, bad
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # The whole segment speculation of a block, kernel by kernel as encode_batch() launches them: table states (the copy and
-# scatter kernels) or a candidate table, lz77_spec_kernel and lz77_seam_kernel per segment, lz77_stitch_kernel,
-# lz77_move_tokens_kernel.  Segments of a few KiB put seams, swallowed segments and re-walks into small inputs.
+# scatter kernels), lz77_spec3_kernel -- a workgroup of three waves per segment: producer | evaluator | chain with their
+# rings in LDS (lz77_duo.inc) --, lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel.  Segments of a
+# few KiB put seams, swallowed segments and re-walks into small inputs.
 # ---------------------------------------------------------------------------------------------------------------------
 SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 6, 0, 2, 15], 16384), ([5, 1, 5, 0, 0, 14], 4096)]
 
 
 def _spec_case(job):
-    args, seg, cand = job
+    args, seg = job
     L = _SO[0]
-    L.walk_emu_duo(1 if cand == 2 else 0)          # 2: the table walk as two waves per segment (lz77_duo.inc)
-    cand = cand == 1
     L.spec_emu.restype = C.c_long
-    L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     inputs = _inputs()
     inputs["seams"] = (datagen.text_like(5000, 11) * 3)[:14000] + bytes(9000) + datagen.text_like(5000, 12)   # matches across several segment edges, a swallowed segment
     for name, b in inputs.items():
         n = len(b)
-        ptr = None
-        if cand:
-            t = orc.lz77_cand(b, args)
-            raw = np.zeros(len(t) + 16, dtype=np.uint32)
-            off = (-(raw.ctypes.data // 4)) % 4
-            tab = raw[off:off + len(t)]
-            tab[:] = t
-            ptr = tab.ctypes.data
         cap = n // 4 + 16
         tok = np.zeros(3 * cap, dtype=np.uint32)
         err = C.create_string_buffer(256)
-        r = L.spec_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), seg, ptr, tok.ctypes.data, cap, err, 256)
+        r = L.spec_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), seg, tok.ctypes.data, cap, err, 256)
         if r < 0:
-            return (args, seg, cand, name, r, err.value.decode())
+            return (args, seg, name, r, err.value.decode())
         got = [(int(tok[i]), int(tok[cap + i]), int(tok[2 * cap + i])) for i in range(r)]
         want = orc.lz77_encode(b, args, trace=True)[1]
         if got != want:
-            return (args, seg, cand, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
+            return (args, seg, name, len(got), len(want), next(((i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w), None))
     return None
 
 
 def test_segment_speculation_on_emulated_waves_gives_the_oracles_tokens(tmp_path_factory):
     _lib(tmp_path_factory)
-    bad = _pool_map(_spec_case, [(a, sg, c) for a, sg in SPEC_CASES for c in (0, 1, 2)])
+    bad = _pool_map(_spec_case, SPEC_CASES)
     assert not bad, bad
 
 
-def _direct_case(job):
-    args, cand = job
+def _direct_case(args):
     L = _SO[0]
-    L.walk_emu_duo(1 if cand == 2 else 0)
-    cand = cand == 1
     L.direct_emu.restype = C.c_long
-    L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
+    L.direct_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     for name, b in _inputs().items():
         n = len(b)
-        words = (n << args[4]) if cand else (1 << args[5])
+        words = 1 << args[5]
         raw = np.zeros(words + 16, dtype=np.uint32)
         off = (-(raw.ctypes.data // 4)) % 4
         tab = raw[off:off + words]
-        if cand:
-            tab[:] = orc.lz77_cand(b, args)
         cap = n + n // 8 + 1024
         out = np.zeros(cap, dtype=np.uint8)
         err = C.create_string_buffer(256)
-        r = L.direct_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, 1 if cand else 0, out.ctypes.data, cap, err, 256)
+        r = L.direct_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), tab.ctypes.data, out.ctypes.data, cap, err, 256)
         if r < 0:
-            return (args, cand, name, r, err.value.decode())
+            return (args, name, r, err.value.decode())
         if bytes(out[:r]) != orc.lz77_encode(b, args):
-            return (args, cand, name, "stream differs")
+            return (args, name, "stream differs")
     return None
 
 
-def test_direct_kernel_on_an_emulated_wave_writes_the_oracles_stream(tmp_path_factory):
-    """lz77_direct_kernel: one wave parses a block and writes the code stream itself (literal runs spread over the lanes,
-    match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
+def test_direct_kernel_on_emulated_waves_writes_the_oracles_stream(tmp_path_factory):
+    """lz77_direct3_kernel: one workgroup parses a block and its chain wave writes the code stream itself (literal runs spread
+    over the lanes, match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
     _lib(tmp_path_factory)
-    bad = _pool_map(_direct_case, [(a, c) for a in ([4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]) for c in (0, 1, 2)])
+    bad = _pool_map(_direct_case, [[4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]])
     assert not bad, bad
-
-
-def _long_case(args):
-    L = _SO[0]
-    L.cand_long_emu.restype = C.c_long
-    L.cand_long_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
-    inputs = {"text": datagen.text_like(50000, 1), "runs": bytes(9000) + b"ab" * 6000 + datagen.random_bytes(500, 4), "mixed": datagen.mixed(30000, 3),
-              "tiny": b"abcabcabc", "one": b"x"}
-    seen_long = 0
-    for name, b in inputs.items():
-        want = orc.lz77_cand(b, args)
-        for klong in (0, 16, 100, 1000):
-            n = len(b)
-            cand = np.zeros(max(1, n << args[4]), dtype=np.uint32)
-            nl = C.c_uint32(0)
-            err = C.create_string_buffer(256)
-            r = L.cand_long_emu(b + bytes(64), n, (C.c_int32 * 9)(*(list(args) + [0] * 9)[:9]), klong, cand.ctypes.data, C.byref(nl), err, 256)
-            if r < 0:
-                return ("error", args, name, klong, err.value.decode())
-            if not np.array_equal(cand[: len(want)], want):
-                return ("differs", args, name, klong, nl.value)
-            seen_long += nl.value
-    return ("ok", seen_long)
-
-
-def test_long_runs_swept_by_a_whole_wave_give_the_sequential_table(tmp_path_factory):
-    """Candidate tables with the long-run hand-off: keys and the sweep thread by thread, runs longer than klong queued and
-    swept by lz77_cand_sweep_long_kernel on emulated waves (pieces per lane, 'later write wins per slot' scanned over the
-    lanes, second sweep writing).  Small klong values put hundreds of runs through the wave form."""
-    _lib(tmp_path_factory)
-    res = _pool_map(_long_case, [[4, 1, 5, 0, 3, 16], [0, 1, 4, 0, 1, 15], [4, 1, 5, 0, 0, 16]])
-    assert all(r[0] == "ok" for r in res), res
-    assert all(r[1] > 300 for r in res), res

@@ -1,6 +1,6 @@
 """Random inputs and settings through the frag_emu emulation (tests/cpp/frag_emu.cpp: the engine's DEVICE source -- and for the
 LZ77 encoder its host code too -- on the CPU fibre emulator) against the oracle.  usage: python fuzz_fragmenter.py <seed> <seconds>
-(the LZ77 switches ZPQ_LZ_CAND / ZPQ_LZ_SEG / ZPQ_LZ_DIRECT / ZPQ_SORT select the path, as on the GPU)."""
+(the LZ77 switches ZPQ_LZ_SEG / ZPQ_LZ_DIRECT select the path, as on the GPU)."""
 import os, subprocess, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SO = os.path.join(tempfile.gettempdir(), "frag_emu.so")

@@ -1,5 +1,5 @@
-# Round 4: two waves per block on one table (lz77_duo.inc, default on), after the relaxed hand-off, the one-pass decision and the
-# producer's fast path for swallowed windows -- parity on the chip and the bench lines
+# Round 4: three waves per block on one table (lz77_duo.inc, default on): producer | evaluator | chain --
+# parity on the chip and the bench lines
 R=$GRAFT_REPO_ROOT
 T=${1:-r04l}
 mkdir -p $R/gpurun_out

@@ -18,11 +18,11 @@ args = [[4, 1, 5, 0, 3, 24]] * nb
 e.lz77_encode(blocks, args)
 out = (ctypes.c_ulonglong * 8)()
 e.L.zpq_debug_lzprof(out, 1)
-_o2 = (ctypes.c_ulonglong * 16)(); e.L.zpq_debug_lzprof2(_o2, 1)
+_o2 = (ctypes.c_ulonglong * 24)(); e.L.zpq_debug_lzprof2(_o2, 1)
 t = time.time(); e.lz77_encode(blocks, args); dt = time.time() - t
 e.L.zpq_debug_lzprof(out, 1)
 v = list(out); tot = sum(v)
-out2 = (ctypes.c_ulonglong * 16)()
+out2 = (ctypes.c_ulonglong * 24)()
 e.L.zpq_debug_lzprof2(out2, 1)
 w = nb * (1 << 24) / 64
 print("%%s: %%.1f ms wall" %% (os.environ.get("LABEL"), dt * 1e3))
@@ -30,13 +30,13 @@ if tot:
     print("   one wave: cycles/window %%.0f; by phase (hash, rows+forward, candidates, decision, chain, insert): %%s" %% (tot / w, [round(x / w) for x in v[:6]]))
 if sum(out2):
     v2 = list(out2)
-    print("   producer cycles/window (ring wait, hash, rows+forward, ring write, insert+wait, swallowed): %%s = %%.0f" %% ([round(x / w) for x in v2[:6]], sum(v2[:8]) / w))
-    print("   consumer cycles/window (head wait, ring read, candidates, decision, chain): %%s = %%.0f" %% ([round(x / w) for x in v2[8:13]], sum(v2[8:16]) / w))
+    print("   producer  cycles/window (ring wait, hash, rows+forward, ring write, insert+wait, swallowed): %%s = %%.0f" %% ([round(x / w) for x in v2[:6]], sum(v2[:8]) / w))
+    print("   evaluator cycles/window (ring-1 wait, read, ring-2 wait, candidates, decision, swallowed, write): %%s = %%.0f" %% ([round(x / w) for x in v2[8:15]], sum(v2[8:16]) / w))
+    print("   chain     cycles/window (ring-2 wait, read, -, -, chain): %%s = %%.0f" %% ([round(x / w) for x in v2[16:21]], sum(v2[16:24]) / w))
 ''' % {"root": ROOT}
-for label, env in (("silesia-like units, direct one wave", {"ZPQ_LZ_DIRECT": "1", "ZPQ_LZ_DUO": "0", "CORPUS": "silesia", "NB": "12"}),
-                   ("silesia-like units, direct two waves", {"ZPQ_LZ_DIRECT": "1", "CORPUS": "silesia", "NB": "12"}),
-                   ("silesia-like units, spec two waves", {"CORPUS": "silesia", "NB": "12"}),
-                   ("silesia-like units, spec one wave", {"ZPQ_LZ_DUO": "0", "CORPUS": "silesia", "NB": "12"})):
+for label, env in (("silesia-like units, direct three waves", {"ZPQ_LZ_DIRECT": "1", "CORPUS": "silesia", "NB": "12"}),
+                   ("silesia-like units, spec three waves", {"CORPUS": "silesia", "NB": "12"}),
+                   ("mixed, direct three waves", {"ZPQ_LZ_DIRECT": "1"}), ("mixed, spec three waves", {})):
     e = dict(os.environ, LABEL=label, **env)
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=e, timeout=600)
     print(r.stdout.strip() or r.stderr[-800:])

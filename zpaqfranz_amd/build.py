@@ -10,14 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libzpaqhip.so")
-SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "twins.hip", "radix.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "cm_jit.hip", "config.hip", "e8e9.hip", "checksum.hip", "ibwt.hip"]
+SOURCES = ["ctx.hip", "sha.hip", "fragment.hip", "twins.hip", "dedup.hip", "lz77_enc.hip", "lz77_sa.hip", "lz77_dec.hip", "block.hip", "unblock.hip", "cm.hip", "cm_jit.hip", "config.hip", "e8e9.hip", "checksum.hip", "ibwt.hip"]
 
 
 def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(CSRC, "lz77_cand.inc"), os.path.join(CSRC, "lz77_pipe.inc"), os.path.join(CSRC, "lz77_duo.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(CSRC, "lz77_duo.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
             os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h"),
             os.path.join(HERE, "shim", "jidac_gpu.cpp")]
     return any(os.path.getmtime(d) > t for d in deps)

@@ -13,12 +13,17 @@
 //    chain "take the match and skip blen, or emit literals" is serial: a wave-uniform loop over
 //    v_readlane'd results that jumps over literal runs with one ballot.  Positions whose candidates
 //    hit the 32-byte compare cap are re-evaluated exactly with 512-bytes-per-step whole-wave compares.
-//  * Blocks are cut into segments of 1 MiB.  The table state at every segment start is built up
+//  * What touches the table, what evaluates candidates and what chains tokens are three WAVES of one workgroup
+//    (lz77_duo.inc: producer | evaluator | chain, rings in LDS): only the chain depends on the parse, so one table
+//    serves three instruction streams.  lz_walk below is the same walk in one wave (seams and re-walks: short).
+//  * Blocks are cut into segments of 2 MiB.  The table state at every segment start is built up
 //    front (copy + atomicMax scatter), every segment is parsed speculatively from its own start
-//    (lz77_spec_kernel, one wave per segment), and one wave per block walks the true chain
+//    (lz77_spec3_kernel, one workgroup per segment), and one wave per block walks the true chain
 //    (lz77_stitch_kernel): it re-parses from where the previous segment really ended until one of
 //    its matches ends exactly where a speculative match ends -- both chains are then in the same
 //    state (lit == 0), so the rest of that segment's speculative tokens are adopted verbatim.
+//    With hundreds of blocks there is no speculation: one workgroup per block parses and writes the code
+//    stream itself (lz77_direct3_kernel).
 //  * Tokens -> bits: a workgroup scan gives every token its bit offset; code bits and literal
 //    bytes are OR-ed into the zeroed output in parallel (LSB-first, :6171-6186).
 // Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
@@ -30,8 +35,6 @@
 #include <mutex>
 #include <stdlib.h>
 
-#include <rocprim/device/device_radix_sort.hpp>     // (only the experimental candidate-table path sorts)
-
 #include "zpq_internal.h"
 #define ZPQ_WAIT_VMCNT0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
@@ -42,18 +45,16 @@ constexpr u32 kMaxMatch = (1u << 14) * 3;   // ZSFX/libzpaq.cpp:6258 (BUFSIZE*3)
 constexpr u32 kMaxLiteral = (1u << 14) / 4;  // :6259
 constexpr u32 kCap = 32;                     // speculative compare cap (bytes)
 constexpr u32 kNoCand = 0xffffffffu;
-constexpr u32 kSegMin = 1u << 20;            // smallest speculation segment (more segments do not help: the parse is bound by random-access throughput)
+constexpr u32 kSegMin = 2u << 20;            // smallest speculation segment: 15 table states per 16 MiB block instead of 31, and the three-wave parse of
+                                             // 2 MiB (~140 ms) stays below the block's checksum chain (215 ms); measured 98 against 109 ms per headline step
 constexpr u32 kMaxSeg = 64;                  // segments per block (64 MiB blocks at most)
 
-#define ZPQ_CAND_KERNEL(bounds) __global__ __launch_bounds__(bounds)
-#define ZPQ_CAND_DEV __device__ __forceinline__
-#define ZPQ_CAND_TID ((u32)threadIdx.x)
-#define ZPQ_CAND_BID_X ((u32)blockIdx.x)
-#define ZPQ_CAND_BID_Y ((u32)blockIdx.y)
-#define ZPQ_CAND_GDIM_X ((u32)gridDim.x)
-#define ZPQ_CAND_GLOBAL __attribute__((address_space(1)))
-#define ZPQ_CAND_ATOMIC_INC(p) atomicAdd((p), 1u)
-#include "lz77_cand.inc"      // LzCfg, CandJob, lz77_cand_keys_kernel, lz77_cand_sweep_kernel (also compiled for the host by tests/cpp/cand_host.cpp)
+struct LzCfg {
+  const u8* in;
+  u32 n;
+  u32 minMatch, bucket, htbits, checkbits, shift1, rb;
+  u32 upd_limit;   // positions < upd_limit are inserted (i + minMatchBoth < n)
+};
 
 // per (block, segment)
 struct LzSegDev {
@@ -253,11 +254,7 @@ struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 // from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
 // matches ends where a speculative match ends and returns that token's index (else -1).
 //
-// CAND (experimental, ZPQ_LZ_CAND=1; written at the end of round 3, not yet run on hardware): `ht_generic` is the block's
-// precomputed candidate table instead -- cand[q * NB + k] = the word the reference's search at position q reads from
-// ht[h1 ^ k], i.e. the table as of q, already in probe order (lz77_cand_sweep_kernel).  Lookups become one sequential
-// read per position, nothing is inserted or forwarded, and windows a match swallowed are skipped.
-template <int NB, bool DIRECT = false, bool CAND = false>
+template <int NB, bool DIRECT = false>
 __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
                        SpecList* spec, unsigned long long* T_generic, BitSink* bits = nullptr) {
   const u32 lane = (u32)lane_id();
@@ -276,9 +273,6 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 #endif
 
   for (u32 base = wbase; base < x1 && base < n; base += 64) {
-    if constexpr (CAND) {
-      if (cur >= base + 64) { base += ((cur - base) & ~63u) - 64u; continue; }   // nothing to insert: go to the window that holds cur
-    }
     const u32 q = base + lane;
     const bool inb = q < n && q < x1;
     u32 wend = base + 64 < x1 ? base + 64 : x1;
@@ -300,52 +294,52 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 
     LZ_T(0);
     u32 ent[NB];
-    if (look) GroupLoad<NB>::ld((g_cu32*)(ht + (CAND ? (size_t)q * NB : (size_t)grp)), ent);   // bypasses L1: the table is rewritten by this wave
+    if (look) GroupLoad<NB>::ld((g_cu32*)(ht + (size_t)grp), ent);   // bypasses L1: the table is rewritten by this wave
     else {
 #pragma unroll
       for (int j = 0; j < NB; ++j) ent[j] = 0;
     }
     // ---- forward inserts of earlier lanes in this window; find superseded stores ---------------
     bool superseded = false;
-    if constexpr (!CAND) {
-      const u32 tk = (grp >> 3) & 255u;
-      if (inb) __hip_atomic_fetch_or(&T[tk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      __builtin_amdgcn_wave_barrier();
-      unsigned long long cm = inb ? Tv[tk] : 0ull;
-      cm &= ~(1ull << lane);
-      while (__ballot(cm != 0)) {
-        const int k = cm ? __builtin_ctzll(cm) : 0;  // ascending: later lanes overwrite earlier ones
-        const u32 sk = __shfl(slot, k), vk = __shfl(val, k);
-        const bool ik = __shfl((int)ins, k) != 0;
-        if (cm) {
-          if (ik && (u32)k < lane && (sk & ~C.bucket) == grp) {
+    {
+    const u32 tk = (grp >> 3) & 255u;
+    if (inb) __hip_atomic_fetch_or(&T[tk], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long cm = inb ? Tv[tk] : 0ull;
+    cm &= ~(1ull << lane);
+    while (__ballot(cm != 0)) {
+      const int k = cm ? __builtin_ctzll(cm) : 0;  // ascending: later lanes overwrite earlier ones
+      const u32 sk = __shfl(slot, k), vk = __shfl(val, k);
+      const bool ik = __shfl((int)ins, k) != 0;
+      if (cm) {
+        if (ik && (u32)k < lane && (sk & ~C.bucket) == grp) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-              if ((sk & C.bucket) == (u32)j) ent[j] = vk;
-          }
-          if (ik && (u32)k > lane && sk == slot) superseded = true;
-          cm &= cm - 1;
+          for (int j = 0; j < NB; ++j)
+            if ((sk & C.bucket) == (u32)j) ent[j] = vk;
         }
+        if (ik && (u32)k > lane && sk == slot) superseded = true;
+        cm &= cm - 1;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (inb) Tv[tk] = 0ull;
     }
+    __builtin_amdgcn_wave_barrier();
+    if (inb) Tv[tk] = 0ull;
+  }
     LZ_T(1);
     // ---- reorder the group into probe order ht[h1^k], k = 0..bucket (:6397) ---------------------
-    if constexpr (!CAND) {
-      const u32 hb = h & C.bucket;
+    {
+    const u32 hb = h & C.bucket;
 #pragma unroll
-      for (int bit = 1; bit < NB; bit <<= 1) {
-        const bool sw = (hb & (u32)bit) != 0;
+    for (int bit = 1; bit < NB; bit <<= 1) {
+      const bool sw = (hb & (u32)bit) != 0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (!(j & bit)) {
-            u32 a = ent[j], b = ent[j | bit];
-            ent[j] = sw ? b : a;
-            ent[j | bit] = sw ? a : b;
-          }
-      }
+      for (int j = 0; j < NB; ++j)
+        if (!(j & bit)) {
+          u32 a = ent[j], b = ent[j | bit];
+          ent[j] = sw ? b : a;
+          ent[j | bit] = sw ? a : b;
+        }
     }
+  }
     // ---- speculative candidate evaluation (lanes at or after the chain head) -------------------
     // All first 16-byte loads are issued before any is used: one memory round trip for the group.
     u32 cp[NB], cl[NB];
@@ -522,10 +516,10 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
     }
     LZ_T(4);
     // ---- insert this window's positions (latest writer of a slot wins) --------------------------
-    if constexpr (!CAND) {
-      if (ins && !superseded) ht[slot] = val;
-      ZPQ_WAIT_VMCNT0;
-    }
+    {
+    if (ins && !superseded) ht[slot] = val;
+    ZPQ_WAIT_VMCNT0;
+  }
     LZ_T(5);
   }
 #ifdef ZPQ_LZ_PROFILE
@@ -533,8 +527,6 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
 #endif
   return -1;
 }
-
-#include "lz77_pipe.inc"       // lz_walk_pipe (experimental: the candidate walk software-pipelined), lz_walk_sel
 
 
 // ---- table state at every segment start --------------------------------------------------------------
@@ -567,121 +559,11 @@ __global__ __launch_bounds__(256) void lz77_table_scatter_kernel(const ScatterJo
   }
 }
 
-// ---- candidate tables (experimental, ZPQ_LZ_CAND=1; not yet run on hardware) -----------------------------------------
-// Every position is inserted whatever the parse decides, so the eight words the reference's search reads at position q
-// are a function of the data.  Sort all positions of a batch by (block, hash group, position); the entries of one
-// group then form a run in position order, and ONE lane sweeps a run carrying the group's bucket+1 table words in
-// registers: write them out as cand[q] (probe order ht[h1 ^ k]), then apply q's own insert.  A run is a serial chain
-// (the most frequent 5-gram of a 16 MiB block of the stand-in: ~150 k entries), the runs are independent.
-// (CandJob and the two kernels: lz77_cand.inc)
-
-// A long run (lz77_cand_sweep_kernel handed its start over) swept by a whole wave: the run is cut into 64 pieces; every
-// lane first sweeps its piece without writing, to learn which slots the piece overwrites and with what (the effect of a
-// piece on the group's words is "later write wins per slot", which composes); an exclusive scan over the lanes gives
-// every piece the words it starts from; then every lane sweeps its piece again, writing.
-template <int NB>
-__global__ __launch_bounds__(64) void lz77_cand_sweep_long_kernel(const CandJob* __restrict__ jobs, const u64* __restrict__ keys,
-                                                                  const u32* __restrict__ vals, u64 total, const u32* __restrict__ longq, u32 long_cap) {
-  const u32 lane = (u32)lane_id();
-  const u32 nlong = longq[0] < long_cap ? longq[0] : long_cap;
-  for (u32 r = blockIdx.x; r < nlong; r += gridDim.x) {
-    const u64 i0 = (u64)longq[2 + 2 * (size_t)r] | ((u64)longq[3 + 2 * (size_t)r] << 32);
-    const u64 g0 = keys[i0] >> 26;
-    // end of the run: first index in (i0, total] whose group differs (every lane does the same binary search)
-    u64 lo = i0, hi = total;                       // keys[lo] is in the run, hi is not (or is the end)
-    while (hi - lo > 1) {
-      const u64 mid = lo + ((hi - lo) >> 1);
-      if ((keys[mid] >> 26) == g0) lo = mid; else hi = mid;
-    }
-    const u64 end = hi, len = end - i0;
-    const u64 piece = (len + 63) / 64;
-    const u64 a = i0 + piece * lane < end ? i0 + piece * lane : end;
-    const u64 b = a + piece < end ? a + piece : end;
-    const CandJob J = jobs[(u32)(g0 >> 22)];
-    u32 v[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) v[j] = 0;
-    u32 has = 0;
-    cand_sweep_range<NB, false>(J, keys, vals, a, b, v, has);
-    // inclusive scan of (v, has) over the lanes: the higher lane's writes win
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u32 ph = __shfl_up(has, d);
-      u32 pv[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) pv[j] = __shfl_up(v[j], d);
-      if (lane >= (u32)d) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) v[j] = (has >> j) & 1u ? v[j] : pv[j];
-        has |= ph;
-      }
-    }
-    // exclusive: what the lanes below leave behind (nothing for lane 0: a run starts from an empty group)
-    u32 s[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { const u32 x = __shfl_up(v[j], 1); s[j] = lane ? x : 0u; }
-    u32 dummy = 0;
-    cand_sweep_range<NB, true>(J, keys, vals, a, b, s, dummy);
-  }
-}
-
-// ---- speculative parse: one wave per segment ------------------------------------------------------------
-template <int NB, bool CAND = false>
-__global__ __launch_bounds__(64) void lz77_spec_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list, const zpq_place P) {
-  // The block-checksum chains (sha1_chain_kernel, other stream) are pure VALU and may land on the same
-  // SIMD: this latency-bound parse must win issue arbitration or its slowest wave doubles the launch.
-  __builtin_amdgcn_s_setprio(3);
-  __shared__ unsigned long long T[256];
-  const u32 lane = (u32)lane_id();
-  // plain launch: segment list[blockIdx.x]; with placement (zpq_internal.h): surplus workgroups over a queue of segments,
-  // a wave parses where it has a SIMD to itself
-  u32 key; bool polite;
-  u32 item = zpq_place_begin(P, key, polite);
-  while (item != 0xffffffffu) {
-    const LzSegDev S = segs[list[item]];
-    T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
-    __builtin_amdgcn_wave_barrier();
-    TokSink sink{S.tpos, S.tlen, S.toff, S.tcap, 0};
-    u32 cur = S.x0, lit = 0;
-    if constexpr (CAND) lz_walk_sel<NB, false, true>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
-    else lz_walk<NB, false, false>(S.c, S.work, S.x0, S.x1, cur, lit, sink, nullptr, T);
-    if (lane == 0) {
-      S.state[0] = sink.n < sink.cap ? sink.n : sink.cap;
-      S.state[1] = cur; S.state[2] = lit; S.state[3] = sink.n > sink.cap;
-    }
-    __builtin_amdgcn_wave_barrier();
-    item = zpq_place_next(P, key, polite);
-  }
-}
-
-// ---- one wave per block, no speculation: parse and emit in one go (many blocks: "one wavefront per ZPAQ block") --------
-template <int NB, bool CAND = false>
-__global__ __launch_bounds__(64) void lz77_direct_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
-                                                         const u32* __restrict__ list) {
-  const LzJobDev J = jobs[list[blockIdx.x]];
-  const LzSegDev S = segs[J.seg0];
-  __shared__ unsigned long long T[256];
-  const u32 lane = (u32)lane_id();
-  T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
-  __builtin_amdgcn_wave_barrier();
-  TokSink sink{nullptr, nullptr, nullptr, 0, 0};
-  BitSink bs;
-  bs.out = (__attribute__((address_space(1))) u8*)J.out; bs.out_cap = J.out_cap;
-  bs.in = (__attribute__((address_space(1))) const u8*)J.in;
-  bs.acc = 0; bs.accbits = 0; bs.bytepos = 0; bs.gap_start = 0; bs.rb = J.rb; bs.overflow = 0;
-  u32 cur = 0, lit = 0;
-  if constexpr (CAND) lz_walk_sel<NB, true, true>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
-  else lz_walk<NB, true, false>(S.c, S.work, 0, J.n, cur, lit, sink, nullptr, T, &bs);
-  const u32 bytes = bs.finish(J.n, lane);
-  const unsigned long long ov = __ballot(bs.overflow != 0);
-  if (lane == 0) { J.result[0] = sink.n; J.result[1] = bytes; J.result[2] = (ov != 0 || bytes > J.out_cap) ? 1u : 0u; }
-}
-
 // ---- seams: one wave per segment boundary -----------------------------------------------------------------
 // Seam k continues the parse from where segment k-1's SPECULATION ended (true whenever segment k-1 got back
 // in step, which the stitch kernel verifies) into segment k, on the pristine table of x0, until one of its
 // matches ends where a speculative match of segment k ends.
-template <int NB, bool CAND = false>
+template <int NB>
 __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restrict__ segs, const u32* __restrict__ list) {
   __builtin_amdgcn_s_setprio(3);
   const u32 si = list[blockIdx.x];
@@ -699,8 +581,7 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
   if (cur == S.x0 && lit == 0) hit = -2;                           // in step from the first position
   else if (cur < S.x1) {
     SpecList sl{S.tpos, S.tlen, S.state[0], 0};
-    if constexpr (CAND) hit = lz_walk_sel<NB, false, true>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
-    else hit = lz_walk<NB, false, false>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+    hit = lz_walk<NB, false>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
   }
   if (lane == 0) {
     S.seam[0] = sink.n < sink.cap ? sink.n : sink.cap;
@@ -714,7 +595,7 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
 // Glues [speculative tokens of segment 0] [seam 1] [speculative tokens of segment 1 from its sync index] ...
 // A seam is used only if it started from the state the true chain really is in; otherwise the segment is
 // re-walked here on work[k-1] (after the speculative pass that table holds exactly the inserts < x0).
-template <int NB, bool CAND = false>
+template <int NB>
 __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restrict__ jobs, const LzSegDev* __restrict__ segs,
                                                          const u32* __restrict__ list) {
   __builtin_amdgcn_s_setprio(3);
@@ -758,9 +639,7 @@ __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restr
     // exact re-walk (rare: the previous segment never got back in step)
     SpecList sl{S.tpos, S.tlen, ns, 0};
     u32* table = k ? segs[J.seg0 + k - 1].work : S.work;
-    int hit;
-    if constexpr (CAND) hit = lz_walk_sel<NB, false, true>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
-    else hit = lz_walk<NB, false, false>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    const int hit = lz_walk<NB, false>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
     T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
     __builtin_amdgcn_wave_barrier();
     if (hit >= 0) { append(0, (u32)hit + 1, ns); cur = S.state[1]; lit = S.state[2]; }
@@ -786,7 +665,7 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
-#include "lz77_duo.inc"        // two waves per block on one table: lz77_spec2_kernel, lz77_direct2_kernel
+#include "lz77_duo.inc"        // three waves per block on one table: lz77_spec3_kernel, lz77_direct3_kernel
 
 #if defined(ZPQ_EMU_WALK_ONLY) && !defined(ZPQ_EMU_FULL)
 }  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled.
@@ -921,9 +800,9 @@ __global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev*
 extern "C" size_t zpq_lz77_bound(size_t n) { return n + n / 64 + 64; }   // level 2 spends a byte per 64 literals, level 1 15 bits per 4096
 
 #ifdef ZPQ_LZ_PROFILE
-extern "C" int zpq_debug_lzprof2(unsigned long long out[16], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzprof2), 128) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzprof2), z, 128); }
+extern "C" int zpq_debug_lzprof2(unsigned long long out[24], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzprof2), 192) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzprof2), z, 192); }
   return 0;
 }
 extern "C" int zpq_debug_lzprof(unsigned long long out[8], int reset) {
@@ -976,14 +855,6 @@ static T* carve(u8*& p, size_t count) {
 
 // HBM a job needs while it is parsed with segments of kSegBytes: 2*segments-1 hash tables plus the token lists
 static size_t job_bytes_direct(const zpq_lz77_job& z) { return ((size_t)4 << z.args[5]) + 4096; }
-// the same with a candidate table instead of table states (ZPQ_LZ_CAND): bucket+1 words per position, the sort's double
-// buffers (8 + 4 bytes per position, twice) and its temporary storage (bounded by another 12)
-static size_t job_bytes_cand(const zpq_lz77_job& z, u32 kSegBytes, bool direct) {
-  const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
-  const size_t mm = (size_t)(z.args[2] >= 4 ? z.args[2] : 4);
-  const size_t toks = direct ? 0 : (size_t)z.n / mm + 3 + 3 * nseg;
-  return (size_t)z.n * (((size_t)4 << z.args[4]) + 36) + toks * (16 + 12 + (nseg > 1 ? 12 : 0)) + 4096;
-}
 static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   const u32 nseg = std::max<u32>(1, (u32)(((u64)z.n + kSegBytes - 1) / kSegBytes));
   // tokens are matches of at least args[2] bytes that do not overlap: n / minMatch of them at most.  Final list 4 words
@@ -993,103 +864,29 @@ static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + toks * (16 + 12 + (nseg > 1 ? 12 : 0));
 }
 
-// Candidate tables of a batch: keys of every position, one sort, one sweep.  `buf` holds two key and two value arrays
-// (24 bytes per position) followed by `temp_bytes` of temporary storage for the sort; every job's `cand` pointer must have
-// room for n << lb words.
-// EXPERIMENTAL (ZPQ_LZ_CAND_SHARED_SORT=1, with ZPQ_LZ_CAND=1): keys, values and the sort's temporary -- 24+ bytes per position,
-// 5 GB for a job of the headline -- are needed from the keys kernel to the end of the sweep only, a few milliseconds of
-// chip-filling kernels that gain nothing from overlapping with another job's.  One arena per DEVICE then serves every
-// context of the process instead of one per context (13 -> 8 GB per job in flight): a user makes its stream wait for the
-// event the previous user recorded behind its sweep, enqueues, records the event anew.
-struct CandArena { std::mutex mu; void* buf = nullptr; size_t cap = 0; hipEvent_t last = nullptr; };
-static CandArena g_cand_arena[64];
-static bool cand_shared_sort() { static const bool on = [] { const char* e = getenv("ZPQ_LZ_CAND_SHARED_SORT"); return e && atoi(e) != 0; }(); return on; }
-
-static int cand_build(zpq_ctx* ctx, hipStream_t st, const std::vector<CandJob>& cjobs, CandJob* d_cjobs, u64 positions, u32 max_n, u8* buf,
-                      size_t temp_bytes) {
-  const size_t nj = cjobs.size();
-  if (!nj || !positions) return ZPQ_OK;
-  u64* d_keys0 = (u64*)buf;
-  u64* d_keys1 = d_keys0 + positions;
-  u32* d_vals0 = (u32*)(d_keys1 + positions);
-  u32* d_vals1 = d_vals0 + positions;
-  void* d_tmp = (void*)(((uintptr_t)(d_vals1 + positions) + 255) & ~(uintptr_t)255);
-  ZPQ_HIP(ctx, hipMemcpyAsync(d_cjobs, cjobs.data(), nj * sizeof(CandJob), hipMemcpyHostToDevice, st));
-  ZPQ_HIP(ctx, hipStreamSynchronize(st));          // cjobs may be a local of the caller
-  ZPQ_LAUNCH(ctx, "lz77_cand_keys_kernel", st, lz77_cand_keys_kernel, dim3(std::min<u32>((max_n + 255) / 256, 2048), (unsigned)nj), dim3(256), d_cjobs,
-             d_keys0, d_vals0);
-  ZPQ_HIP(ctx, hipGetLastError());
-  {
-    ZpqProfScope prof_scope_(ctx, "lz77_cand_sort", st);
-    size_t tb = temp_bytes;
-    u32 end_bit = 48;
-    while (end_bit < 64 && (nj - 1) >> (end_bit - 48)) ++end_bit;
-    if (zpq_own_sort()) {
-      int rc = zpq_radix_sort_pairs(ctx, st, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, (u32*)d_tmp);
-      if (rc) return rc;
-    } else
-    ZPQ_HIP(ctx, rocprim::radix_sort_pairs(d_tmp, tb, d_keys0, d_keys1, d_vals0, d_vals1, (size_t)positions, 0u, end_bit, st));
-  }
-  // runs of more than kLong entries go to a queue in the (now free) first key array and get a wave each
-  constexpr u32 kLong = 4096;
-  u32 klong = kLong;
-  if (const char* e = getenv("ZPQ_LZ_CAND_LONG")) klong = (u32)strtoul(e, 0, 10);        // 0: no hand-off (tests)
-  u32* d_longq = (u32*)d_keys0;
-  const u32 long_cap = klong ? (u32)std::min<u64>(positions / klong + 1, (positions * 2 - 2) / 2) : 0;
-  ZPQ_HIP(ctx, hipMemsetAsync(d_longq, 0, 8, st));
-  const unsigned sweep_grid = (unsigned)((positions + 63) / 64);
-  const unsigned long_grid = (unsigned)std::min<u64>((u64)long_cap, (u64)ctx->cu_count * 8);
-#define ZPQ_CAND_SWEEPS(NBV)                                                                                                              \
-  ZPQ_LAUNCH(ctx, "lz77_cand_sweep_kernel", st, lz77_cand_sweep_kernel<NBV>, dim3(sweep_grid), dim3(64), d_cjobs, d_keys1, d_vals1, positions, \
-             d_longq, long_cap, klong);                                                                                                   \
-  if (long_grid) ZPQ_LAUNCH(ctx, "lz77_cand_sweep_long_kernel", st, lz77_cand_sweep_long_kernel<NBV>, dim3(long_grid), dim3(64), d_cjobs, d_keys1, \
-                            d_vals1, positions, d_longq, long_cap)
-  switch (cjobs[0].lb) {
-    case 0: ZPQ_CAND_SWEEPS(1); break;
-    case 1: ZPQ_CAND_SWEEPS(2); break;
-    case 2: ZPQ_CAND_SWEEPS(4); break;
-    default: ZPQ_CAND_SWEEPS(8); break;
-  }
-#undef ZPQ_CAND_SWEEPS
-  ZPQ_HIP(ctx, hipGetLastError());
-  return ZPQ_OK;
-}
-
-// Two-wave kernels (lz77_duo.inc).  Ring depth: 14 windows (30 KB of LDS per workgroup at -m1: five workgroups per compute
-// unit) while the launch itself leaves room for the launches of other contexts beside it, 8 (18 KB) otherwise.  Deeper
-// rings bought nothing once the producer had its fast path for swallowed windows (56: 1620 ms, 14: 1627 ms for a 16 MiB
-// block), and a ring of 56 -- one workgroup per unit -- made six jobs in flight queue for the LDS (127 against 109 ms per step).
-static int duo_ring(const zpq_ctx* ctx, size_t workgroups) {
-  const size_t per_cu = (workgroups + (size_t)ctx->cu_count - 1) / (size_t)std::max(1, ctx->cu_count);
-  return per_cu <= 2 ? 14 : 8;
+// Three-wave kernels (lz77_duo.inc): producer | evaluator | chain, one workgroup per segment / block
+template <int NB>
+static void launch_spec3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzSegDev* d_segs, const u32* sl) {
+  ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec3_kernel<NB>, grid, dim3(192), d_segs, sl);
 }
 template <int NB>
-static void launch_spec2(zpq_ctx* ctx, hipStream_t st, dim3 grid, int R, const LzSegDev* d_segs, const u32* sl) {
-  if (R >= 14) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec2_kernel<NB, 14>), grid, dim3(128), d_segs, sl);
-  else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec2_kernel<NB, 8>), grid, dim3(128), d_segs, sl);
-}
-template <int NB>
-static void launch_direct2(zpq_ctx* ctx, hipStream_t st, dim3 grid, int R, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
-  if (R >= 14) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct2_kernel<NB, 14>), grid, dim3(128), d_jobs, d_segs, jl);
-  else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct2_kernel<NB, 8>), grid, dim3(128), d_jobs, d_segs, jl);
+static void launch_direct3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
+  ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct3_kernel<NB>, grid, dim3(192), d_jobs, d_segs, jl);
 }
 
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
-static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct, const bool cand = false) {
+static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, const u32 kSegBytes, const bool direct) {
   hipStream_t st = ctx->stream;
   const size_t nj = hi - lo;
   std::vector<LzJobDev> hj(nj);
   std::vector<LzSegDev> hs;
   size_t table_words = 0, tok_words = 0;
   u32 max_n = 0, max_seg = 1;
-  u64 cand_positions = 0;            // candidate-table mode: positions of the batch (= sort keys)
-  size_t cand_sort_temp = 0;
   for (size_t i = 0; i < nj; ++i) {
     const zpq_lz77_job& z = jobs[lo + i];
     const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
     const size_t words = (size_t)1 << z.args[5];
-    if (cand) { table_words += (size_t)z.n << z.args[4]; cand_positions += z.n; }
-    else table_words += words * (2 * (size_t)nseg - 1);
+    table_words += words * (2 * (size_t)nseg - 1);
     const u32 mmt = (u32)(z.args[2] >= 4 ? z.args[2] : 4);
     if (!direct) tok_words += ((size_t)z.n / mmt + 3) * 4;  // final pos/len/off/bit
     for (u32 k = 0; k < nseg && !direct; ++k) {
@@ -1100,16 +897,9 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   size_t nseg_total = 0;
   for (size_t i = 0; i < nj; ++i) nseg_total += std::max<u32>(1, (jobs[lo + i].n + kSegBytes - 1) / kSegBytes);
-  const size_t cand_words = table_words;       // (candidate-table mode) the sort buffers sit behind the tables
-  if (cand) {
-    ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, cand_sort_temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)cand_positions, 0u, 64u, st));
-    cand_sort_temp = std::max(cand_sort_temp, zpq_radix_scratch_words((size_t)cand_positions) * 4);
-    table_words = ((cand_words + 63) & ~(size_t)63) + 64;
-    if (!cand_shared_sort()) table_words += (size_t)cand_positions * 6 + 64 + (cand_sort_temp + 3) / 4;
-  }
   u32* d_tab = (u32*)zpq_scratch(ctx, 0, table_words * 4 + 256);
   u32* d_tok = (u32*)zpq_scratch(ctx, 1, tok_words * 4 + 256);
-  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4 + sizeof(CandJob)) + 256 + nseg_total * (sizeof(LzSegDev) + 48 + 36 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
+  const size_t meta_bytes = nj * (sizeof(LzJobDev) + 16 + 4 * 4) + 256 + nseg_total * (sizeof(LzSegDev) + 48 + 36 + 4 * 4 + sizeof(CopyJob) * 2 + sizeof(ScatterJob)) + 8192;
   u8* d_meta = (u8*)zpq_scratch(ctx, 2, meta_bytes);
   if (!d_tab || !d_tok || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 scratch (%zu MiB of tables)", table_words >> 18);
   u8* mp = d_meta;
@@ -1122,7 +912,6 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   u32* d_lists = carve<u32>(mp, (nj + nseg_total) * 4);      // per bucket width: job list, segment list
   CopyJob* d_copy = carve<CopyJob>(mp, nseg_total * 2);
   ScatterJob* d_scat = carve<ScatterJob>(mp, nseg_total);
-  CandJob* d_cjobs = carve<CandJob>(mp, nj);
   ZPQ_HIP(ctx, hipMemsetAsync(d_res, 0, nj * 16, st));
 
   size_t to = 0, tabo = 0;
@@ -1151,22 +940,19 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     // tables: work[0..nseg-1], pristine[1..nseg-1]
     u32* work0 = d_tab + tabo;
     u32* prist0 = work0 + words * nseg - words;   // pristine[k] = prist0 + k*words, k >= 1
-    if (cand) tabo += (size_t)z.n << a[4];        // work0 = this block's candidate table; every segment reads it
-    else {
-      tabo += words * (2 * (size_t)nseg - 1);
-      copy_step[0].push_back({nullptr, work0, (u32)words});
-    }
+    tabo += words * (2 * (size_t)nseg - 1);
+    copy_step[0].push_back({nullptr, work0, (u32)words});
     for (u32 k = 0; k < nseg; ++k) {
       LzSegDev S;
       S.c = c; S.x0 = k * kSegBytes; S.x1 = (u32)std::min<u64>((u64)S.x0 + kSegBytes, z.n);
-      S.work = cand ? work0 : work0 + words * k;
-      S.pristine = cand ? work0 : k ? prist0 + words * k : nullptr;
+      S.work = work0 + words * k;
+      S.pristine = k ? prist0 + words * k : nullptr;
       const u32 scap = direct ? 0u : (S.x1 - S.x0) / mmt + 3;
       S.tpos = d_tok + to; S.tlen = S.tpos + scap; S.toff = S.tlen + scap; S.tcap = scap ? scap - 1 : 0; to += (size_t)scap * 3;
       if (k) { S.qpos = d_tok + to; S.qlen = S.qpos + scap; S.qoff = S.qlen + scap; to += (size_t)scap * 3; }
       else { S.qpos = S.tpos; S.qlen = S.tlen; S.qoff = S.toff; }       // no seam walk enters a first segment (never written, never read)
       S.state = d_state + 12 * hs.size(); S.seam = S.state + 4;
-      if (k && !cand) {
+      if (k) {
         copy_step[k].push_back({k == 1 ? nullptr : prist0 + words * (k - 1), S.pristine, (u32)words});
         scat_step[k].push_back({c, (k - 1) * kSegBytes, k * kSegBytes, S.pristine});
         copy_work.push_back({S.pristine, S.work, (u32)words});
@@ -1178,42 +964,8 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), nj * sizeof(LzJobDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_segs, hs.data(), hs.size() * sizeof(LzSegDev), hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  // 1'. candidate tables instead of table states: keys, sort, one sweep (see lz77_cand_sweep_kernel)
-  if (cand) {
-    std::vector<CandJob> cjobs(nj);
-    u64 pos0 = 0;
-    for (size_t i = 0; i < nj; ++i) {
-      CandJob& Cj = cjobs[i];
-      Cj.c = hs[hj[i].seg0].c; Cj.pos0 = pos0; Cj.cand = hs[hj[i].seg0].work; Cj.lb = (u32)jobs[lo + i].args[4]; Cj.pad = 0;
-      pos0 += jobs[lo + i].n;
-    }
-    if (cand_shared_sort() && ctx->device >= 0 && ctx->device < 64) {
-      CandArena& A = g_cand_arena[ctx->device];
-      std::lock_guard<std::mutex> lk(A.mu);
-      const size_t need = (size_t)cand_positions * 24 + 512 + cand_sort_temp + 256;
-      if (A.cap < need) {
-        if (A.last) ZPQ_HIP(ctx, hipEventSynchronize(A.last));        // nobody is still sorting in the old arena
-        if (A.buf) (void)hipFree(A.buf);
-        A.buf = nullptr; A.cap = 0;
-        const size_t cap = need + need / 8;
-        if (hipMalloc(&A.buf, cap) != hipSuccess) { A.buf = nullptr; return zpq_fail(ctx, ZPQ_ERR_NOMEM, "candidate sort arena (%zu MiB)", cap >> 20); }
-        A.cap = cap;
-      }
-      if (!A.last) ZPQ_HIP(ctx, hipEventCreateWithFlags(&A.last, hipEventDisableTiming));
-      else ZPQ_HIP(ctx, hipStreamWaitEvent(st, A.last, 0));
-      const int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)A.buf, cand_sort_temp);
-      if (rc) return rc;
-      ZPQ_HIP(ctx, hipEventRecord(A.last, st));
-    } else {
-      int rc = cand_build(ctx, st, cjobs, d_cjobs, cand_positions, max_n, (u8*)(d_tab + ((cand_words + 63) & ~(size_t)63)), cand_sort_temp);
-      if (rc) return rc;
-    }
-    // which candidate walk the kernels use (lz77_pipe.inc): the switch lives in device memory, the plain kernels never read it
-    static const u32 pipe_on = [] { const char* e = getenv("ZPQ_LZ_CAND_PIPE"); return e && atoi(e) != 0 ? 1u : 0u; }();
-    ZPQ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lz_cand_pipe), &pipe_on, sizeof pipe_on, 0, hipMemcpyHostToDevice, st));
-  }
   // 1. table states at the segment starts: pristine[k] = pristine[k-1] + inserts of segment k-1
-  if (!cand) {
+  {
     std::vector<CopyJob> cj; std::vector<ScatterJob> sj;
     std::vector<std::pair<size_t, size_t>> crange(max_seg), srange(max_seg);
     for (u32 k = 0; k < max_seg; ++k) {
@@ -1257,30 +1009,17 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
-  // two waves per block / segment on one table (lz77_duo.inc); ZPQ_LZ_DUO=0: the one-wave walk
-  static const bool duo = [] { const char* e = getenv("ZPQ_LZ_DUO"); return !(e && atoi(e) == 0); }();
-  static const int ring_env = [] { const char* e = getenv("ZPQ_LZ_RING"); return e ? atoi(e) : 0; }();      // (tests: force a ring depth -- 8 or 14)
+  // three waves per block / segment on one table (lz77_duo.inc): producer | evaluator | chain
   if (direct) {
     for (int nb = 0; nb <= 3; ++nb) {
       if (!rng[nb].jn) continue;
-      dim3 gj((unsigned)rng[nb].jn), blk(64);
+      dim3 gj((unsigned)rng[nb].jn);
       const u32* jl = d_lists + rng[nb].joff;
-      if (duo && !cand) {
-        const int R = ring_env ? ring_env : duo_ring(ctx, rng[nb].jn);
-        switch (nb) {
-          case 0: launch_direct2<1>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
-          case 1: launch_direct2<2>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
-          case 2: launch_direct2<4>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
-          default: launch_direct2<8>(ctx, st, gj, R, d_jobs, d_segs, jl); break;
-        }
-        ZPQ_HIP(ctx, hipGetLastError());
-        continue;
-      }
       switch (nb) {
-        case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<1, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-        case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<2, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-        case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<4, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-        default: if (cand) ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, (lz77_direct_kernel<8, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+        case 0: launch_direct3<1>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        case 1: launch_direct3<2>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        case 2: launch_direct3<4>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        default: launch_direct3<8>(ctx, st, gj, d_jobs, d_segs, jl); break;
       }
       ZPQ_HIP(ctx, hipGetLastError());
     }
@@ -1296,53 +1035,21 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   for (int nb = 0; nb <= 3; ++nb) {
     if (!rng[nb].sn) continue;
-    dim3 gs((unsigned)rng[nb].sn), gj((unsigned)rng[nb].jn), blk(64);
+    const dim3 gs((unsigned)rng[nb].sn), gj((unsigned)rng[nb].jn), blk(64);
     const u32* sl = d_lists + rng[nb].soff; const u32* jl = d_lists + rng[nb].joff;
-    zpq_place PL{nullptr, nullptr, (u32)rng[nb].sn, 0};
-    if (rng[nb].sn <= 4096 && zpq_place_enabled()) {
-      u32* tab = zpq_simd_table(ctx);
-      u32* counter = (u32*)zpq_scratch(ctx, 7, 256);
-      if (tab && counter) {
-        counter += 44 + nb;
-        ZPQ_HIP(ctx, hipMemsetAsync(counter, 0, 4, st));
-        PL.queue = counter; PL.tab = tab; PL.polite = (u32)(2 * rng[nb].sn + 64);
-        gs = dim3((unsigned)(3 * rng[nb].sn + 64));
-      }
-    }
-    if (duo && !cand) {
-      const dim3 g2((unsigned)rng[nb].sn), b2(128);
-      const int R = ring_env ? ring_env : duo_ring(ctx, rng[nb].sn);
-      (void)b2;
-      switch (nb) {
-        case 0: launch_spec2<1>(ctx, st, g2, R, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, g2, blk, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-        case 1: launch_spec2<2>(ctx, st, g2, R, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, g2, blk, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-        case 2: launch_spec2<4>(ctx, st, g2, R, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, g2, blk, d_segs, sl);
-                ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-        default: launch_spec2<8>(ctx, st, g2, R, d_segs, sl);
-                 ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, g2, blk, d_segs, sl);
-                 ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
-      }
-      ZPQ_HIP(ctx, hipGetLastError());
-      continue;
-    }
     switch (nb) {
-      case 0: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<1, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<1>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<1, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<1, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
-      case 1: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<2, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<2>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<2, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<2, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
-      case 2: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<4, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<4>, gs, blk, d_segs, sl, PL);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<4, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-              if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<4, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
-      default: if (cand) ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, (lz77_spec_kernel<8, true>), gs, blk, d_segs, sl, PL); else ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec_kernel<8>, gs, blk, d_segs, sl, PL);
-               if (cand) ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, (lz77_seam_kernel<8, true>), dim3((unsigned)rng[nb].sn), blk, d_segs, sl); else ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, dim3((unsigned)rng[nb].sn), blk, d_segs, sl);
-               if (cand) ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, (lz77_stitch_kernel<8, true>), gj, blk, d_jobs, d_segs, jl); else ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
+      case 0: launch_spec3<1>(ctx, st, gs, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<1>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<1>, gj, blk, d_jobs, d_segs, jl); break;
+      case 1: launch_spec3<2>(ctx, st, gs, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<2>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<2>, gj, blk, d_jobs, d_segs, jl); break;
+      case 2: launch_spec3<4>(ctx, st, gs, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<4>, gs, blk, d_segs, sl);
+              ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<4>, gj, blk, d_jobs, d_segs, jl); break;
+      default: launch_spec3<8>(ctx, st, gs, d_segs, sl);
+               ZPQ_LAUNCH(ctx, "lz77_seam_kernel", st, lz77_seam_kernel<8>, gs, blk, d_segs, sl);
+               ZPQ_LAUNCH(ctx, "lz77_stitch_kernel", st, lz77_stitch_kernel<8>, gj, blk, d_jobs, d_segs, jl); break;
     }
     ZPQ_HIP(ctx, hipGetLastError());
   }
@@ -1364,35 +1071,6 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     jobs[lo + i].out_len = res[4 * i + 1];
     if (res[4 * i + 2]) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: token or output capacity exceeded", lo + i);
   }
-  return ZPQ_OK;
-}
-
-// Experimental / test entry: the candidate table of ONE block (args as for zpq_lz77_encode_dev, hash-table finder):
-// d_cand receives n << args[4] words, cand[q * (bucket+1) + k] = what the reference's search at q reads from ht[h1 ^ k].
-extern "C" int zpq_lz77_cand_dev(zpq_ctx* ctx, const void* d_in, uint32_t n, const int32_t args[9], uint32_t* d_cand) {
-  if (!ctx || !args || (n && (!d_in || !d_cand))) return ZPQ_ERR_ARG;
-  (void)hipSetDevice(ctx->device);
-  int rc = check_args(ctx, args, n);
-  if (rc) return rc;
-  if (uses_suffix_array(args) || args[4] > 3 || args[5] - args[4] > 22 || n >= (1u << 26)) return zpq_fail(ctx, ZPQ_ERR_ARG, "no candidate table for these arguments");
-  if (n == 0) return ZPQ_OK;
-  hipStream_t st = ctx->stream;
-  std::vector<CandJob> cj(1);
-  LzCfg& c = cj[0].c;
-  c.in = (const u8*)d_in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
-  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
-  const u32 mmb = args[2] + 4;
-  c.upd_limit = n > mmb ? n - mmb : 0;
-  cj[0].pos0 = 0; cj[0].cand = d_cand; cj[0].lb = (u32)args[4]; cj[0].pad = 0;
-  size_t temp = 0;
-  ZPQ_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, st));
-  temp = std::max(temp, zpq_radix_scratch_words((size_t)n) * 4);
-  u8* buf = (u8*)zpq_scratch(ctx, 0, (size_t)n * 24 + temp + 1024);
-  CandJob* d_cjobs = (CandJob*)zpq_scratch(ctx, 2, sizeof(CandJob) + 256);
-  if (!buf || !d_cjobs) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "candidate table scratch");
-  rc = cand_build(ctx, st, cj, d_cjobs, n, n, buf, temp);
-  if (rc) return rc;
-  ZPQ_HIP(ctx, hipStreamSynchronize(st));
   return ZPQ_OK;
 }
 
@@ -1439,42 +1117,6 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
       for (size_t i = 0; i < njobs; ++i) { bytes += job_bytes(jobs[i], seg); nseg += std::max<u32>(1, (u32)(((u64)jobs[i].n + seg - 1) / seg)); }
       if (bytes <= budget || seg >= max_n || nseg <= 2048 || seg >= (1u << 30)) break;
       seg <<= 1;
-    }
-  }
-  // Experimental (ZPQ_LZ_CAND=1; written at the end of round 3, not yet run on hardware): candidate tables instead of
-  // table states.  Memory per block no longer depends on the number of segments, so the segment size is chosen for waves
-  // alone (about four per SIMD, 256 KiB at least) and what does not fit runs in batches.
-  static const int cand_mode = [] { const char* e = getenv("ZPQ_LZ_CAND"); return e ? atoi(e) : 0; }();
-  if (cand_mode) {
-    bool ok = njobs < 65536;
-    u64 all_n = 0;
-    for (size_t i = 0; i < njobs && ok; ++i) {
-      ok = jobs[i].args[4] == jobs[0].args[4] && jobs[i].args[5] - jobs[i].args[4] <= 22 && jobs[i].n < (1u << 26);
-      all_n += jobs[i].n;
-    }
-    if (ok) {
-      bool cdirect = false;
-      if (const char* e = getenv("ZPQ_LZ_DIRECT")) cdirect = atoi(e) != 0;
-      // batches by memory (token lists sized for the smallest segments), then PER BATCH the segment size that puts about
-      // four waves on every SIMD: with hundreds of blocks a batch is ~100 of them (1.3 GB of tables each), and it is the
-      // batch that has to fill the chip
-      size_t lo = 0;
-      while (lo < njobs) {
-        size_t hi = lo, bytes = 0;
-        u64 batch_n = 0;
-        while (hi < njobs) {
-          const size_t bts = job_bytes_cand(jobs[hi], 256u << 10, cdirect);
-          if (hi > lo && bytes + bts > budget) break;
-          bytes += bts; batch_n += jobs[hi].n; ++hi;
-        }
-        u32 cseg = 256u << 10;
-        if (const char* e = getenv("ZPQ_LZ_SEG")) cseg = std::max<u32>(1u << 16, (u32)strtoul(e, 0, 10));
-        else while ((u64)cseg * 4096 < batch_n && cseg < (1u << 30)) cseg <<= 1;
-        int rc = encode_batch(ctx, jobs, lo, hi, cdirect ? (1u << 30) : cseg, cdirect, true);
-        if (rc) return rc;
-        lo = hi;
-      }
-      return ZPQ_OK;
     }
   }
   // Two ways to run a batch.  Speculative segments: many waves per block, 2*segments-1 tables and token lists per block

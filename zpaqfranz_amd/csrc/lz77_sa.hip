@@ -111,7 +111,7 @@ size_t sa_temp_bytes(u32 n) {
   (void)rocprim::radix_sort_pairs(nullptr, a, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0);
   (void)rocprim::inclusive_scan(nullptr, b, (u32*)nullptr, (u32*)nullptr, (size_t)n, rocprim::maximum<u32>(), (hipStream_t)0);
   (void)rocprim::inclusive_scan(nullptr, c, (u64*)nullptr, (u64*)nullptr, (size_t)n, rocprim::plus<u64>(), (hipStream_t)0);
-  return std::max(std::max(a, zpq_radix_scratch_words(n) * 4), std::max(b, c)) + 256;
+  return std::max(a, std::max(b, c)) + 256;
 }
 
 size_t sa_work_bytes(u32 n) {
@@ -148,10 +148,6 @@ int build_suffix_array(zpq_ctx* ctx, hipStream_t st, const u8* d_in, u32 n, u32*
     {
       ZpqProfScope prof_scope_(ctx, "sa_radix_sort_pairs", st);
       size_t tb = W.tmp_bytes;
-      if (zpq_own_sort()) {      // experimental: the hand-written sort (radix.hip); the input buffers are free after the sort
-        int rc = zpq_radix_sort_pairs(ctx, st, W.key[kb], W.key[kb ^ 1], W.val[vb], W.val[vb ^ 1], (size_t)m, 0u, bits, (u32*)W.tmp);
-        if (rc) return rc;
-      } else
       ZPQ_HIP(ctx, rocprim::radix_sort_pairs(W.tmp, tb, W.key[kb], W.key[kb ^ 1], W.val[vb], W.val[vb ^ 1], (size_t)m, 0u, bits, st));
     }
     kb ^= 1; vb ^= 1;

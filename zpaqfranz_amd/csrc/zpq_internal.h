@@ -200,12 +200,6 @@ static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 80, "layout
 // twin files (twins.hip): rep[f] = earliest extent with the same bytes (compared), else f; off / len are host arrays
 int zpq_twins_find(zpq_ctx* ctx, hipStream_t st, const u8* d_base, const u64* off, const u64* len, size_t n, u64 min_bytes, u32* rep,
                    u64 stats[4]);
-// hand-written LSD radix sort of (u64, u32) pairs (radix.hip; experimental: ZPQ_SORT=own selects it over rocPRIM in the
-// suffix-array construction and in the candidate tables).  keys_in / vals_in are clobbered, the result is in *_out.
-size_t zpq_radix_scratch_words(size_t n);
-int zpq_radix_sort_pairs(zpq_ctx* ctx, hipStream_t st, u64* keys_in, u64* keys_out, u32* vals_in, u32* vals_out, size_t n, u32 begin_bit, u32 end_bit,
-                         u32* scratch);
-static inline bool zpq_own_sort() { static const bool on = [] { const char* e = getenv("ZPQ_SORT"); return e && !strcmp(e, "own"); }(); return on; }
 // one WAVE per extent (long chains: block checksums); zpq_sha1_extents_on uses one LANE per extent
 int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64* d_off, const u32* d_len, size_t n,
                        u8* d_digests, const char* prof_name = "sha1_chain_kernel");
