@@ -297,7 +297,8 @@ int zpq_suffix_array_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint32_t* d_s
 /* What LZBuffer emits for (args[1] & 3) == 3, the BWT front end of methods 3 and 4 (ZSFX/libzpaq.cpp:6317-6326):
  * d_out[0] = last input byte, d_out[1..n] = the byte before every suffix in suffix order (255 for the suffix that is
  * the whole block), d_out[n+1..n+4] = that suffix's 1-based rank, LSB first.  d_out holds n+5 bytes.  (compressBlock
- * does not offer the BWT methods yet: their post-processor program is not pinned) */
+ * serves these methods since round 3 -- level 3 for text, "x<N>,3..." -- with the post-processor program decode-pinned by
+ * the reference's own PostProcessor) */
 int zpq_bwt_dev(zpq_ctx* ctx, const void* d_in, size_t n, uint8_t* d_out);
 
 /* ---- block configuration on the host (rows a5, a6); no GPU needed, ctx may be NULL ------------- */

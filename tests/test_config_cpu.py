@@ -254,3 +254,17 @@ def test_builtin_models_through_the_reference_compiler_and_predictor(cfg, level)
     coded = orc.ref_cm_encode(h, x)
     assert len(coded) < len(x) * 3 // 4                     # it is a model, not noise
     assert orc.ref_cm_decode(h, coded, len(x) + 16) == x
+
+
+def test_lz77_context_preamble_constant_follows_the_compiled_program():
+    """The HCOMP of the byte-aligned LZ77 methods skips the post-processor section of the coded stream before it starts to
+    track codes (ZPAQ's constant 111 = 3 + the 108 bytes of its level-2 program).  Here the program is restated (and differs
+    with the E8E9 stage: 160 bytes), so the constant must be 3 + whatever THIS compiler makes of THIS
+    program -- an edit of the program that forgot the constant would silently shift the model's parse state."""
+    import re
+    from zpaqfranz_amd import engine
+    for method, want in (("x4,2,12,0,7,25,1c0,0,511i2", 108), ("x4,6,12,0,7,25,1c0,0,511i2", 160)):
+        src, args = engine.make_config(engine.expand_method(method, b""))
+        _, pcomp = engine.compile_config(src, args)
+        skip = int(re.search(r"a=r 1 a== 0 if\s+a= (\d+)", src).group(1))
+        assert len(pcomp) == want and skip == 3 + len(pcomp)

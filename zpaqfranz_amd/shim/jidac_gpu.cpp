@@ -344,13 +344,14 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       const Bytes& g = got[r];
       if (g.size() < 16) return ZPQ_ERR_FORMAT;
       const uint64_t n = get64(g.data());
-      if (g.size() < 16 + n * 28) return ZPQ_ERR_FORMAT;
+      if (n > (g.size() - 16) / 28) return ZPQ_ERR_FORMAT;                 // (no product that could wrap)
       Shard& S = sh[r];
       S.nf = (size_t)n; S.flen.resize(n); S.ffile.resize(n); S.dig.resize(n * 20);
       memcpy(S.flen.data(), g.data() + 8, n * 4); memcpy(S.ffile.data(), g.data() + 8 + n * 4, n * 4); memcpy(S.dig.data(), g.data() + 8 + n * 8, n * 20);
       const uint8_t* q = g.data() + 8 + n * 28;
       const uint64_t nc = get64(q); q += 8;
-      if ((size_t)(g.data() + g.size() - q) < nc * 12) return ZPQ_ERR_FORMAT;
+      // a peer sends one checksum pair per file of its range (none without ZPQJ_FILE_CHECKSUMS): the i blocks index sh[r].xxh / crc by file
+      if (nc > (uint64_t)(g.data() + g.size() - q) / 12 || nc != (checksums ? (uint64_t)(S.f1 - S.f0) : 0ull)) return ZPQ_ERR_FORMAT;
       S.crc.resize(nc); S.xxh.resize(nc);
       memcpy(S.crc.data(), q, nc * 4); memcpy(S.xxh.data(), q + nc * 4, nc * 8);
     }
@@ -509,7 +510,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       std::vector<uint64_t> hits(mine.size(), 0), bytes(mine.size(), 0); std::vector<uint32_t> nf(mine.size(), 0), tx(mine.size(), 0), ex(mine.size(), 0);
       for (size_t i = 0; i < fo.size(); ++i) { const size_t m = fb[i]; hits[m] += st[4 * i]; tx[m] += st[4 * i + 1]; ex[m] += st[4 * i + 2]; bytes[m] += st[4 * i + 3]; ++nf[m]; }
       for (size_t m = 0; m < mine.size(); ++m) {
-        uint64_t R = hits[m] * 256 / (bytes[m] + 1);
+        uint64_t R = hits[m] / (bytes[m] / 256 + 1);             // zpaq's add(): redundancy / (size / 256 + 1)
         if (R > 255) R = 255;
         const unsigned t = (ex[m] * 8 > nf[m] ? 2u : 0u) + (tx[m] * 4 > nf[m] ? 1u : 0u);
         mth[m] += "," + std::to_string(R) + "," + std::to_string(t);

@@ -390,7 +390,28 @@ bool Decompresser::decompress(int n) {
   return d.given < d.plain.size();
 }
 
-bool Decompresser::pcomp(Writer*) { return false; }
+// The PCOMP section of the block (ZSFX/libzpaq.h:1254: pp.z.write(out2, true) -- two size bytes, then the program), valid once the
+// first segment has been read.  Blocks without a context model keep it in their stored sub-blocks, where it is read from
+// here; behind a model it sits inside the coded stream the device decodes and post-processes in one go, and is not kept
+// (false, as before: nothing is written).
+bool Decompresser::pcomp(Writer* out2) {
+  Impl& d = *d_;
+  if (d.ncomp != 0 || !d.have_marker || d.segments != 1) return false;
+  std::vector<uint8_t> first;                                  // the first bytes of the stored stream: 1 lo hi program...
+  for (size_t p = 0; p + 4 <= d.payload.size();) {
+    const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
+    p += 4;
+    if (!k || p + k > d.payload.size()) break;
+    first.insert(first.end(), d.payload.begin() + p, d.payload.begin() + p + k);
+    p += k;
+    if (first.size() >= 3 && first.size() >= 3 + ((size_t)first[1] | (size_t)first[2] << 8)) break;
+  }
+  if (first.size() < 3 || first[0] != 1) return false;
+  const size_t n = (size_t)first[1] | (size_t)first[2] << 8;
+  if (first.size() < 3 + n) return false;
+  if (out2) { out2->put(first[1]); out2->put(first[2]); out2->write((const char*)&first[3], (int)n); }
+  return true;
+}
 
 void Decompresser::readSegmentEnd(char* sha1string) {
   Impl& d = *d_;

@@ -11,10 +11,11 @@
 // so that a Jidac-style caller (one compressBlock per block per worker thread; one Decompresser per block on the
 // extract side, ZSFX/zsfx.cpp:1783-1801) links against this header unchanged.
 //
-// What runs where: the byte work (LZ77 level 1, stored framing, block SHA-1, LZ77 inverse) runs in
-// HIP kernels behind the C ABI of include/zpaqhip.h.  Method strings outside the family the engine
-// implements (byte-aligned LZ77, BWT and E8E9 front ends) end in libzpaq::error("...") -- there is
-// no CPU fallback compiled into this library; the host keeps its CPU libzpaq for those if it wants.
+// What runs where: the byte work (LZ77 levels 1 / 2, BWT, E8E9, the context-mixing coder, stored framing, block
+// SHA-1 and their inverses) runs in HIP kernels behind the C ABI of include/zpaqhip.h.  Method strings outside the
+// family the engine implements (byte-aligned LZ77 with the hash-table finder, BWT+E8E9 above 16 MiB, more than 255
+// components) end in libzpaq::error("...") -- there is no CPU fallback compiled into this library; the host keeps
+// its CPU libzpaq for those if it wants.
 //
 // Batching: compressBlock(), Decompresser::decompress() and SHA1/SHA256::result() block the calling thread like
 // the reference's do.  Calls made concurrently from N worker threads (zpaqfranz -tN) are coalesced by small
@@ -133,7 +134,7 @@ class Decompresser {
   void setOutput(Writer* out) { out_ = out; }
   void setSHA1(SHA1* sha1ptr) { sha_ = sha1ptr; }
   bool decompress(int n = -1);              // n bytes (-1 = all); false once the segment is exhausted
-  bool pcomp(Writer* out2);                 // not retained by this implementation: returns false
+  bool pcomp(Writer* out2);                 // the PCOMP section (size, program) of a block WITHOUT a context model; false behind a model
   void readSegmentEnd(char* sha1string = 0);// [0] = 1 if a SHA-1 follows in [1..20], else 0
   int stat(int) { return 0; }               // the reference reports predictor statistics here (debug builds only)
   int buffered() { return 0; }
