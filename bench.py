@@ -1147,11 +1147,12 @@ def main():
         return main_cm_m5(a, rank, world, local, dev)
     steps = a.steps if a.steps is not None else {"silesia_x256_m1": 24, "dup8_m1": 2, "extract_m1": 6}[a.workload]
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
-    # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, 150 ms of LZ77 parse on a few
-    # hundred waves) behind the chip-wide kernels of other steps; measured 197 / 172 / 167 ms per step at 3 / 5 / 6: six by default
+    # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, ~140 ms of LZ77 parse per 2 MiB
+    # segment) behind the chip-wide kernels of other steps; round 4 (three-wave parse, 2 MiB segments: 12.5 GB of table states
+    # per job): 106.8 / 99.5 / 98.0 ms per step at 8 / 10 / 12, 133 at 14 (the tables no longer fit): twelve by default
     # (multi-rank runs too: every step in flight adds three collective sections to the one fixed order, CollectiveOrder)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 6, "dup8_m1": 1, "extract_m1": 4}[a.workload])
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 12, "dup8_m1": 1, "extract_m1": 4}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
@@ -1167,9 +1168,10 @@ def main():
         layout = silesia_layout(dev, corpus, a.copies)
     torch.cuda.empty_cache()       # what the generators left in torch's cache is HBM the engine cannot see (its LZ77 batches are sized by free memory)
     if a.workload == "silesia_x256_m1" and a.pipeline is None:
-        # every job in flight holds its own hash-table states (~26 GB for the 13 blocks): no deeper than HBM allows
+        # every job in flight holds its own hash-table states (12.5 GB for the 13 blocks at 2 MiB segments) and ~3 GB of
+        # fragment tables, block buffers and outputs: no deeper than HBM allows
         free_b = torch.cuda.mem_get_info(dev)[0]
-        depth = max(1, min(depth, int((free_b - (20 << 30)) // (30 << 30))))
+        depth = max(1, min(depth, int((free_b - (24 << 30)) // (16 << 30))))
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
     engines, pipes = [], []

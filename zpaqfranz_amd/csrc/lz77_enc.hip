@@ -186,6 +186,10 @@ struct BitSink {
   u32 bytepos;                 // bytes written
   u32 gap_start;               // first position not yet emitted
   u32 rb, overflow;
+  // the block's bytes [lit_lo, lit_hi) as the chain wave keeps them in LDS (512-byte ring, position & 511): a literal run
+  // ends where a match starts -- in the window being parsed -- and is a few bytes long, so its bytes come from there
+  // instead of three dependent global loads per run (lit == nullptr: no such cache)
+  __attribute__((address_space(3))) const u8* lit; u32 lit_lo, lit_hi;
 
   __device__ __forceinline__ void put(u64 v, u32 k, u32 lane) {           // k <= 56 bits, LSB first
     acc |= v << accbits;
@@ -204,6 +208,17 @@ struct BitSink {
     ++k;
     put(v, k, lane);
     const u32 sh = accbits;                  // 0..7 bits already in the byte the run starts in
+    if (lit && from >= lit_lo && from + len <= lit_hi) {
+      for (u32 j = lane; j < len; j += 64) {
+        const u32 c = lit[(from + j) & 511u];
+        const u32 left = lit[(from + j - 1u) & 511u];                    // (unused for j == 0)
+        const u32 carry = j ? (sh ? left >> (8 - sh) : 0u) : (u32)acc;
+        if (bytepos + j < out_cap) out[bytepos + j] = (u8)((c << sh) | carry); else overflow = 1;
+      }
+      bytepos += len;
+      acc = sh ? (u64)((u32)lit[(from + len - 1u) & 511u] >> (8 - sh)) : 0ull;
+      return;
+    }
     for (u32 j = lane; j < len; j += 64) {
       const u32 c = in[from + j];
       const u32 left = j ? (u32)in[from + j - 1] : 0u;
