@@ -267,7 +267,7 @@ class Pipeline:
         first = self.first[:ntot].cpu().numpy()
         lens = flen.cpu().numpy().astype(np.int64)
         # 4. pack (host: which unique fragment goes to which block, who owns it) -- zpaqfranz_amd/sharding.py
-        P = shard_plan(first, lens, cnts, self.rank)
+        P = shard_plan(first, lens, cnts, self.rank, balance=getattr(self, 'balance_blocks', False))
         uniq_idx, mine, starts, nblk = P["uniq_idx"], P["mine"], P["starts"], P["nblocks"]
         # block buffers of the blocks this rank owns: fragments + size table + 0 + count
         blk_n, src_off, src_len, dst_off, trailers, layout = [], [], [], [], [], {}
@@ -290,8 +290,9 @@ class Pipeline:
             do = torch.from_numpy(np.concatenate(dst_off).astype(np.int64)).to(dev)
             abs_off = self.frag_off[:nf][so]
             tsync()
-            eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
-                           blocks_buf.data_ptr())
+            if so.numel():        # (a block dealt to this rank may hold none of its own fragments: --shared-corpus)
+                eng.gather_dev(self.data.data_ptr(), abs_off.data_ptr(), sl.data_ptr(), do.data_ptr(), so.numel(),
+                               blocks_buf.data_ptr())
             if len(trailers) <= 64:
                 for p_, tr in trailers:
                     blocks_buf[p_:p_ + len(tr)] = torch.frombuffer(bytearray(tr), dtype=torch.uint8).to(dev)
@@ -1182,6 +1183,7 @@ def main():
     for p_ in pipes:
         p_.no_block_sha1 = a.no_block_sha1
         p_.use_twins = not a.no_twins
+        p_.balance_blocks = shared and world > 1      # one corpus over several ranks: the d blocks are dealt out, not left to rank 0
     ex_pipe = None
     if a.workload == "extract_m1":
         import hashlib

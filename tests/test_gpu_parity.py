@@ -662,7 +662,8 @@ def test_two_rank_shared_corpus_equals_the_single_gpu_archive(tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one, two = str(tmp_path / "one.bin"), str(tmp_path / "two.bin")
-    common = ["--steps", "1", "--warmup", "1", "--copies", "4", "--scale", "0.05", "--no-cpu-baseline", "--no-verify", "--workload", "silesia_x256_m1"]
+    # (scale 0.2: three d blocks, so that the balanced ownership gives rank 1 a block whose fragments all live on rank 0)
+    common = ["--steps", "1", "--warmup", "1", "--copies", "4", "--scale", "0.2", "--no-cpu-baseline", "--no-verify", "--workload", "silesia_x256_m1"]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-archive", one] + common, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     # no launcher in front: `bench.py --gpus 2` starts its two ranks itself, and one corpus split over the ranks is the default

@@ -84,3 +84,31 @@ def test_pack_blocks_respects_limit():
         m = blk == b
         nxt = lens[np.nonzero(blk == b + 1)[0][0]]
         assert lens[m].sum() + 4 * m.sum() + 8 + nxt + 4 > sharding.BLOCK_LIMIT
+
+
+def test_balanced_ownership_deals_the_blocks_out_and_the_lists_match():
+    """ONE corpus split by file range (bench.py's default with several ranks): every new fragment sits on rank 0.  Ownership
+    by residence gives rank 0 every block; balance=True deals contiguous block ranges to the ranks, and what a rank sends is
+    what the owner expects, fragment for fragment."""
+    rng = np.random.default_rng(3)
+    n0 = 3000
+    dig0 = rng.integers(0, 256, size=(n0, 20), dtype=np.uint8)
+    lens0 = rng.integers(4096, 200000, size=n0).astype(np.int64)
+    world = 4
+    dig = np.concatenate([dig0] * world); lens = np.concatenate([lens0] * world)          # ranks 1.. hold copies of rank 0's files
+    first = sharding.first_occurrence(dig)
+    plans = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20) for r in range(world)]
+    assert len(plans[0]["mine"]) == plans[0]["nblocks"] and all(len(p["mine"]) == 0 for p in plans[1:])
+    bal = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20, balance=True) for r in range(world)]
+    nb = bal[0]["nblocks"]
+    assert nb >= 2 * world
+    owned = [p["mine"].tolist() for p in bal]
+    assert sorted(sum(owned, [])) == list(range(nb))
+    assert all(abs(len(o) - nb / world) <= 1 for o in owned)
+    assert all(owned[r] == sorted(owned[r]) and (not owned[r] or not owned[r + 1] or owned[r][-1] < owned[r + 1][0]) for r in range(world - 1))
+    for src in range(world):
+        for dst in range(world):
+            if src != dst:
+                a = bal[src]["send"].get(dst, np.zeros(0, dtype=np.int64)); b = bal[dst]["recv"].get(src, np.zeros(0, dtype=np.int64))
+                assert a.tolist() == b.tolist()
+    assert sum(len(v) for v in bal[0]["send"].values()) > 0 and not bal[1]["send"]       # rank 0 ships the blocks it does not keep

@@ -27,11 +27,15 @@ def pack_blocks(uniq_len, block_limit=BLOCK_LIMIT):
     return blk, b
 
 
-def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT):
+def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT, balance=False):
     """Returns a dict describing what `rank` has to do:
       uniq_idx     global indices of new fragments (ascending)
       nblocks      number of d blocks in the archive
-      mine         block ids this rank compresses (owner = rank holding the block's first fragment)
+      mine         block ids this rank compresses (owner = rank holding the block's first fragment; balance=True: the d
+                   blocks are dealt out in equal contiguous ranges instead, rank r taking blocks [r n / N, (r+1) n / N) --
+                   for ONE corpus split over the ranks by file range every NEW fragment sits on the first ranks (a copy
+                   duplicates an earlier file), and ownership by residence would leave the compressor to rank 0 alone;
+                   ascending ranks still own ascending blocks, so the per-rank streams concatenate to block order)
       blocks       {block id: (global fragment indices, lengths, owning rank of each fragment)}
       send         {dst rank: global indices of MY fragments that live in blocks owned by dst, in order}
       recv         {src rank: global indices of fragments I need from src, in order}"""
@@ -45,6 +49,8 @@ def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT):
     owner = np.searchsorted(bounds, uniq_idx, side="right")          # rank holding each unique fragment
     first_in_blk = np.concatenate(([0], np.nonzero(np.diff(blk))[0] + 1)) if len(blk) else np.zeros(0, dtype=np.int64)
     blk_owner = owner[first_in_blk] if len(blk) else np.zeros(0, dtype=np.int64)
+    if balance and nblk:
+        blk_owner = (np.arange(nblk, dtype=np.int64) * len(counts)) // nblk
     starts = np.concatenate((first_in_blk, [len(uniq_idx)])).astype(np.int64)
     mine = np.nonzero(blk_owner == rank)[0]
     blocks = {}
