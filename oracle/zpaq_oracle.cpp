@@ -176,12 +176,13 @@ extern "C" void orc_e8e9_inverse(U8* buf, long n) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LZ77 level 1 (variable-length codes) encoder with the bucketed hash-table match finder.
+// LZ77 encoder with the bucketed hash-table match finder: level 1 (variable-length codes) and level 2 (byte-aligned
+// codes, where a far match must be 1 / 2 bytes longer to be taken, :6415-6416).
 // Reference: LZBuffer::LZBuffer / fill / write_literal / write_match / putb / flush,
-// ZSFX/libzpaq.cpp:6140-6552; code format documented at :6211-6222.
-// args[] as in ZSFX/libzpaq.cpp:6128-6138.  Only level 1 with the hash table
-// (args[5]-args[0] < 21) and no secondary context (args[3]==0, args[6]==0) is restated:
-// that is every configuration compressBlock emits for method 1x.
+// ZSFX/libzpaq.cpp:6140-6552; code formats documented at :6211-6222.
+// args[] as in ZSFX/libzpaq.cpp:6128-6138.  The hash table (args[5]-args[0] < 21) without a secondary context
+// (args[3]==0, args[6]==0) is restated: that is every configuration compressBlock emits for method 1x (SURVEY.md
+// Appendix C.3), and "x<N>,2,..." / "x<N>,6,..." with a small N6.
 // ------------------------------------------------------------------------------------------
 namespace {
 struct BitSink {
@@ -223,7 +224,8 @@ void emit_match(BitSink& bs, U32 len, U32 off, int rb) {  // write_match level 1
 extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* out, long cap,
                                 U32* trace, long trace_cap, long* ntrace) {
   const U32 n = (U32)n_;
-  if (args[3] != 0 || args[6] != 0 || (args[1] & 3) != 1 || args[5] - args[0] >= 21 || args[2] < 4) return -10;
+  const int level = args[1] & 3;
+  if (args[3] != 0 || args[6] != 0 || (level != 1 && level != 2) || args[5] - args[0] >= 21 || args[2] < 4) return -10;
   const int checkbits = 12 - args[0];                 // :6253
   const U32 htsize = 1u << args[5];                   // :6250
   const U32 minMatch = args[2], maxMatch = (1u << 14) * 3, maxLiteral = (1u << 14) / 4;  // :6258-6262
@@ -235,6 +237,26 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
   std::vector<U32> ht(htsize, 0);
   std::vector<U8> v; v.reserve(n / 2 + 16);
   BitSink bs(v);
+  auto write_literal = [&](U32 end, U32 lit) {        // :6464-6489
+    if (level == 1) { emit_literals(bs, in, end, lit); return; }
+    while (lit > 0) {                                 // level 2: 00xxxxxx then x+1 bytes
+      const U32 lit1 = lit > 64 ? 64 : lit;
+      v.push_back((U8)(lit1 - 1));
+      for (U32 j = end - lit; j < end - lit + lit1; ++j) v.push_back(in[j]);
+      lit -= lit1;
+    }
+  };
+  auto write_match = [&](U32 len, U32 off) {          // :6494-6549
+    if (level == 1) { emit_match(bs, len, off, rb); return; }
+    --off;
+    while (len > 0) {                                 // pieces of minMatch .. minMatch+63 bytes
+      const U32 len1 = len > minMatch * 2 + 63 ? minMatch + 63 : len > minMatch + 63 ? len - minMatch : len;
+      if (off < (1u << 16)) { v.push_back((U8)(64 + len1 - minMatch)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      else if (off < (1u << 24)) { v.push_back((U8)(128 + len1 - minMatch)); v.push_back((U8)(off >> 16)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      else { v.push_back((U8)(192 + len1 - minMatch)); v.push_back((U8)(off >> 24)); v.push_back((U8)(off >> 16)); v.push_back((U8)(off >> 8)); v.push_back((U8)off); }
+      len -= len1;
+    }
+  };
   U32 i = 0, h1 = 0, lit = 0; long nt = 0;
   while (i < n) {                                     // fill(), :6329-6453
     U32 blen = minMatch - 1, bp = 0; int bscore = 0;
@@ -252,9 +274,9 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
       if (blen >= 128) break;
     }
     const U32 off = i - bp;                           // :6413-6421
-    if (off > 0 && bscore > 0 && blen >= minMatch) {
-      emit_literals(bs, in, i, lit); lit = 0;
-      emit_match(bs, blen, off, rb);
+    if (off > 0 && bscore > 0 && blen >= minMatch + (level == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)))) {
+      write_literal(i, lit); lit = 0;
+      write_match(blen, off);
       if (trace && nt < trace_cap) { trace[3 * nt] = i; trace[3 * nt + 1] = blen; trace[3 * nt + 2] = off; }
       ++nt;
     } else { blen = 1; ++lit; }
@@ -266,10 +288,10 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
       }
       ++i;
     }
-    if (lit >= maxLiteral) { emit_literals(bs, in, i, lit); lit = 0; }  // :6450-6451
+    if (lit >= maxLiteral) { write_literal(i, lit); lit = 0; }  // :6450-6451
   }
-  emit_literals(bs, in, n, lit);                      // :6456-6460
-  bs.flush();
+  write_literal(n, lit);                              // :6456-6460
+  if (level == 1) bs.flush();
   if (ntrace) *ntrace = nt;
   if ((long)v.size() > cap) return -2;
   if (!v.empty()) memcpy(out, v.data(), v.size());

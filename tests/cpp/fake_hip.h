@@ -132,6 +132,7 @@ static inline bool zpq_place_enabled() { return false; }
 static inline u32* zpq_simd_table(zpq_ctx*) { return nullptr; }
 int zpq_lz77_sa_encode(zpq_ctx*, zpq_lz77_job*, const size_t*, size_t);
 int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
+int zpq_lz77_pack2_launch(zpq_ctx* ctx, const zpq_lzjob_dev* h_jobs, const u32* min_match, size_t nj, u32 max_n);
 
 // ---- rocPRIM: what the engine calls, by std::stable_sort ----------------------------------------------------------------------
 namespace rocprim {

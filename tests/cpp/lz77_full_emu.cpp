@@ -8,6 +8,7 @@
 #include "lz77_enc.hip"
 
 int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job*, const size_t*, size_t) { return zpq_fail(ctx, ZPQ_ERR_METHOD, "suffix-array jobs are not part of this emulation"); }
+int zpq_lz77_pack2_launch(zpq_ctx* ctx, const zpq_lzjob_dev*, const u32*, size_t, u32) { return zpq_fail(ctx, ZPQ_ERR_METHOD, "level-2 packing (lz77_sa.hip) is not part of this emulation"); }
 
 // in: n bytes + 64 readable bytes; out: cap bytes.  Returns the length of the code stream or a negative status.
 extern "C" long lz77_full_emu(const u8* in, u32 n, const int32_t args[9], u8* out, u32 cap, char* err, u32 err_cap) {

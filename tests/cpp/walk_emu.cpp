@@ -86,7 +86,7 @@ void walk_body() {
 LzCfg make_cfg(const u8* in, u32 n, const int32_t args[9]) {
   LzCfg c;
   c.in = in; c.n = n; c.minMatch = args[2]; c.bucket = (1u << args[4]) - 1; c.htbits = args[5]; c.checkbits = 12 - args[0];
-  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0;
+  c.shift1 = (args[5] - 1) / args[2] + 1; c.rb = args[0] > 4 ? args[0] - 4 : 0; c.level = (u32)(args[1] & 3);
   const u32 mmb = args[2] + 4;
   c.upd_limit = n > mmb ? n - mmb : 0;
   return c;

@@ -32,7 +32,8 @@ def exe_like(n, seed):
 
 
 METHODS = ["34", "34,200,1", "34,170,2", "34,30,0", "x4,2,12,0,7,25,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,7ci1",
-           "x4,4ci1,1,1,1,2a", "44,160,2", "x0,3ci1", "x6,3ci1"]
+           "x4,4ci1,1,1,1,2a", "44,160,2", "x0,3ci1", "x6,3ci1",
+           "x4,2,8,0,3,22,0c0,0,511i2", "x4,6,6,0,2,20,0c0,0,511", "x4,2,5,0,3,24,0"]     # byte-aligned codes from the HASH-TABLE finder (round 4)
 
 
 def _coded_payload(framed):

@@ -246,6 +246,29 @@ def test_lz77_streams_bit_identical(eng, args):
         assert g == want, k
 
 
+L2_HASH_ARGS = [(4, 2, 5, 0, 3, 22), (4, 2, 12, 0, 3, 24), (0, 2, 4, 0, 1, 18), (5, 2, 6, 0, 2, 20), (4, 2, 4, 0, 0, 16)]
+
+
+@pytest.mark.parametrize("args", L2_HASH_ARGS)
+def test_lz77_level2_byte_codes_from_the_hash_table_finder(eng, args):
+    """(args[1] & 3) == 2 with args[5] - args[0] < 21: LZBuffer's hash-table search (ZSFX/libzpaq.cpp:6373-6461) with the
+    byte-aligned codes and their rule that a far match must be 1 / 2 bytes longer (:6415-6416, :6482-6547).  `far` holds
+    matches of exactly minMatch .. minMatch + 2 bytes at distances beyond 2^16, where that rule decides."""
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()
+    far = bytearray(base)
+    mm = args[2]
+    for i in range(600):
+        p = int(rng.integers(0, 60000))
+        far += base[p:p + mm + (i % 3)] + bytes(rng.integers(0, 256, size=3, dtype=np.uint8))
+    blocks = [datagen.text_like(200000, 31), datagen.mixed(150000, 32), bytes(far), datagen.binary_like(90000, 33), b"", b"z", b"ab" * 40]
+    out = eng.lz77_encode(blocks, [args] * len(blocks))
+    for b, o in zip(blocks, out):
+        assert o == orc.lz77_encode(b, args), (args, len(b))
+        if orc.have_ref():
+            assert o == orc.ref_lzbuffer(b, args), (args, len(b))
+
+
 def test_lz77_long_matches_and_literal_limit(eng):
     rng = np.random.default_rng(9)
     unit = rng.integers(0, 256, size=60000, dtype=np.uint8).tobytes()

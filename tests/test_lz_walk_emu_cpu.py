@@ -90,7 +90,8 @@ def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(tmp_path_factory)
 # rings in LDS (lz77_duo.inc) --, lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel.  Segments of a
 # few KiB put seams, swallowed segments and re-walks into small inputs.
 # ---------------------------------------------------------------------------------------------------------------------
-SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 6, 0, 2, 15], 16384), ([5, 1, 5, 0, 0, 14], 4096)]
+SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 6, 0, 2, 15], 16384), ([5, 1, 5, 0, 0, 14], 4096),
+              ([4, 2, 5, 0, 3, 15], 4096), ([0, 2, 4, 0, 1, 14], 16384)]          # level 2: the same parse with the byte codes' take rule
 
 
 def _spec_case(job):
@@ -100,6 +101,14 @@ def _spec_case(job):
     L.spec_emu.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     inputs = _inputs()
     inputs["seams"] = (datagen.text_like(5000, 11) * 3)[:14000] + bytes(9000) + datagen.text_like(5000, 12)   # matches across several segment edges, a swallowed segment
+    if (args[1] & 3) == 2:          # short matches at distances beyond 2^16: a far match must be longer to be taken
+        rng = np.random.default_rng(21)
+        base = rng.integers(0, 256, size=66000, dtype=np.uint8).tobytes()
+        far = bytearray(base)
+        for i in range(150):
+            p = int(rng.integers(0, 400))
+            far += base[p:p + args[2] + (i % 3)] + bytes(rng.integers(0, 256, size=3, dtype=np.uint8))
+        inputs = {"far": bytes(far), "text": inputs["text"], "runs": inputs["runs"], "tiny": inputs["tiny"], "empty": b""}
     for name, b in inputs.items():
         n = len(b)
         cap = n // 4 + 16

@@ -65,6 +65,24 @@ def test_lz77_long_match_and_literal_limits():
         assert orc.lz77_decode(ours, len(b)) == b
 
 
+L2_HASH_ARGS = [(4, 2, 5, 0, 3, 22), (4, 2, 12, 0, 3, 24), (0, 2, 4, 0, 1, 18), (5, 2, 6, 0, 2, 20), (4, 2, 4, 0, 0, 16)]
+
+
+@pytest.mark.parametrize("args", L2_HASH_ARGS, ids=lambda a: ",".join(map(str, a)))
+def test_lz77_level2_hash_finder_stream_identical_to_lzbuffer(args):
+    """Byte-aligned codes from the hash-table finder (round 4): the restatement against the real LZBuffer, with matches of
+    minMatch .. minMatch + 2 bytes at distances beyond 2^16, where the 'a far match must be longer' rule (:6415-6416) decides,
+    a match beyond maxMatch (cut into pieces) and a literal run beyond maxLiteral."""
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()
+    far = bytearray(base)
+    for i in range(600):
+        p = int(rng.integers(0, 60000))
+        far += base[p:p + args[2] + (i % 3)] + bytes(rng.integers(0, 256, size=3, dtype=np.uint8))
+    for b in list(INPUTS.values()) + [bytes(far), base + base + datagen.random_bytes(6000, 3) + base[:100]]:
+        assert orc.lz77_encode(b, args) == orc.ref_lzbuffer(b, args), (args, len(b))
+
+
 def test_e8e9_forward_and_inverse():
     rng = np.random.default_rng(11)
     b = bytearray(rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes())

@@ -1,4 +1,4 @@
-# Round 4: literal runs from the chain wave's LDS cache -- profile, parity, dup8
+# Round 4: profile, parity and dup8 after a change to the three-wave parse
 R=$GRAFT_REPO_ROOT
 T=${1:-r04r}
 mkdir -p $R/gpurun_out

@@ -35,7 +35,8 @@ if sum(out2):
     print("   chain     cycles/window (ring-2 wait, read, -, -, chain): %%s = %%.0f" %% ([round(x / w) for x in v2[16:21]], sum(v2[16:24]) / w))
 ''' % {"root": ROOT}
 for label, env in (("silesia-like units, direct three waves", {"ZPQ_LZ_DIRECT": "1", "CORPUS": "silesia", "NB": "12"}),
-                   ("mixed, direct three waves", {"ZPQ_LZ_DIRECT": "1"})):
+                   ("silesia-like units, spec three waves", {"CORPUS": "silesia", "NB": "12"}),
+                   ("mixed, spec three waves", {})):
     e = dict(os.environ, LABEL=label, **env)
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=e, timeout=600)
     print(r.stdout.strip() or r.stderr[-800:])

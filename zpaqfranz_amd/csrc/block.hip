@@ -128,8 +128,7 @@ int parse_method(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, C
   else if (pre > 7) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': pre-processor %d does not exist", m.c_str(), pre);
   else if (level == 0) cfg->kind = KIND_STOREX;                                      // model only (x,0) or E8E9 + model (x,4)
   else if (level == 1 && cfg->args[0] <= 6) cfg->kind = KIND_LZ1;                    // blocks up to 64 MiB (rb = 0..2)
-  else if (level == 2 && cfg->args[5] - cfg->args[0] >= 21) cfg->kind = KIND_LZ1;    // byte-aligned codes over the suffix array
-  else if (level == 2) return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s': byte-aligned LZ77 with the hash-table match finder is not implemented (use the suffix array: N6 = N1 + 21)", m.c_str());
+  else if (level == 2 && cfg->args[0] <= 6) cfg->kind = KIND_LZ1;                    // byte-aligned codes: over the suffix array (N6 - N1 >= 21) or the hash table
   else if (level == 3) cfg->kind = KIND_BWT;
   else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s' not implemented", m.c_str());
   if (cfg->kind != KIND_STORE0 && (u64)n > (1ull << (20 + cfg->args[0])))

@@ -54,7 +54,12 @@ struct LzCfg {
   u32 n;
   u32 minMatch, bucket, htbits, checkbits, shift1, rb;
   u32 upd_limit;   // positions < upd_limit are inserted (i + minMatchBoth < n)
+  u32 level;       // 1: bit codes, 2: byte-aligned codes -- a match must then be 1 / 2 bytes longer to pay for a 3- / 4-byte offset
 };
+// the length a match at distance off must reach to be taken (ZSFX/libzpaq.cpp:6415-6416)
+__device__ __forceinline__ u32 lz_need(const LzCfg& C, u32 off) {
+  return C.minMatch + (C.level == 2 ? (u32)(off >= (1u << 16)) + (u32)(off >= (1u << 24)) : 0u);
+}
 
 // per (block, segment)
 struct LzSegDev {
@@ -410,7 +415,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
           }
         }
         const u32 off = q - bp;
-        if (off > 0 && bscore > 0 && blen >= mm) { rlen[f] = blen; roff[f] = off; }
+        if (off > 0 && bscore > 0 && blen >= lz_need(C, off)) { rlen[f] = blen; roff[f] = off; }
       }
     }
     // ---- serial greedy chain over this window (wave-uniform) -----------------------------------
@@ -492,7 +497,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
           }
         }
         const u32 off = i - bp;
-        const bool take = off > 0 && bscore > 0 && blen >= mm;
+        const bool take = off > 0 && bscore > 0 && blen >= lz_need(C, off);
         tlen = take ? blen : 0u; toff = off;
       } else {
         const u32 l0 = __builtin_amdgcn_readlane(rlen[0], j), l1 = __builtin_amdgcn_readlane(rlen[1], j);
@@ -842,8 +847,8 @@ static bool uses_suffix_array(const int32_t a[9]) { return a[5] - a[0] >= 21; }
 
 static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
   const int lvl = a[1] & 3;
-  if (a[1] < 1 || a[1] > 7 || a[1] == 4 || lvl == 3 || lvl == 0 || (lvl == 2 && !uses_suffix_array(a)))
-    return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 pre-processor %d not implemented (level 1, and level 2 over a suffix array, are)", a[1]);
+  if (a[1] < 1 || a[1] > 7 || a[1] == 4 || lvl == 3 || lvl == 0)
+    return zpq_fail(ctx, ZPQ_ERR_METHOD, "LZ77 pre-processor %d not implemented (levels 1 and 2 are)", a[1]);
   if (uses_suffix_array(a)) {        // LZ77-SA (methods 2..4): lz77_sa.hip
     if (a[0] < 0 || a[0] > 6 || a[5] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "suffix-array LZ77: block size 2^%d out of range", 20 + a[0]);
     if (lvl == 1 ? (a[2] < 4 || a[2] > 255) : (a[2] < 1 || a[2] > 64)) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
@@ -938,7 +943,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     const int32_t* a = z.args;
     LzCfg c;
     c.in = z.d_in; c.n = z.n; c.minMatch = a[2]; c.bucket = (1u << a[4]) - 1; c.htbits = a[5]; c.checkbits = 12 - a[0];
-    c.shift1 = (a[5] - 1) / a[2] + 1; c.rb = a[0] > 4 ? a[0] - 4 : 0;
+    c.shift1 = (a[5] - 1) / a[2] + 1; c.rb = a[0] > 4 ? a[0] - 4 : 0; c.level = (u32)(a[1] & 3);
     const u32 mmb = a[2] + 4;
     c.upd_limit = z.n > mmb ? z.n - mmb : 0;
     const u32 nseg = std::max<u32>(1, (z.n + kSegBytes - 1) / kSegBytes);
@@ -1076,8 +1081,24 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     ZPQ_LAUNCH(ctx, "lz77_move_tokens_kernel", st, lz77_move_tokens_kernel, dim3(32, (unsigned)(nseg_total * 2)), dim3(256), d_jobs, d_segs, d_segjob);
     ZPQ_HIP(ctx, hipGetLastError());
   }
-  // 4. tokens -> bits
-  { int rc = zpq_lz77_pack_launch(ctx, d_jobs, nj, max_n); if (rc) return rc; }
+  // 4. tokens -> bits (level 1) / bytes (level 2: lz77_sa.hip's pack kernels)
+  {
+    std::vector<zpq_lzjob_dev> j1, j2; std::vector<u32> mm2;
+    u32 max1 = 0, max2 = 0;
+    for (size_t i = 0; i < nj; ++i) {
+      if ((jobs[lo + i].args[1] & 3) == 2) { j2.push_back(hj[i]); mm2.push_back((u32)jobs[lo + i].args[2]); max2 = std::max(max2, jobs[lo + i].n); }
+      else { j1.push_back(hj[i]); max1 = std::max(max1, jobs[lo + i].n); }
+    }
+    if (j2.empty()) { int rc = zpq_lz77_pack_launch(ctx, d_jobs, nj, max_n); if (rc) return rc; }
+    else {
+      if (!j1.empty()) {
+        ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, j1.data(), j1.size() * sizeof(LzJobDev), hipMemcpyHostToDevice, st));      // (the kernels above are enqueued: the records may be replaced)
+        ZPQ_HIP(ctx, hipStreamSynchronize(st));
+        int rc = zpq_lz77_pack_launch(ctx, d_jobs, j1.size(), max1); if (rc) return rc;
+      }
+      int rc = zpq_lz77_pack2_launch(ctx, j2.data(), mm2.data(), j2.size(), max2); if (rc) return rc;
+    }
+  }
   std::vector<u32> res(nj * 4);
   ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
@@ -1145,6 +1166,7 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
   const size_t nbatch = (all_bytes + budget - 1) / budget, nbatch_d = (all_direct + budget - 1) / budget;
   bool direct = (double)nbatch_d * (double)max_n < (double)nbatch * (double)std::min<u32>(seg, max_n ? max_n : 1);
   if (const char* e = getenv("ZPQ_LZ_DIRECT")) direct = atoi(e) != 0;
+  for (size_t i = 0; i < njobs; ++i) if ((jobs[i].args[1] & 3) == 2) direct = false;      // (the chain wave writes bit codes only: byte codes go through the token lists)
   // batches of about equal size (a last batch of a few blocks would leave the chip idle behind its slowest wave)
   const size_t total = direct ? all_direct : all_bytes, nb_ = direct ? nbatch_d : nbatch;
   const size_t target = nb_ > 1 ? std::min(budget, total / nb_ + (total / nb_) / 16) : budget;

@@ -612,6 +612,28 @@ __global__ __launch_bounds__(256) void lz77_pack2_literals_kernel(const Pack2Dev
 }
 }  // namespace
 
+// tokens -> byte-aligned codes for nj blocks whose token lists are final (result[0] = token count, out zeroed); also what
+// the hash-table parse of lz77_enc.hip calls for its level-2 jobs
+int zpq_lz77_pack2_launch(zpq_ctx* ctx, const zpq_lzjob_dev* h_jobs, const u32* min_match, size_t nj, u32 max_n) {
+  if (!nj) return ZPQ_OK;
+  hipStream_t st = ctx->stream;
+  std::vector<Pack2Dev> j2(nj);
+  for (size_t i = 0; i < nj; ++i) {
+    Pack2Dev& P = j2[i];
+    P.in = h_jobs[i].in; P.n = h_jobs[i].n; P.minMatch = min_match[i]; P.tok_pos = h_jobs[i].tok_pos; P.tok_len = h_jobs[i].tok_len; P.tok_off = h_jobs[i].tok_off;
+    P.tok_at = h_jobs[i].tok_bit; P.result = h_jobs[i].result; P.out = h_jobs[i].out; P.out_cap = h_jobs[i].out_cap;
+  }
+  Pack2Dev* d_p2 = (Pack2Dev*)zpq_scratch(ctx, 30, nj * sizeof(Pack2Dev) + 256);
+  if (!d_p2) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "level-2 pack records");
+  ZPQ_HIP(ctx, hipMemcpyAsync(d_p2, j2.data(), nj * sizeof(Pack2Dev), hipMemcpyHostToDevice, st));
+  ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  ZPQ_LAUNCH(ctx, "lz77_pack2_tokens_kernel", st, lz77_pack2_tokens_kernel, dim3((unsigned)nj), dim3(1024), d_p2);
+  if (max_n) ZPQ_LAUNCH(ctx, "lz77_pack2_literals_kernel", st, lz77_pack2_literals_kernel, dim3((max_n + 255) / 256, (unsigned)nj), dim3(256), d_p2);
+  ZPQ_HIP(ctx, hipGetLastError());
+  return ZPQ_OK;
+}
+
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 
 // divsufsort's result on the device (ZSFX/libzpaq.cpp:6047): d_sa[n] and, when asked for, its inverse d_isa[n]

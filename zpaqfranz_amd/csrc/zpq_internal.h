@@ -12,7 +12,7 @@
 
 // grow-only device scratch arenas; slot numbers are fixed per use (see the zpq_scratch callers):
 // 0-11 compress side / hashing, 12-17 the device-resident decode path (unblock.hip), 18-19 checksums, 20-22 E8E9,
-// 24 per-block arrays of the suffix-array LZ77 path, 28-29 twin files (twins.hip, fragment.hip)
+// 24 per-block arrays of the suffix-array LZ77 path, 28-29 twin files (twins.hip, fragment.hip), 30 level-2 pack records
 #define ZPQ_SCRATCH_SLOTS 32
 
 struct zpq_ctx {
@@ -148,6 +148,8 @@ struct zpq_lzjob_dev {
 };
 // tokens -> code bits for nj records (out must be zeroed, result[0] = token count); max_n = longest block
 int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
+// the same for level 2 (byte-aligned codes; lz77_sa.hip): HOST records, minMatch per record
+int zpq_lz77_pack2_launch(zpq_ctx* ctx, const zpq_lzjob_dev* h_jobs, const u32* min_match, size_t nj, u32 max_n);
 // the jobs jobs[which[0..nj)] whose match finder is the suffix array (lz77_sa.hip)
 int zpq_lz77_sa_encode(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, size_t nj);
 // decodes every record on `st`; no host round trip for results (h_jobs = host copy of d_jobs, for the scratch layout)
