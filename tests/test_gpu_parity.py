@@ -413,12 +413,14 @@ def test_compress_block_cm_methods_equal_reference_coder(eng, method):
 
 
 def test_unsupported_methods_are_refused_not_approximated(eng):
-    # what is still outside the implemented family is refused, never approximated: byte-aligned LZ77 with the hash-table
-    # match finder (only the suffix-array finder produces level-2 codes here), BWT + E8E9 above 16 MiB blocks (its
-    # post-processor is not restated), pre-processor numbers that do not exist.  (Levels 2 / 3 / E8E9-only themselves are
-    # served since round 3: tests/test_gpu_m3.py.)
-    res = eng.compress_blocks([b"hello world" * 100] * 3, ["x4,6,4,0,3,24c0", "x5,7ci1", "x4,9ci1"], None, None, True)
+    # what is still outside the implemented family is refused, never approximated: a secondary LZ77 context (args[3] > 0:
+    # the second hash table of LZBuffer is not restated), BWT + E8E9 above 16 MiB blocks (its post-processor is not
+    # restated), pre-processor numbers that do not exist.  (Levels 2 / 3 / E8E9-only are served since round 3, level 2 from
+    # the hash-table finder since round 4: tests/test_gpu_m3.py.)
+    res = eng.compress_blocks([b"hello world" * 100] * 3, ["x4,1,4,8,3,24", "x5,7ci1", "x4,9ci1"], None, None, True)
     assert [st for st, _ in res] == [-5, -5, -5]
+    (st, blk), = eng.compress_blocks([b"hello world" * 100], ["x4,6,4,0,3,24c0"], None, None, True)       # byte codes from the hash-table finder + E8E9
+    assert st == 0 and eng.decompress_blocks([blk], [2000])[0]["data"] == b"hello world" * 100
     (st, blk), = eng.compress_blocks([b"hello world" * 100], ["14,100,2"], None, None, True)
     assert st == 0 and eng.decompress_blocks([blk], [2000])[0]["data"] == b"hello world" * 100
 
