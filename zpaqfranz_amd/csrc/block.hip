@@ -133,6 +133,7 @@ int parse_method(zpq_ctx* ctx, const char* method, const u8* host_data, u32 n, C
   else return zpq_fail(ctx, ZPQ_ERR_METHOD, "method '%s' not implemented", m.c_str());
   if (cfg->kind != KIND_STORE0 && (u64)n > (1ull << (20 + cfg->args[0])))
     return zpq_fail(ctx, ZPQ_ERR_ARG, "block larger than 2^%d", 20 + cfg->args[0]);
+  if (cfg->kind == KIND_LZ1) return zpq_lz77_check_args(ctx, cfg->args, n);      // (e.g. a secondary context: refused for THIS block)
   return ZPQ_OK;
 }
 

@@ -1110,6 +1110,9 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   return ZPQ_OK;
 }
 
+// what compressBlock asks before it queues a block for the encoder: a refusal belongs to that block, not to the whole call
+int zpq_lz77_check_args(zpq_ctx* ctx, const int32_t args[9], u32 n) { return check_args(ctx, args, n); }
+
 extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;

@@ -148,6 +148,7 @@ struct zpq_lzjob_dev {
 };
 // tokens -> code bits for nj records (out must be zeroed, result[0] = token count); max_n = longest block
 int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u32 max_n);
+int zpq_lz77_check_args(zpq_ctx* ctx, const int32_t args[9], u32 n);     // ZPQ_OK or the status zpq_lz77_encode_dev would return for these arguments
 // the same for level 2 (byte-aligned codes; lz77_sa.hip): HOST records, minMatch per record
 int zpq_lz77_pack2_launch(zpq_ctx* ctx, const zpq_lzjob_dev* h_jobs, const u32* min_match, size_t nj, u32 max_n);
 // the jobs jobs[which[0..nj)] whose match finder is the suffix array (lz77_sa.hip)
