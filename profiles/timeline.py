@@ -56,7 +56,10 @@ def main(dbdir, last_ms=None, skip_end_ms=0.0):
         wg = max(1, wx) * max(1, wy or 1) * max(1, wz or 1)
         threads = max(1, gx) * max(1, gy or 1) * max(1, gz or 1)        # HIP grid sizes are in threads here
         waves = (threads // wg) * -(-wg // 64)
-        ev.append((int(s), int(e), short(name), max(1, waves)))
+        nm = short(name)
+        if nm == "sha1_chain_kernel":            # one symbol, two launch shapes: a wave per 16 MiB block (13 waves, the block checksums) / per fragment (thousands)
+            nm += " [block checksums]" if waves <= 64 else " [fragment ids]"
+        ev.append((int(s), int(e), nm, max(1, waves)))
     t_lo = min(s for s, _, _, _ in ev); t_hi = max(e for _, e, _, _ in ev)
     b = t_hi - skip_end_ms * 1e6
     a = t_lo if last_ms is None else max(t_lo, b - last_ms * 1e6)
@@ -97,10 +100,10 @@ def main(dbdir, last_ms=None, skip_end_ms=0.0):
     for s, e, n, w in ev:
         c, d, ww = per.get(n, (0, 0.0, 0.0))
         per[n] = (c + 1, d + (e - s), ww + w)
-    print("\n%-40s %6s %10s %9s %12s" % ("kernel", "calls", "sum_ms", "waves", "chip-ms"))
+    print("\n%-40s %6s %10s %9s %12s %10s" % ("kernel", "calls", "sum_ms", "waves", "chip-ms", "avg_ms"))
     print("# chip-ms: time x (waves / 1024, capped at 1, shared with whatever else runs): SIMD-seats the kernel held, in ms of the whole chip")
     for n, (c, d, ww) in sorted(per.items(), key=lambda kv: -share.get(kv[0], 0.0))[:28]:
-        print("%-40s %6d %10.1f %9d %12.1f" % (n, c, d / 1e6, ww / c, share.get(n, 0.0) / 1e6))
+        print("%-40s %6d %10.1f %9d %12.1f %10.2f" % (n, c, d / 1e6, ww / c, share.get(n, 0.0) / 1e6, d / 1e6 / c))
     print("%-40s %6s %10s %9s %12.1f  (= %.1f %% of the traced time)" % ("total", "", "", "", sum(share.values()) / 1e6, 100 * sum(share.values()) / span))
 
 
