@@ -1029,6 +1029,11 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
   }
   ZPQ_HIP(ctx, hipMemcpyAsync(d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
+  {
+    // who gets issue priority where waves share a SIMD: the block checksum chains (default) or the segment parse (ZPQ_PRIO=lz)
+    static const u32 lz_prio = [] { const char* e = getenv("ZPQ_PRIO"); return e && !strcmp(e, "lz") ? 1u : 0u; }();
+    ZPQ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lz_prio), &lz_prio, sizeof lz_prio, 0, hipMemcpyHostToDevice, st));
+  }
   // three waves per block / segment on one table (lz77_duo.inc): producer | evaluator | chain
   if (direct) {
     for (int nb = 0; nb <= 3; ++nb) {

@@ -392,8 +392,10 @@ __device__ __forceinline__ void sha1_chain_one(const u8* __restrict__ base, cons
   }
 }
 
+// prio: the chains ask for issue priority where they share a SIMD (a job is as long as its longest chain: ZPQ_PRIO, lz77_enc.hip)
 __global__ __launch_bounds__(64) void sha1_chain_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
-                                                        const u32* __restrict__ len, u8* __restrict__ digests) {
+                                                        const u32* __restrict__ len, u8* __restrict__ digests, const u32 prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
   sha1_chain_one(base, off, len, digests, blockIdx.x);
 }
 
@@ -597,6 +599,12 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
     (void)hipFuncSetAttribute((const void*)sha1_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hog);
     attr_set = true;
   }
+  u32 chain_prio = 0;
+  {
+    // few long chains (block checksums): issue priority where they share a SIMD with other jobs' waves, unless ZPQ_PRIO=lz
+    static const u32 lz_first = [] { const char* e = getenv("ZPQ_PRIO"); return e && !strcmp(e, "lz") ? 1u : 0u; }();
+    chain_prio = (n <= 64 && !lz_first) ? 1u : 0u;
+  }
   {
     ZpqProfScope prof_scope_(ctx, prof_name, s);
     const char* hog_env = getenv("ZPQ_CHAIN_HOG");
@@ -610,7 +618,7 @@ int zpq_sha1_chains_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64*
       const zpq_place P{counter, tab, (u32)n, (u32)(4 * n + 64)};
       hipLaunchKernelGGL(sha1_chain_placed_kernel, dim3((unsigned)(5 * n + 64)), dim3(64), 0, s, d_base, d_off, d_len, d_digests, P);
     } else {
-      hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests);
+      hipLaunchKernelGGL(sha1_chain_kernel, dim3((unsigned)n), dim3(64), reserve ? hog : 0, s, d_base, d_off, d_len, d_digests, chain_prio);
     }
   }
   ZPQ_HIP(ctx, hipGetLastError());
