@@ -51,7 +51,7 @@ template <class T> static inline T emu_shfl(T v, int src, int op) { return emu::
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #define __builtin_amdgcn_s_sleep(x) ((void)(emu::g_active ? (emu::to_main(), 0) : 0))      /* a sleeping wave lets the other wave of the workgroup run */
-#define LZ_DUO_TID() ((u32)emu::g_tid)                 /* lz77_duo.inc: two-wave workgroups (threadIdx is not per fibre in this harness) */
+#define LZ_DUO_TID() ((u32)emu::g_tid)                 /* lz77_waves.inc: two-wave workgroups (threadIdx is not per fibre in this harness) */
 #define LZ_DUO_WAVE_ID() ((u32)emu::wave())
 #define ZPQ_WAIT_VMCNT0 ((void)emu::wave_rendezvous(0, __LINE__))      /* lockstep: every lane's stores before anybody's next loads */
 // serial stand-ins for the global atomics of the thread-independent kernels (one thread runs after the other)
@@ -115,7 +115,7 @@ extern "C" long walk_emu(const u8* in, u32 n, const int32_t args[9], u32* table,
 
 // ---- the segment speculation of one block, as encode_batch() lays it out -----------------------------------------------------
 // table states (copy + scatter kernels), then lz77_spec3_kernel per segment (a workgroup of three waves: producer | evaluator |
-// chain, lz77_duo.inc), lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel: the kernels themselves,
+// chain, lz77_waves.inc), lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel: the kernels themselves,
 // the wave kernels as emulated waves, the thread-independent ones thread by thread.
 namespace {
 struct SpecRun { const LzSegDev* segs; const u32* list; const LzJobDev* jobs; u32 nseg; };

@@ -1,4 +1,4 @@
-"""The one-pass form of the LZ77 level-1 decision (lz77_duo.inc): LZBuffer scores a candidate with
+"""The one-pass form of the LZ77 level-1 decision (lz77_waves.inc): LZBuffer scores a candidate with
 score = 8 l - lg(offset) - 2 (lit > 0) - 11 (ZSFX/libzpaq.cpp:6396-6408), and the GPU needs the decision for both values of
 (lit > 0).  The two runs accept the same candidates unless one is accepted with a score of 1 or 2; the kernel therefore
 makes one run and repeats it only where that happened.  Here: a model of both forms over random candidate lists in which

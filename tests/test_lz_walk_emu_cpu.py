@@ -1,4 +1,4 @@
-"""The LZ77 hash-table parse (zpaqfranz_amd/csrc/lz77_enc.hip, lz77_duo.inc) run on the CPU: tests/cpp/walk_emu.cpp compiles
+"""The LZ77 hash-table parse (zpaqfranz_amd/csrc/lz77_enc.hip, lz77_waves.inc) run on the CPU: tests/cpp/walk_emu.cpp compiles
 THE DEVICE SOURCE for the host and runs it as emulated waves (64 lanes as fibres in lockstep, the wave-level operations as
 rendezvous; the three waves of a parse workgroup -- producer | evaluator | chain -- as 192 fibres whose spin loops yield to
 each other).  Tokens and code streams must be the oracle's.  Needs the ROCm clang++ (address spaces, ext vectors) as a
@@ -87,7 +87,7 @@ def test_the_walk_on_an_emulated_wave_gives_the_oracles_tokens(tmp_path_factory)
 # ---------------------------------------------------------------------------------------------------------------------
 # The whole segment speculation of a block, kernel by kernel as encode_batch() launches them: table states (the copy and
 # scatter kernels), lz77_spec3_kernel -- a workgroup of three waves per segment: producer | evaluator | chain with their
-# rings in LDS (lz77_duo.inc) --, lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel.  Segments of a
+# rings in LDS (lz77_waves.inc) --, lz77_seam_kernel per segment, lz77_stitch_kernel, lz77_move_tokens_kernel.  Segments of a
 # few KiB put seams, swallowed segments and re-walks into small inputs.
 # ---------------------------------------------------------------------------------------------------------------------
 SPEC_CASES = [([4, 1, 5, 0, 3, 15], 4096), ([0, 1, 4, 0, 1, 14], 8192), ([4, 1, 6, 0, 2, 15], 16384), ([5, 1, 5, 0, 0, 14], 4096),

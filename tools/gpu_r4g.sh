@@ -1,4 +1,4 @@
-# Round 4: two waves per block on one table (lz77_duo.inc, default on) -- parity on the chip, wall times, A/B against ZPQ_LZ_DUO=0
+# Round 4: two waves per block on one table (lz77_waves.inc, default on) -- parity on the chip, wall times, A/B against ZPQ_LZ_DUO=0
 R=$GRAFT_REPO_ROOT
 T=${1:-r04g}
 mkdir -p $R/gpurun_out

@@ -1,4 +1,4 @@
-# Round 4: three waves per block on one table (lz77_duo.inc, default on): producer | evaluator | chain --
+# Round 4: three waves per block on one table (lz77_waves.inc, default on): producer | evaluator | chain --
 # parity on the chip and the bench lines
 R=$GRAFT_REPO_ROOT
 T=${1:-r04l}

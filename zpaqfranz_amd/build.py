@@ -17,7 +17,7 @@ def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(CSRC, "lz77_duo.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(CSRC, "lz77_waves.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
             os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h"),
             os.path.join(HERE, "shim", "jidac_gpu.cpp")]
     return any(os.path.getmtime(d) > t for d in deps)

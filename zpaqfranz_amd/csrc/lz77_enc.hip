@@ -14,7 +14,7 @@
 //    v_readlane'd results that jumps over literal runs with one ballot.  Positions whose candidates
 //    hit the 32-byte compare cap are re-evaluated exactly with 512-bytes-per-step whole-wave compares.
 //  * What touches the table, what evaluates candidates and what chains tokens are three WAVES of one workgroup
-//    (lz77_duo.inc: producer | evaluator | chain, rings in LDS): only the chain depends on the parse, so one table
+//    (lz77_waves.inc: producer | evaluator | chain, rings in LDS): only the chain depends on the parse, so one table
 //    serves three instruction streams.  lz_walk below is the same walk in one wave (seams and re-walks: short).
 //  * Blocks are cut into segments of 2 MiB.  The table state at every segment start is built up
 //    front (copy + atomicMax scatter), every segment is parsed speculatively from its own start
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
-#include "lz77_duo.inc"        // three waves per block on one table: lz77_spec3_kernel, lz77_direct3_kernel
+#include "lz77_waves.inc"        // three waves per block on one table: lz77_spec3_kernel, lz77_direct3_kernel
 
 #if defined(ZPQ_EMU_WALK_ONLY) && !defined(ZPQ_EMU_FULL)
 }  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled.
@@ -884,7 +884,7 @@ static size_t job_bytes(const zpq_lz77_job& z, u32 kSegBytes) {
   return ((size_t)4 << z.args[5]) * (2 * (size_t)nseg - 1) + toks * (16 + 12 + (nseg > 1 ? 12 : 0));
 }
 
-// Three-wave kernels (lz77_duo.inc): producer | evaluator | chain, one workgroup per segment / block
+// Three-wave kernels (lz77_waves.inc): producer | evaluator | chain, one workgroup per segment / block
 template <int NB>
 static void launch_spec3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzSegDev* d_segs, const u32* sl) {
   ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec3_kernel<NB>, grid, dim3(192), d_segs, sl);
@@ -1034,7 +1034,7 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
     static const u32 lz_prio = [] { const char* e = getenv("ZPQ_PRIO"); return e && !strcmp(e, "lz") ? 1u : 0u; }();
     ZPQ_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lz_prio), &lz_prio, sizeof lz_prio, 0, hipMemcpyHostToDevice, st));
   }
-  // three waves per block / segment on one table (lz77_duo.inc): producer | evaluator | chain
+  // three waves per block / segment on one table (lz77_waves.inc): producer | evaluator | chain
   if (direct) {
     for (int nb = 0; nb <= 3; ++nb) {
       if (!rng[nb].jn) continue;
