@@ -1,4 +1,5 @@
-// Test infrastructure: libzpaq::Decompresser::pcomp() of the shim over an archive, without decoding anything (no GPU needed):
+// Test infrastructure: libzpaq::Decompresser::pcomp() of the shim over an archive, without decoding a segment (no GPU needed for
+// blocks without a context model; behind a model the head of the coded stream is decoded on the device):
 // per block "<filename>|<hex of what pcomp() wrote, empty if it returned false>".
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,9 +33,11 @@ int main(int argc, char** argv) {
         d.readComment();
         d.readSegmentEnd();                       // the segment is read, not decoded
         if (first) {
-          const bool have = d.pcomp(&pc);
-          printf("%s|", name.c_str());
-          if (have) for (size_t i = 0; i < pc.size(); ++i) printf("%02x", pc.c_str()[i] & 255);
+          fwrite(name.c_str(), 1, name.size(), stdout); printf("|");        // (a StringBuffer is not NUL-terminated)
+          try {
+            const bool have = d.pcomp(&pc);          // (behind a context model this decodes the head of the stream on the device)
+            if (have) for (size_t i = 0; i < pc.size(); ++i) printf("%02x", pc.c_str()[i] & 255);
+          } catch (std::exception& e) { printf("error: %s", e.what()); }
           printf("\n");
           first = false;
         }

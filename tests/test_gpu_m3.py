@@ -4,6 +4,8 @@ fixture in the reference tree; they are pinned by DECODE parity: the REAL refere
 ZSFX/libzpaq.cpp:2239-2366 with its PostProcessor / ZPAQL machine) restores every block this engine writes, stored SHA-1
 verified; the pre-processed stream inside equals the REAL LZBuffer's (:6140-6552); and the engine's own decode side
 (native level-2 decoder, inverse BWT by list ranking, E8E9 inverse, or the translated program) gives the input back."""
+import os
+
 import numpy as np
 import pytest
 
@@ -148,3 +150,31 @@ def test_fragment_statistics_and_method_hint(eng):
         assert r["sha1_ok"] == 1
         pos += r["consumed"]
     assert len(methods) >= 2          # not one header for everything: the hint chose per block
+
+
+def test_shim_decompresser_pcomp_behind_a_context_model(eng, tmp_path):
+    """libzpaq::Decompresser::pcomp() (ZSFX/libzpaq.h:1254): for a block whose post-processor section sits inside the
+    arithmetic-coded stream the shim decodes the head of that stream on the device -- the section it hands back must be the
+    program compressBlock put there (two size bytes in front); a block coded by a model alone has none."""
+    import subprocess
+    from zpaqfranz_amd import build, engine as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    here = os.path.join(root, "zpaqfranz_amd")
+    drv = str(tmp_path / "pcomp_driver")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(here, "shim"), os.path.join(root, "tests", "cpp", "pcomp_driver.cpp"),
+                           "-L" + here, "-lzpaq_gpu", "-lzpaqhip", "-Wl,-rpath," + here, "-o", drv])
+    data = datagen.text_like(60000, 9)
+    methods = ["x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,0ci1", "x4,2,8,0,3,22,0c0,0,511i2"]
+    res = eng.compress_blocks([data] * len(methods), methods, ["f%d" % i for i in range(len(methods))], ["c"] * len(methods), True)
+    arc = tmp_path / "m.zpaq"
+    arc.write_bytes(b"".join(f for st, f in res))
+    assert all(st == 0 for st, _ in res)
+    r = subprocess.run([drv, str(arc)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split("|") for l in r.stdout.strip().splitlines()]
+    assert [l[0] for l in lines] == ["f%d" % i for i in range(len(methods))]
+    for m, l in zip(methods, lines):
+        src, args = E.make_config(E.expand_method(m, data))
+        _, pc = E.compile_config(src, args)
+        want = (bytes([len(pc) & 255, len(pc) >> 8]) + pc).hex() if pc else ""
+        assert l[1] == want, (m, l[1][:40], want[:40])

@@ -1,7 +1,8 @@
 """libzpaq::Decompresser::pcomp() of the shim (ZSFX/libzpaq.h:1254): for the reference's own fixture the three LZ77-coded
 i blocks must hand back the 302-byte level-1 post-processor program the reference wrote (two size bytes in front), the
-stored c / h blocks nothing; the d block is coded behind a context model, where the shim does not keep the program.
-Host-side parsing only: runs without a GPU."""
+stored c / h blocks nothing; the d block is coded behind a context model, where the head of the stream has to be decoded on the
+device (here, without one: an error, not a wrong answer; tests/test_gpu_m3.py asks the chip).  Host-side parsing only: runs
+without a GPU."""
 import ctypes as C
 import json
 import os
@@ -31,4 +32,4 @@ def test_pcomp_of_the_fixture_blocks(tmp_path):
     kinds = {b["filename"][17]: l[1] for b, l in zip(blocks, lines)}            # jDC<14 digits><c|d|h|i><10 digits>
     assert bytes.fromhex(kinds["i"]) == want                                    # LZ77 level 1: the golden program
     assert kinds["c"] == "" and kinds["h"] == ""                                 # stored blocks: no PCOMP section
-    assert kinds["d"] == ""                                                      # behind a context model: not kept
+    assert kinds["d"] == "" or kinds["d"].startswith("error:")                   # behind a context model: needs the device (GPU test below the -m gpu marker)

@@ -392,19 +392,48 @@ bool Decompresser::decompress(int n) {
 
 // The PCOMP section of the block (ZSFX/libzpaq.h:1254: pp.z.write(out2, true) -- two size bytes, then the program), valid once the
 // first segment has been read.  Blocks without a context model keep it in their stored sub-blocks, where it is read from
-// here; behind a model it sits inside the coded stream the device decodes and post-processes in one go, and is not kept
-// (false, as before: nothing is written).
+// here; behind a model it is the head of the coded stream, which the device decodes as far as the section reaches
+// (zpq_cm_decode_dev stops at out_cap with the bytes produced so far valid): three bytes for the size, then the program.
 bool Decompresser::pcomp(Writer* out2) {
   Impl& d = *d_;
-  if (d.ncomp != 0 || !d.have_marker || d.segments != 1) return false;
-  std::vector<uint8_t> first;                                  // the first bytes of the stored stream: 1 lo hi program...
-  for (size_t p = 0; p + 4 <= d.payload.size();) {
-    const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
-    p += 4;
-    if (!k || p + k > d.payload.size()) break;
-    first.insert(first.end(), d.payload.begin() + p, d.payload.begin() + p + k);
-    p += k;
-    if (first.size() >= 3 && first.size() >= 3 + ((size_t)first[1] | (size_t)first[2] << 8)) break;
+  if (!d.have_marker || d.segments != 1) return false;
+  std::vector<uint8_t> first;                                  // the first bytes of the decoded stream: 1 lo hi program...
+  if (d.ncomp == 0) {
+    for (size_t p = 0; p + 4 <= d.payload.size();) {
+      const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
+      p += 4;
+      if (!k || p + k > d.payload.size()) break;
+      first.insert(first.end(), d.payload.begin() + p, d.payload.begin() + p + k);
+      p += k;
+      if (first.size() >= 3 && first.size() >= 3 + ((size_t)first[1] | (size_t)first[2] << 8)) break;
+    }
+  } else {
+    if (d.head.size() < 20 || d.payload.empty()) return false;
+    EngineHolder& e = engine();
+    std::lock_guard<std::mutex> g(e.mu);
+    zpq_ctx* ctx = e.get();
+    void *d_in = nullptr, *d_out = nullptr;
+    const size_t cap_max = 3 + 65535 + 64;
+    int rc = zpq_dev_alloc(ctx, d.payload.size() + 64, &d_in);
+    if (rc == ZPQ_OK) rc = zpq_dev_alloc(ctx, cap_max, &d_out);
+    if (rc == ZPQ_OK) rc = zpq_h2d(ctx, d_in, d.payload.data(), d.payload.size());
+    for (size_t want = 3; rc == ZPQ_OK;) {
+      zpq_cm_job j;
+      memset(&j, 0, sizeof j);
+      j.header = d.head.data() + 18; j.header_len = (uint32_t)(d.head.size() - 18);       // hsize[2] hh hm ph pm n COMP 0 HCOMP 0
+      j.d_in = (const uint8_t*)d_in; j.n = (uint32_t)d.payload.size();
+      j.d_out = (uint8_t*)d_out; j.out_cap = (uint32_t)want;
+      rc = zpq_cm_decode_dev(ctx, &j, 1);
+      if (rc != ZPQ_OK && rc != ZPQ_ERR_CAPACITY) break;
+      if (j.status != ZPQ_OK && j.status != ZPQ_ERR_CAPACITY) { rc = j.status; break; }
+      first.resize(j.out_len < want ? j.out_len : want);
+      rc = first.empty() ? ZPQ_OK : zpq_d2h(ctx, first.data(), d_out, first.size());
+      if (rc != ZPQ_OK || first.size() < 3 || first[0] != 1 || want > 3) break;
+      want = 3 + ((size_t)first[1] | (size_t)first[2] << 8);
+    }
+    if (d_in) zpq_dev_free(ctx, d_in);
+    if (d_out) zpq_dev_free(ctx, d_out);
+    if (rc != ZPQ_OK && rc != ZPQ_ERR_CAPACITY) fail(ctx, rc, "Decompresser::pcomp");
   }
   if (first.size() < 3 || first[0] != 1) return false;
   const size_t n = (size_t)first[1] | (size_t)first[2] << 8;

@@ -134,7 +134,7 @@ class Decompresser {
   void setOutput(Writer* out) { out_ = out; }
   void setSHA1(SHA1* sha1ptr) { sha_ = sha1ptr; }
   bool decompress(int n = -1);              // n bytes (-1 = all); false once the segment is exhausted
-  bool pcomp(Writer* out2);                 // the PCOMP section (size, program) of a block WITHOUT a context model; false behind a model
+  bool pcomp(Writer* out2);                 // the PCOMP section (size, program); behind a context model the head of the stream is decoded for it
   void readSegmentEnd(char* sha1string = 0);// [0] = 1 if a SHA-1 follows in [1..20], else 0
   int stat(int) { return 0; }               // the reference reports predictor statistics here (debug builds only)
   int buffered() { return 0; }
