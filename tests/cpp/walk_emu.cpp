@@ -80,7 +80,7 @@ template <int NB>
 void walk_body() {
   TokSink sink{g_w.tpos, g_w.tlen, g_w.toff, g_w.tcap, 0};
   u32 cur = 0, lit = 0;
-  lz_walk<NB, false>(g_w.c, g_w.table, 0, g_w.c.n, cur, lit, sink, nullptr, g_T);
+  lz_walk<NB>(g_w.c, g_w.table, 0, g_w.c.n, cur, lit, sink, nullptr, g_T);
   if (lane_id() == 0) { g_w.ntok = sink.n; g_w.end_cur = cur; g_w.end_lit = lit; }
 }
 LzCfg make_cfg(const u8* in, u32 n, const int32_t args[9]) {

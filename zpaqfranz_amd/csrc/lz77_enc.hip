@@ -180,8 +180,8 @@ __device__ unsigned long long g_lzprof[8];
 #define LZ_T(i) do {} while (0)
 #endif
 
-// Direct emitter: with one wave per block (no segment speculation) the parse order IS the output order, so the wave
-// writes the code stream as it goes -- LZBuffer::write_literal / write_match / putb (ZSFX/libzpaq.cpp:6166-6184,
+// Direct emitter: with one workgroup per block (no segment speculation) the parse order IS the output order, so the chain
+// wave writes the code stream as it goes -- LZBuffer::write_literal / write_match / putb (ZSFX/libzpaq.cpp:6166-6184,
 // 6455-6520) -- and no token list exists.  Control is wave-uniform; a literal run's bytes are spread over the lanes,
 // each shifting in the bits its left neighbour spills.
 struct BitSink {
@@ -273,10 +273,11 @@ struct SpecList { const u32* pos; const u32* len; u32 n; u32 j; };
 // (which must hold exactly the inserts of all positions < wbase) and continues the greedy parse
 // from (cur, lit).  Tokens go to `sink`.  With a SpecList the walk stops as soon as one of its
 // matches ends where a speculative match ends and returns that token's index (else -1).
-//
-template <int NB, bool DIRECT = false>
+// This is the walk in ONE wave: what the seam and stitch kernels call (a few windows each).  Whole segments and blocks are
+// parsed by three waves that split the same work between them (lz77_waves.inc).
+template <int NB>
 __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, u32 x1, u32& cur, u32& lit, TokSink& sink,
-                       SpecList* spec, unsigned long long* T_generic, BitSink* bits = nullptr) {
+                       SpecList* spec, unsigned long long* T_generic) {
   const u32 lane = (u32)lane_id();
   g_cu8* in = (g_cu8*)C.in;
   g_u32* ht = (g_u32*)ht_generic;
@@ -506,8 +507,7 @@ __device__ int lz_walk(const LzCfg& C, u32* __restrict__ ht_generic, u32 wbase, 
       }
       if (tlen) {
         LZ_C(2);
-        if (DIRECT) bits->match(cur, tlen, toff, lane);
-        else if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
+        if (lane == 0 && sink.n < sink.cap) { sink_pos[sink.n] = cur; sink_len[sink.n] = tlen; sink_off[sink.n] = toff; }
         ++sink.n;
         lit = 0;
         cur += tlen;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64) void lz77_seam_kernel(const LzSegDev* __restric
   if (cur == S.x0 && lit == 0) hit = -2;                           // in step from the first position
   else if (cur < S.x1) {
     SpecList sl{S.tpos, S.tlen, S.state[0], 0};
-    hit = lz_walk<NB, false>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
+    hit = lz_walk<NB>(S.c, S.pristine, S.x0, S.x1, cur, lit, sink, &sl, T);
   }
   if (lane == 0) {
     S.seam[0] = sink.n < sink.cap ? sink.n : sink.cap;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64) void lz77_stitch_kernel(const LzJobDev* __restr
     // exact re-walk (rare: the previous segment never got back in step)
     SpecList sl{S.tpos, S.tlen, ns, 0};
     u32* table = k ? segs[J.seg0 + k - 1].work : S.work;
-    const int hit = lz_walk<NB, false>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
+    const int hit = lz_walk<NB>(S.c, table, S.x0, S.x1, cur, lit, out, &sl, T);
     T[lane] = 0; T[lane + 64] = 0; T[lane + 128] = 0; T[lane + 192] = 0;
     __builtin_amdgcn_wave_barrier();
     if (hit >= 0) { append(0, (u32)hit + 1, ns); cur = S.state[1]; lit = S.state[2]; }
