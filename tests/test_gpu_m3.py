@@ -159,9 +159,9 @@ def test_shim_decompresser_pcomp_behind_a_context_model(eng, tmp_path):
     import subprocess
     from zpaqfranz_amd import build, engine as E
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    here = os.path.join(root, "zpaqfranz_amd")
+    here = build.HERE                      # (the product's directory; the emulated engine's when the suite runs on the CPU)
     drv = str(tmp_path / "pcomp_driver")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(here, "shim"), os.path.join(root, "tests", "cpp", "pcomp_driver.cpp"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(root, "zpaqfranz_amd", "shim"), os.path.join(root, "tests", "cpp", "pcomp_driver.cpp"),
                            "-L" + here, "-lzpaq_gpu", "-lzpaqhip", "-Wl,-rpath," + here, "-o", drv])
     data = datagen.text_like(60000, 9)
     methods = ["x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,0ci1", "x4,2,8,0,3,22,0c0,0,511i2"]
