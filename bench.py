@@ -1308,7 +1308,7 @@ def main():
                    # member bytes streamed once + the representatives they are compared with (cache resident after the first touch)
                    "twin_compare_kernel": tw["compared_bytes"] + (walked if tw["compared_bytes"] else 0), "lz77_spec_kernel": ub // max(1, world) + out_bytes // max(1, world),
                    "lz77_direct_kernel": ub // max(1, world) + out_bytes // max(1, world), "sha1_chain_kernel": ub // max(1, world)}
-            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": 3 * -(-ub // (2 << 20)), "lz77_direct_kernel": 3 * st["blocks"]}     # three waves per segment / block
+            waves = {"sha1_chain_kernel": st["blocks"], "lz77_spec_kernel": 3 * -(-ub // (2 << 20)), "lz77_direct_kernel": 4 * st["blocks"]}     # three waves per segment, four per block
             if tw["twin_bytes"]:
                 # what is left after the fold is walked by a handful of waves (one lane per 256 KiB segment / per fragment)
                 seg_b = max(256 << 10, walked // 158720)

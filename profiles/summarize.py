@@ -57,7 +57,7 @@ def main(root, tag, work=""):
         for name, calls, sm in cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
             k = short(name)
             k = "fragment_resume_kernel" if k.startswith("fragment_spec_kernel<true") else k.split("<")[0]   # names bench.py uses
-            k = {"lz77_spec3_kernel": "lz77_spec_kernel", "lz77_direct3_kernel": "lz77_direct_kernel"}.get(k, k)
+            k = {"lz77_spec3_kernel": "lz77_spec_kernel", "lz77_direct3_kernel": "lz77_direct_kernel", "lz77_direct4_kernel": "lz77_direct_kernel"}.get(k, k)
             per[k] = per.get(k, 0) + int(sm * 1024 * mul / max(1, calls))
     if per:
         import json

@@ -31,7 +31,7 @@ typedef u32 __attribute__((aligned(1))) u32_u;
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 #define __shared__ static
 struct EmuIdx { u32 x, y, z; };
 static EmuIdx blockIdx, gridDim;
@@ -48,6 +48,7 @@ static inline int lane_id() { return emu::lane(); }
 #define __builtin_amdgcn_readfirstlane(v) emu::shfl((v), 0, __LINE__)
 #define __builtin_amdgcn_wave_barrier() ((void)emu::wave_rendezvous(0, __LINE__))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+
 #define __syncthreads() emu::block_barrier(__LINE__)
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), __ATOMIC_RELAXED)

@@ -25,7 +25,7 @@ typedef u32 __attribute__((aligned(1))) u32_u;
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 #define __shared__ static
 struct EmuIdx { u32 x, y, z; };
 static EmuIdx blockIdx, gridDim;

@@ -27,7 +27,7 @@ typedef u32 __attribute__((aligned(1))) u32_u;
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 #define __shared__ static
 struct EmuDim { u32 x, y, z; };
 static EmuDim threadIdx, blockIdx, gridDim;
@@ -43,6 +43,7 @@ template <class T> static inline T emu_shfl(T v, int src, int op) { return emu::
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0, __LINE__)
 #define __builtin_amdgcn_wave_barrier() ((void)emu::wave_rendezvous(0, __LINE__))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_max(p, v, order, scope) __atomic_fetch_max((p), (v), __ATOMIC_RELAXED)
 #define __ATOMIC_RELAXED_HIP 0
@@ -196,9 +197,9 @@ extern "C" long spec_emu(const u8* in, u32 n, const int32_t args[9], u32 seg_byt
   return (long)nt;
 }
 
-// ---- one workgroup per block, parsing and emitting in one go (lz77_direct3_kernel) -------------------------------------------
+// ---- one workgroup per block, parsing and emitting in one go (lz77_direct4_kernel) -------------------------------------------
 namespace {
-template <int NB> void direct_body() { lz77_direct3_kernel<NB>(g_s.jobs, g_s.segs, g_s.list); }
+template <int NB> void direct_body() { lz77_direct4_kernel<NB>(g_s.jobs, g_s.segs, g_s.list); }
 }
 // out: the code stream (out_cap bytes, zeroed by the caller).  Returns its length, < 0 on an emulation error, -2 on overflow.
 extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* table, u8* out, u32 out_cap, char* err, u32 err_cap) {
@@ -219,7 +220,7 @@ extern "C" long direct_emu(const u8* in, u32 n, const int32_t args[9], u32* tabl
     default: b = direct_body<8>; break;
   }
   gridDim = {1, 1, 1};
-  const char* e = wave(b, 0, 192);
+  const char* e = wave(b, 0, 256);
   if (e) { if (err && err_cap) { strncpy(err, e, err_cap - 1); err[err_cap - 1] = 0; } return -1; }
   if (result[2]) return -2;
   return (long)result[1];

@@ -40,6 +40,8 @@ def _inputs():
         "mixed": datagen.mixed(10000, 3),
         "runs": bytes(4000) + b"ab" * 2500 + datagen.random_bytes(600, 4),            # very long matches: whole-wave compares
         "long": unit + unit + unit[:100] + datagen.random_bytes(6000, 5) + unit,       # capped candidates, a literal run past 4096
+        # literal runs of 250..530 bytes between matches: the emitting wave's byte ring filled across chunk borders, the 512-byte limit of its LDS path
+        "gaps": b"".join(unit[:700] + datagen.random_bytes(250 + 40 * k, 20 + k) for k in range(8)),
         "tiny": b"abcabcabcabc", "one": b"x", "empty": b"", "window": datagen.text_like(64, 7), "window+1": datagen.text_like(65, 8),
     }
 
@@ -152,8 +154,9 @@ def _direct_case(args):
 
 
 def test_direct_kernel_on_emulated_waves_writes_the_oracles_stream(tmp_path_factory):
-    """lz77_direct3_kernel: one workgroup parses a block and its chain wave writes the code stream itself (literal runs spread
-    over the lanes, match codes by put): byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
+    """lz77_direct4_kernel: one workgroup of four waves parses a block and writes the code stream (the chain wave's matches
+    go through a token ring to the emitting wave: literal runs spread over the lanes from its byte ring, match codes by put):
+    byte for byte the oracle's stream, raw offset bits (args[0] > 4) included."""
     _lib(tmp_path_factory)
     bad = _pool_map(_direct_case, [[4, 1, 5, 0, 3, 15], [5, 1, 4, 0, 2, 15], [6, 1, 6, 0, 1, 14]])
     assert not bad, bad

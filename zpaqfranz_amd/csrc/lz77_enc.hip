@@ -23,7 +23,7 @@
 //    its matches ends exactly where a speculative match ends -- both chains are then in the same
 //    state (lit == 0), so the rest of that segment's speculative tokens are adopted verbatim.
 //    With hundreds of blocks there is no speculation: one workgroup per block parses and writes the code
-//    stream itself (lz77_direct3_kernel).
+//    stream itself, the emission in a wave of its own (lz77_direct4_kernel).
 //  * Tokens -> bits: a workgroup scan gives every token its bit offset; code bits and literal
 //    bytes are OR-ed into the zeroed output in parallel (LSB-first, :6171-6186).
 // Integer/byte work on random table slots: latency bound, no MFMA.  Algorithmic traffic per block of
@@ -191,10 +191,28 @@ struct BitSink {
   u32 bytepos;                 // bytes written
   u32 gap_start;               // first position not yet emitted
   u32 rb, overflow;
-  // the block's bytes [lit_lo, lit_hi) as the chain wave keeps them in LDS (512-byte ring, position & 511): a literal run
-  // ends where a match starts -- in the window being parsed -- and is a few bytes long, so its bytes come from there
-  // instead of three dependent global loads per run (lit == nullptr: no such cache)
-  __attribute__((address_space(3))) const u8* lit; u32 lit_lo, lit_hi;
+  // the block's bytes [lit_lo, lit_hi) as the emitting wave keeps them in LDS (a ring of lit_mask + 1 bytes, position &
+  // lit_mask, filled 256 bytes at a time with the next 256 already requested): a literal run is a few bytes long and starts
+  // where the last match ended, so its bytes come from there instead of two dependent global loads per run
+  // (lit == nullptr: no such cache)
+  __attribute__((address_space(3))) u8* lit; u32 lit_lo, lit_hi, lit_mask;
+  u32 in_n;                    // bytes of `in` (the ring is filled up to the end of the block, four bytes per lane)
+  u32 pf, pf_at;               // the next 256 bytes' word of this lane, and where they start (~0: none requested)
+
+  __device__ __forceinline__ u32 chunk_word(u32 at, u32 lane) const {
+    return at + 4u * lane < in_n ? *(__attribute__((address_space(1))) const u32_u*)(in + at + 4u * lane) : 0u;   // (buffers are padded)
+  }
+  __device__ __forceinline__ void ensure(u32 from, u32 upto, u32 lane) {   // [from, upto) into the ring; upto - from <= 512
+    if (from < lit_lo || from > lit_hi + 512u) { lit_lo = lit_hi = from & ~255u; pf_at = 0xffffffffu; }
+    while (lit_hi < upto) {
+      const u32 w = pf_at == lit_hi ? pf : chunk_word(lit_hi, lane);
+      ((__attribute__((address_space(3))) u32*)lit)[((lit_hi & lit_mask) >> 2) + lane] = w;
+      lit_hi += 256u;
+      if (lit_hi - lit_lo > lit_mask + 1u) lit_lo = lit_hi - (lit_mask + 1u);
+      pf_at = lit_hi; pf = chunk_word(lit_hi, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 
   __device__ __forceinline__ void put(u64 v, u32 k, u32 lane) {           // k <= 56 bits, LSB first
     acc |= v << accbits;
@@ -213,15 +231,16 @@ struct BitSink {
     ++k;
     put(v, k, lane);
     const u32 sh = accbits;                  // 0..7 bits already in the byte the run starts in
-    if (lit && from >= lit_lo && from + len <= lit_hi) {
+    if (lit && len <= 512u) {
+      ensure(from, from + len, lane);
       for (u32 j = lane; j < len; j += 64) {
-        const u32 c = lit[(from + j) & 511u];
-        const u32 left = lit[(from + j - 1u) & 511u];                    // (unused for j == 0)
+        const u32 c = lit[(from + j) & lit_mask];
+        const u32 left = lit[(from + j - 1u) & lit_mask];                // (unused for j == 0)
         const u32 carry = j ? (sh ? left >> (8 - sh) : 0u) : (u32)acc;
         if (bytepos + j < out_cap) out[bytepos + j] = (u8)((c << sh) | carry); else overflow = 1;
       }
       bytepos += len;
-      acc = sh ? (u64)((u32)lit[(from + len - 1u) & 511u] >> (8 - sh)) : 0ull;
+      acc = sh ? (u64)((u32)lit[(from + len - 1u) & lit_mask] >> (8 - sh)) : 0ull;
       return;
     }
     for (u32 j = lane; j < len; j += 64) {
@@ -685,7 +704,7 @@ __global__ __launch_bounds__(256) void lz77_move_tokens_kernel(const LzJobDev* _
   }
 }
 
-#include "lz77_waves.inc"        // three waves per block on one table: lz77_spec3_kernel, lz77_direct3_kernel
+#include "lz77_waves.inc"        // three / four waves on one table: lz77_spec3_kernel, lz77_direct4_kernel
 
 #if defined(ZPQ_EMU_WALK_ONLY) && !defined(ZPQ_EMU_FULL)
 }  // namespace (host emulation, tests/cpp/walk_emu.cpp: the parse kernels up to here; nothing behind them is compiled.
@@ -890,8 +909,8 @@ static void launch_spec3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzSegDev
   ZPQ_LAUNCH(ctx, "lz77_spec_kernel", st, lz77_spec3_kernel<NB>, grid, dim3(192), d_segs, sl);
 }
 template <int NB>
-static void launch_direct3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
-  ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct3_kernel<NB>, grid, dim3(192), d_jobs, d_segs, jl);
+static void launch_direct4(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
+  ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct4_kernel<NB>, grid, dim3(256), d_jobs, d_segs, jl);
 }
 
 // Encodes jobs[lo..hi) in one batch (their tables fit the memory budget together).
@@ -1041,10 +1060,10 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
       dim3 gj((unsigned)rng[nb].jn);
       const u32* jl = d_lists + rng[nb].joff;
       switch (nb) {
-        case 0: launch_direct3<1>(ctx, st, gj, d_jobs, d_segs, jl); break;
-        case 1: launch_direct3<2>(ctx, st, gj, d_jobs, d_segs, jl); break;
-        case 2: launch_direct3<4>(ctx, st, gj, d_jobs, d_segs, jl); break;
-        default: launch_direct3<8>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        case 0: launch_direct4<1>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        case 1: launch_direct4<2>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        case 2: launch_direct4<4>(ctx, st, gj, d_jobs, d_segs, jl); break;
+        default: launch_direct4<8>(ctx, st, gj, d_jobs, d_segs, jl); break;
       }
       ZPQ_HIP(ctx, hipGetLastError());
     }
