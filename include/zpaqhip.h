@@ -218,9 +218,8 @@ size_t zpq_block_bound(size_t n, const char* filename, const char* comment);
 int zpq_compress_blocks_dev(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs);
 int zpq_compress_blocks(zpq_ctx* ctx, zpq_block_job* jobs, size_t njobs);
 
-/* One framed block (first segment) in, original bytes out; status ZPQ_ERR_CHECKSUM if the stored
- * SHA-1 does not match and verify != 0.  Blocks with context-model components or an unknown
- * PCOMP program give ZPQ_ERR_METHOD. */
+/* One framed block in, original bytes out; status ZPQ_ERR_CHECKSUM if a stored SHA-1 does not match
+ * and verify != 0. */
 typedef struct zpq_unblock_job {
   const uint8_t* in;      /* framed block bytes (device for *_dev, else host) */
   uint32_t n;
@@ -229,7 +228,13 @@ typedef struct zpq_unblock_job {
   uint32_t out_len;       /* result */
   uint32_t consumed;      /* result: bytes of `in` that made up the block */
   int32_t status;         /* result */
-  uint8_t sha1[20];       /* result: SHA-1 of the decoded bytes */
+  uint8_t sha1[20];       /* result: SHA-1 of the decoded bytes (of the first segment's, if the block has several) */
+  /* A block of several segments (a streaming archive with more than one file per block): the decoder's model and the
+   * post-processor carry on from segment to segment (Decompresser::decompress, ZSFX/libzpaq.cpp:2307-2337); out receives the
+   * segments' bytes back to back, every stored SHA-1 is compared with its own segment's when verify != 0. */
+  uint32_t nseg;          /* result: segments in the block */
+  uint32_t seg_cap;       /* entries of seg_out_end the caller provides (0: none) */
+  uint32_t* seg_out_end;  /* host, optional, result: bytes of out up to and including each segment */
 } zpq_unblock_job;
 int zpq_decompress_blocks(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs, int verify);
 /* The same with framed blocks and outputs resident in HBM (in/out are DEVICE pointers; every `in` readable for
@@ -266,6 +271,15 @@ typedef struct zpq_cm_job {
   uint32_t out_cap;
   uint32_t out_len;       /* result */
   int32_t status;         /* result */
+  /* Segments of one block (Compressor::startSegment ... endSegment more than once before endBlock; Decompresser::decompress
+   * after a second findFilename, ZSFX/libzpaq.cpp:2307-2337): the predictor and the HCOMP machine carry on from segment to
+   * segment, only the arithmetic coder starts afresh.  nseg <= 1: one segment, as above.  nseg > 1: d_in holds the segments'
+   * inputs back to back (encode: the bytes of each; decode: each one's coded stream with its end-of-segment symbol and four
+   * 0 bytes), seg_len[s] (host) = input bytes of segment s (their sum = n), and seg_out_end[s] (host, result) = output bytes
+   * produced up to and including segment s (the outputs lie back to back in d_out as well). */
+  uint32_t nseg;
+  const uint32_t* seg_len;
+  uint32_t* seg_out_end;
 } zpq_cm_job;
 int zpq_cm_encode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs);
 int zpq_cm_decode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs);
@@ -278,6 +292,13 @@ int zpq_cm_tables(uint16_t* squash, int16_t* stretch, int32_t* dt, int32_t* dt2k
  * once with 2^32-1 at the end (PostProcessor::write, ZSFX/libzpaq.cpp:2185-2226); OUT bytes -> d_out. */
 int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm,
                       const uint8_t* d_in, uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len);
+/* The same over the segments of one block: d_in holds the decoded streams of the segments back to back (the first without its
+ * post-processor preamble), seg_len[s] (host) bytes each; the machine keeps its state from segment to segment and runs once
+ * with 2^32-1 at the end of each (Decompresser::decompress initialises the post-processor for the first segment only,
+ * ZSFX/libzpaq.cpp:2312-2317); seg_out_end[s] (host, result) = output bytes up to and including segment s. */
+int zpq_pcomp_run_segments_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm,
+                               const uint8_t* d_in, uint32_t n, const uint32_t* seg_len, uint32_t nseg, uint8_t* d_out,
+                               uint32_t out_cap, uint32_t* seg_out_end, uint32_t* out_len);
 
 /* ---- E8E9 pre-processor (row a7) ------------------------------------------------------------- */
 /* libzpaq's e8e9() (ZSFX/libzpaq.cpp:6117-6126) over d_buf[0..n) in place: the x86 CALL/JMP filter

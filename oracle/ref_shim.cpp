@@ -193,6 +193,66 @@ long ref_cm_encode(const unsigned char* header, long hlen, const unsigned char* 
   });
 }
 
+// Several segments of ONE block (Compressor::startSegment ... endSegment more than once before endBlock): the real Predictor
+// carries on from segment to segment, the coder ends each with its end-of-segment symbol and the four 0 bytes (the byte
+// layout Decompresser::decompress / Decoder::decompress read back, ZSFX/libzpaq.cpp:2116-2137, 2307-2337).  data = the
+// segments' bytes back to back, seg_len[s] bytes each; out_end[s] = coded bytes up to and including segment s.
+long ref_cm_encode_segments(const unsigned char* header, long hlen, const unsigned char* data, const unsigned* seg_len, long nseg,
+                            unsigned char* out, long cap, unsigned* out_end) {
+  return guarded([&]() -> long {
+    MemReader hr(header, hlen);
+    libzpaq::ZPAQL z; z.read(&hr);
+    libzpaq::Predictor pr(z); pr.init();
+    std::vector<unsigned char> v;
+    libzpaq::U32 low = 1, high = 0xFFFFFFFFu;
+    auto encode = [&](int y, int p) {
+      libzpaq::U32 mid = low + libzpaq::U32((libzpaq::U64(high - low) * libzpaq::U32(p)) >> 16);
+      if (y) high = mid; else low = mid + 1;
+      while ((high ^ low) < 0x1000000u) {
+        v.push_back((unsigned char)(high >> 24));
+        high = high << 8 | 255; low = low << 8; low += (low == 0);
+      }
+    };
+    long at = 0;
+    for (long s = 0; s < nseg; ++s) {
+      for (long i = 0; i < (long)seg_len[s]; ++i) {
+        encode(0, 0);
+        int c = data[at + i];
+        for (int b = 7; b >= 0; --b) {
+          int p = pr.predict() * 2 + 1; int y = (c >> b) & 1;
+          encode(y, p); pr.update(y);
+        }
+      }
+      at += seg_len[s];
+      encode(1, 0);
+      v.push_back(0); v.push_back(0); v.push_back(0); v.push_back(0);
+      out_end[s] = (unsigned)v.size();
+    }
+    return emit(v, out, cap);
+  });
+}
+
+// The reverse with the real Decoder: coded = the segments' coded streams back to back; one Decoder (init once, as
+// Decompresser::decompress does for the first segment only) decodes segment after segment.
+long ref_cm_decode_segments(const unsigned char* header, long hlen, const unsigned char* coded, long n, long nseg,
+                            unsigned char* out, long cap, unsigned* out_end) {
+  return guarded([&]() -> long {
+    MemReader hr(header, hlen);
+    libzpaq::ZPAQL z; z.read(&hr);
+    libzpaq::Decoder dec(z);
+    MemReader in(coded, n);
+    dec.in = &in;
+    dec.init();
+    std::vector<unsigned char> v;
+    for (long s = 0; s < nseg; ++s) {
+      int c;
+      while ((c = dec.decompress()) >= 0) v.push_back((unsigned char)c);
+      out_end[s] = (unsigned)v.size();
+    }
+    return emit(v, out, cap);
+  });
+}
+
 // The model-independent lookup tables exactly as the reference Predictor holds them after init()
 // (ZSFX/libzpaq.cpp:1724-1742, sources :718-847 and :1264-1695): squash[4096], stretch[32768],
 // dt[1024], dt2k[256], and the bit-history next-state table ns[1024].

@@ -295,6 +295,33 @@ def ref_cm_decode(header, coded, cap):
     return bytes(out[:r])
 
 
+def ref_cm_encode_segments(header, segments):
+    """the real Predictor over several segments of one block -> the coded stream of each"""
+    data = b"".join(segments)
+    k = len(segments)
+    cap = len(data) + len(data) // 2 + 4096 + 16 * k
+    out = (C.c_ubyte * cap)()
+    lens = (C.c_uint * k)(*[len(x) for x in segments]); ends = (C.c_uint * k)()
+    r = _R.ref_cm_encode_segments(_buf(header), C.c_long(len(header)), _buf(data), lens, C.c_long(k), out, C.c_long(cap), ends)
+    if r < 0:
+        raise RuntimeError("ref_cm_encode_segments: %s" % _R.ref_last_error())
+    cuts = [0] + [int(e) for e in ends]
+    return [bytes(out[cuts[i]:cuts[i + 1]]) for i in range(k)]
+
+
+def ref_cm_decode_segments(header, coded_segments, cap):
+    """the real Decoder (initialised once) over the coded streams of a block's segments -> the bytes of each"""
+    coded = b"".join(coded_segments)
+    k = len(coded_segments)
+    out = (C.c_ubyte * max(1, cap))()
+    ends = (C.c_uint * k)()
+    r = _R.ref_cm_decode_segments(_buf(header), C.c_long(len(header)), _buf(coded), C.c_long(len(coded)), C.c_long(k), out, C.c_long(cap), ends)
+    if r < 0:
+        raise RuntimeError("ref_cm_decode_segments: %s" % _R.ref_last_error())
+    cuts = [0] + [int(e) for e in ends]
+    return [bytes(out[cuts[i]:cuts[i + 1]]) for i in range(k)]
+
+
 def ref_tables():
     sq = (C.c_uint16 * 4096)(); st = (C.c_int16 * 32768)(); dt = (C.c_int * 1024)(); d2 = (C.c_int * 256)(); ns = (C.c_ubyte * 1024)()
     if _R.ref_tables(sq, st, dt, d2, ns) != 0:

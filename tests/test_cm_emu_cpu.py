@@ -36,18 +36,27 @@ def build(L, header, path):
     subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-Wno-unused", "-Wno-unused-value", "-I" + os.path.join(ROOT, "tests", "cpp"), cpp, "-o", so])
     lib = C.CDLL(so)
     lib.cm_emu.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
-                           C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+                           C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
     return lib
 
 
-def code(lib, t, header, data, encode, cap):
+def code(lib, t, header, data, encode, cap, segments=None):
+    """segments: the block's segments (their bytes, or their coded streams) instead of `data` -> the output of each"""
+    if segments is not None:
+        data = b"".join(segments)
+    k = len(segments) if segments is not None else 0
     out = np.zeros(cap + 64, dtype=np.uint8)
     res = (C.c_uint32 * 2)()
     err = C.create_string_buffer(256)
+    lens = (C.c_uint32 * max(1, k))(*[len(x) for x in (segments or [])]); ends = (C.c_uint32 * max(1, k))()
     rc = lib.cm_emu(header, t["sq"].ctypes.data, t["st"].ctypes.data, t["dt"].ctypes.data, t["dt2"].ctypes.data, t["ns"].ctypes.data, data + bytes(64), len(data),
-                    out.ctypes.data, cap, 1 if encode else 0, res, err, 256)
+                    out.ctypes.data, cap, 1 if encode else 0, res, err, 256, lens, k, ends)
     assert rc == 0, err.value.decode()
     assert res[1] == 0, "status %d" % res[1]
+    if k > 1:
+        cuts = [0] + [int(e) for e in ends]
+        assert cuts[-1] == res[0], (cuts, res[0])
+        return [bytes(out[cuts[i]:cuts[i + 1]]) for i in range(k)]
     return bytes(out[: res[0]])
 
 
@@ -86,6 +95,17 @@ def _one_model(job):
                 return "%s: %d bytes code differently from the reference Predictor" % (name, len(x))
             if code(lib, t, h, got, False, len(x) + 64) != x:
                 return "%s: %d bytes do not decode back" % (name, len(x))
+        # several segments in one block: the model carries on from one to the next (the real Predictor / Decoder, kept
+        # across segments, are the measure), an empty segment in the middle and at the end
+        segs = [b"\0" + datagen.text_like(nbytes // 2, 3), datagen.text_like(nbytes // 3, 4), b"", datagen.binary_like(nbytes // 4, 5), b""]
+        want = orc.ref_cm_encode_segments(h, segs)
+        got = code(lib, t, h, None, True, sum(map(len, segs)) * 2 + 4096, segments=segs)
+        if got != want:
+            return "%s: a block of %d segments codes differently from the reference Predictor" % (name, len(segs))
+        if want[1] == orc.ref_cm_encode(h, segs[1]):
+            return "%s: the second segment does not depend on the first (test input too weak)" % name
+        if code(lib, t, h, None, False, sum(map(len, segs)) + 64, segments=want) != segs:
+            return "%s: a block of %d segments does not decode back" % (name, len(segs))
     except Exception as ex:          # noqa: BLE001 -- reported by the parent
         return "%s: %r" % (name, ex)
     return None

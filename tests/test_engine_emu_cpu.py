@@ -77,7 +77,7 @@ SLOW = [
     "test_gpu_cm_spec.py::test_builtin_models_of_startblock_level_equal_reference[3]",
 ]
 FILES = ["test_gpu_twins.py", "test_gpu_verify.py", "test_gpu_lzdec.py", "test_gpu_m3.py", "test_gpu_round2.py", "test_gpu_sa.py", "test_gpu_parity.py",
-         "test_gpu_cm_spec.py"]
+         "test_gpu_cm_spec.py", "test_gpu_segments.py"]
 
 
 def emu_env():

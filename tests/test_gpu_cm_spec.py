@@ -47,6 +47,33 @@ def test_specialised_kernel_equals_generic_kernel(eng, monkeypatch):
         assert [s for s, _ in spec] == [0] * len(inputs)
 
 
+def test_segments_of_one_block_continue_the_model(eng, monkeypatch):
+    """Compressor::startSegment ... endSegment more than once before endBlock / Decompresser::decompress after a second
+    findFilename (ZSFX/libzpaq.cpp:2307-2337): the predictor and the HCOMP machine carry on from segment to segment, only the
+    arithmetic coder starts afresh.  Measure: the real Predictor / Decoder kept across the segments (oracle/_ref).  Through
+    the specialised kernels, the generic wave kernel and the one-lane kernel; an empty segment in the middle and at the end."""
+    segs = [b"\0" + datagen.text_like(2500, 21), datagen.text_like(1800, 22), b"", datagen.binary_like(1500, 23), datagen.text_like(700, 21), b""]
+    for name in ("mid", "alltypes", "order1_cm"):
+        h = _hdr(name)
+        want = orc.ref_cm_encode_segments(h, segs)
+        assert want[1] != orc.ref_cm_encode(h, segs[1]), name                # the second segment does depend on the first
+        assert orc.ref_cm_decode_segments(h, want, sum(map(len, segs)) + 16) == segs
+        for env in ({}, {"ZPQ_CM_GENERIC": "1"}, {"ZPQ_CM_GENERIC": "1", "ZPQ_CM_ONE_LANE": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            st, got = eng.cm_code_segments(h, segs, sum(map(len, segs)) * 2 + 4096, encode=True)
+            assert st == 0 and got == want, (name, env)
+            st, back = eng.cm_code_segments(h, want, sum(map(len, segs)) + 16, encode=False)
+            assert st == 0 and back == segs, (name, env)
+            for k in env:
+                monkeypatch.delenv(k)
+    # a block of segments next to ordinary blocks in one call, and a coded segment that does not end where its length says
+    h = _hdr("mid")
+    want = orc.ref_cm_encode_segments(h, segs)
+    st, back = eng.cm_code_segments(h, [want[0] + want[1][:5], want[1][5:]] + want[2:], sum(map(len, segs)) + 16, encode=False)
+    assert st != 0
+
+
 def test_many_blocks_several_headers_one_call(eng):
     """The queue: more blocks than waves in a workgroup, three headers in one call, ragged lengths (incl. empty)."""
     hs = [_hdr("mid"), _hdr("alltypes"), _hdr("order1_cm")]

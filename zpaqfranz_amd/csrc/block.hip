@@ -459,8 +459,12 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
   hipStream_t st = ctx->stream;
   // kind: 0 stored+PASS, 2 stored + the known LZ77-L1 PCOMP (native decoder), 3 generic (context-model
   // coded and/or an arbitrary PCOMP: cm.hip decoder + ZPAQL interpreter)
+  // A block of several segments (ZSFX/libzpaq.cpp:2307-2337: the decoder and the post-processor are initialised for the
+  // first one only) is always kind 3: payload = the segments' coded streams (or stored bytes) back to back, seg_len = the
+  // bytes of each, seg_dec_end / seg_out_end = where each one's decoded stream / output ends, seg_sha = has_sha + SHA-1 each.
   struct Parsed { u32 kind; bool e8; u32 pay_off, pay_len; int has_sha; u8 sha[20]; u32 rb; std::vector<u8> payload;
-                  std::vector<u8> header; u32 ncomp, ph, pm; };
+                  std::vector<u8> header; u32 ncomp, ph, pm;
+                  u32 nseg; std::vector<u32> seg_len, seg_dec_end, seg_out_end; std::vector<u8> seg_sha; };
   std::vector<Parsed> ps(njobs);
   int first_err = ZPQ_OK;
   size_t in_total = 0, out_total = 0;
@@ -483,42 +487,57 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
     P.header.assign(a + p, a + p + 2 + hsize);
     const u32 pm = a[p + 5];
     p += 2 + hsize;
-    if (p >= n || a[p] != 1) { bad(ZPQ_ERR_FORMAT, "missing segment"); continue; }
-    ++p;
-    while (p < n && a[p]) ++p; ++p;
-    while (p < n && a[p]) ++p; ++p;
-    if (p >= n || a[p] != 0) { bad(ZPQ_ERR_FORMAT, "bad segment header"); continue; }
-    ++p;
-    bool ok = true;
-    if (P.ncomp) {
-      // arithmetic-coded data ends with four 0 bytes (Decoder::skip, ZSFX/libzpaq.cpp:2150-2160)
-      u32 q = p, curr = 0;
-      while (curr == 0 && q < n) curr = a[q++];
-      while (curr && q < n) curr = curr << 8 | a[q++];
-      if (curr) { bad(ZPQ_ERR_FORMAT, "unterminated coded data"); continue; }
-      // the coder's last byte (Encoder::flush) may itself be 0: then the scan stopped one short of the
-      // real terminator.  What follows the terminator is 253 or 254, never 0.
-      while (q < n && a[q] == 0) ++q;
-      P.payload.assign(a + p, a + q);
-      p = q;
-    } else
+    // every segment of the block: 1 filename 0 comment 0 0, the coded data, 253 sha1[20] | 254; then 255
+    P.nseg = 0;
+    const char* why = nullptr; int why_code = ZPQ_ERR_FORMAT;
     for (;;) {
-      if (p + 4 > n) { ok = false; break; }
-      const u32 k = (u32)a[p] << 24 | (u32)a[p + 1] << 16 | (u32)a[p + 2] << 8 | a[p + 3];
-      p += 4;
-      if (!k) break;
-      if (p + k > n) { ok = false; break; }
-      P.payload.insert(P.payload.end(), a + p, a + p + k);
-      p += k;
+      if (p >= n || a[p] != 1) { why = "missing segment"; break; }
+      ++p;
+      while (p < n && a[p]) ++p; ++p;
+      while (p < n && a[p]) ++p; ++p;
+      if (p >= n || a[p] != 0) { why = "bad segment header"; break; }
+      ++p;
+      const size_t before = P.payload.size();
+      if (P.ncomp) {
+        // arithmetic-coded data ends with four 0 bytes (Decoder::skip, ZSFX/libzpaq.cpp:2150-2160)
+        u32 q = p, curr = 0;
+        while (curr == 0 && q < n) curr = a[q++];
+        while (curr && q < n) curr = curr << 8 | a[q++];
+        if (curr) { why = "unterminated coded data"; break; }
+        // the coder's last byte (Encoder::flush) may itself be 0: then the scan stopped one short of the
+        // real terminator.  What follows the terminator is 253 or 254, never 0.
+        while (q < n && a[q] == 0) ++q;
+        P.payload.insert(P.payload.end(), a + p, a + q);
+        p = q;
+      } else {
+        bool ok = true;
+        for (;;) {
+          if (p + 4 > n) { ok = false; break; }
+          const u32 k = (u32)a[p] << 24 | (u32)a[p + 1] << 16 | (u32)a[p + 2] << 8 | a[p + 3];
+          p += 4;
+          if (!k) break;
+          if (p + k > n) { ok = false; break; }
+          P.payload.insert(P.payload.end(), a + p, a + p + k);
+          p += k;
+        }
+        if (!ok) { why = "truncated stored data"; break; }
+      }
+      if (P.nseg == 0 && P.payload.empty()) { why = "truncated stored data"; break; }      // the first segment holds at least the post-processor byte
+      P.seg_len.push_back((u32)(P.payload.size() - before));
+      P.seg_sha.resize(21 * (size_t)(P.nseg + 1), 0);
+      if (p < n && a[p] == 253 && p + 21 <= n) { P.seg_sha[21 * (size_t)P.nseg] = 1; memcpy(&P.seg_sha[21 * (size_t)P.nseg + 1], a + p + 1, 20); p += 21; }
+      else if (p < n && a[p] == 254) ++p;
+      else { why = "missing segment end"; break; }
+      ++P.nseg;
+      if (p < n && a[p] == 255) break;
+      if (P.nseg >= 65536) { why = "more than 65536 segments in a block"; why_code = ZPQ_ERR_METHOD; break; }
     }
-    if (!ok || P.payload.empty()) { bad(ZPQ_ERR_FORMAT, "truncated stored data"); continue; }
-    if (p < n && a[p] == 253 && p + 21 <= n) { P.has_sha = 1; memcpy(P.sha, a + p + 1, 20); p += 21; }
-    else if (p < n && a[p] == 254) { P.has_sha = 0; ++p; }
-    else { bad(ZPQ_ERR_FORMAT, "missing segment end"); continue; }
-    if (p >= n || a[p] != 255) { bad(ZPQ_ERR_METHOD, "multi-segment block"); continue; }
+    if (why) { bad(why_code, why); continue; }
+    P.has_sha = P.seg_sha[0]; memcpy(P.sha, &P.seg_sha[1], 20);
+    j.nseg = P.nseg;
     j.consumed = p + 1;
     P.rb = pm > 24 ? pm - 24 : 0; P.e8 = false;
-    if (P.ncomp) { P.kind = 3; P.pay_off = 0; }
+    if (P.ncomp || P.nseg > 1) { P.kind = 3; P.pay_off = 0; }
     else if (P.payload[0] == 0) { P.kind = 0; P.pay_off = 1; }
     else {
       if (P.payload.size() < 3) { bad(ZPQ_ERR_FORMAT, "truncated PCOMP"); continue; }
@@ -533,8 +552,7 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
   }
   u8* d_in = (u8*)zpq_scratch(ctx, 5, in_total + 64);
   u8* d_out = (u8*)zpq_scratch(ctx, 4, out_total + 64);
-  u8* d_aux = (u8*)zpq_scratch(ctx, 3, njobs * 32 + 256);
-  if (!d_in || !d_out || !d_aux) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+  if (!d_in || !d_out) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
   // 2. device: undo LZ77 (or pass), SHA-1 of the result
   std::vector<zpq_lz77_dec_job> dj;
   std::vector<size_t> dj_job;
@@ -600,12 +618,14 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
         memset(&c, 0, sizeof c);
         c.header = P.header.data(); c.header_len = (u32)P.header.size();
         c.d_in = d_coded; c.n = (u32)P.payload.size(); c.d_out = dec_at[i]; c.out_cap = (u32)dcap;
+        if (P.nseg > 1) { P.seg_dec_end.assign(P.nseg, 0); c.nseg = P.nseg; c.seg_len = P.seg_len.data(); c.seg_out_end = P.seg_dec_end.data(); }
         cj.push_back(c); cj_job.push_back(i);
       } else if (P.payload.size() > dcap) {
         jobs[i].status = ZPQ_ERR_CAPACITY; jobs[i].out_len = 0; if (!first_err) first_err = ZPQ_ERR_CAPACITY;
       } else {
         ZPQ_HIP(ctx, hipMemcpyAsync(dec_at[i], P.payload.data(), P.payload.size(), hipMemcpyHostToDevice, st));
         dec_len_of[i] = (u32)P.payload.size();
+        if (P.nseg > 1) { P.seg_dec_end.assign(P.nseg, 0); u32 e = 0; for (u32 q = 0; q < P.nseg; ++q) P.seg_dec_end[q] = (e += P.seg_len[q]); }
       }
     }
     if (!cj.empty()) {
@@ -629,7 +649,34 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
     u8 pre[3] = {0, 0, 0};
     ZPQ_HIP(ctx, hipMemcpyAsync(pre, d_dec, dec_len < 3 ? dec_len : 3, hipMemcpyDeviceToHost, st));
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
-    if (pre[0] == 0) {                                  // PASS
+    if (P.nseg > 1) {
+      // several segments: PASS copies each one's decoded stream; a program runs over all of them on ONE machine, with the
+      // end-of-segment input after each (the programs compressBlock writes would also do segment by segment on the native
+      // decoders, but what carries over is for the program to say: the ZPAQL machine is the definition)
+      if (P.seg_dec_end.size() != P.nseg || P.seg_dec_end[P.nseg - 1] != dec_len) { fail_job(ZPQ_ERR_FORMAT); continue; }
+      P.seg_out_end.assign(P.nseg, 0);
+      if (pre[0] == 0) {
+        const u32 len = dec_len - 1;
+        if (len > jobs[i].out_cap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
+        if (len) ZPQ_HIP(ctx, hipMemcpyAsync(outp[i], d_dec + 1, len, hipMemcpyDeviceToDevice, st));
+        for (u32 q = 0; q < P.nseg; ++q) P.seg_out_end[q] = P.seg_dec_end[q] - 1;
+        jobs[i].out_len = len;
+      } else if (pre[0] == 1 && dec_len >= 3) {
+        const u32 psize = pre[1] | (u32)pre[2] << 8;
+        if (psize < 1 || 3 + psize > P.seg_dec_end[0]) { fail_job(ZPQ_ERR_FORMAT); continue; }      // (the program lies in the first segment)
+        std::vector<u8> pc(psize);
+        ZPQ_HIP(ctx, hipMemcpyAsync(pc.data(), d_dec + 3, psize, hipMemcpyDeviceToHost, st));
+        ZPQ_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<u32> lens(P.nseg);
+        for (u32 q = 0; q < P.nseg; ++q) lens[q] = P.seg_dec_end[q] - (q ? P.seg_dec_end[q - 1] : 3 + psize);
+        u32 olen = 0;
+        int rc = zpq_pcomp_run_segments_dev(ctx, pc.data(), psize, P.ph, P.pm, d_dec + 3 + psize, dec_len - 3 - psize, lens.data(), P.nseg, outp[i],
+                                            jobs[i].out_cap, P.seg_out_end.data(), &olen);
+        if (rc) { fail_job(rc); continue; }
+        jobs[i].out_len = olen;
+      } else { fail_job(ZPQ_ERR_FORMAT); continue; }
+      for (u32 q = 0; q < P.nseg && q < jobs[i].seg_cap; ++q) if (jobs[i].seg_out_end) jobs[i].seg_out_end[q] = P.seg_out_end[q];
+    } else if (pre[0] == 0) {                           // PASS
       const u32 len = dec_len - 1;
       if (len > jobs[i].out_cap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
       if (len) ZPQ_HIP(ctx, hipMemcpyAsync(outp[i], d_dec + 1, len, hipMemcpyDeviceToDevice, st));
@@ -702,27 +749,41 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
       }
     } else { fail_job(ZPQ_ERR_FORMAT); continue; }
   }
-  std::vector<u64> so; std::vector<u32> sl; std::vector<size_t> sj;
   for (size_t i = 0; i < njobs; ++i)
-    if (jobs[i].status == ZPQ_OK) { so.push_back((u64)(uintptr_t)outp[i]); sl.push_back(jobs[i].out_len); sj.push_back(i); }
+    if (jobs[i].status == ZPQ_OK && ps[i].nseg == 1 && jobs[i].seg_out_end && jobs[i].seg_cap) jobs[i].seg_out_end[0] = jobs[i].out_len;
+  // SHA-1 of every segment's bytes (one wave per chain), compared with the stored one of that segment
+  std::vector<u64> so; std::vector<u32> sl; std::vector<size_t> sj; std::vector<u32> ss;
+  for (size_t i = 0; i < njobs; ++i)
+    if (jobs[i].status == ZPQ_OK) {
+      const Parsed& P = ps[i];
+      if (P.nseg > 1)
+        for (u32 q = 0; q < P.nseg; ++q) {
+          const u32 from = q ? P.seg_out_end[q - 1] : 0;
+          so.push_back((u64)(uintptr_t)(outp[i] + from)); sl.push_back(P.seg_out_end[q] - from); sj.push_back(i); ss.push_back(q);
+        }
+      else { so.push_back((u64)(uintptr_t)outp[i]); sl.push_back(jobs[i].out_len); sj.push_back(i); ss.push_back(0); }
+    }
   if (!sj.empty()) {
-    u64* d_so = (u64*)d_aux; u32* d_sl = (u32*)(d_so + njobs); u8* d_dg = (u8*)(d_sl + njobs);
+    u8* d_sha = (u8*)zpq_scratch(ctx, 3, sj.size() * 32 + 256);
+    if (!d_sha) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "decode staging");
+    u64* d_so = (u64*)d_sha; u32* d_sl = (u32*)(d_so + sj.size()); u8* d_dg = (u8*)(d_sl + sj.size());
     ZPQ_HIP(ctx, hipMemcpyAsync(d_so, so.data(), so.size() * 8, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipMemcpyAsync(d_sl, sl.data(), sl.size() * 4, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
-    int rc = zpq_sha1_chains_on(ctx, st, (const u8*)0, d_so, d_sl, sj.size(), d_dg);   // one wave per block checksum
+    int rc = zpq_sha1_chains_on(ctx, st, (const u8*)0, d_so, d_sl, sj.size(), d_dg);   // one wave per checksum
     if (rc) return rc;
     std::vector<u8> dg(sj.size() * 20);
     ZPQ_HIP(ctx, hipMemcpyAsync(dg.data(), d_dg, dg.size(), hipMemcpyDeviceToHost, st));
     for (size_t k = 0; k < sj.size(); ++k) {
       zpq_unblock_job& j = jobs[sj[k]];
-      if (j.out_len) ZPQ_HIP(ctx, hipMemcpyAsync(j.out, outp[sj[k]], j.out_len, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+      if (ss[k] == 0 && j.out_len) ZPQ_HIP(ctx, hipMemcpyAsync(j.out, outp[sj[k]], j.out_len, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     }
     ZPQ_HIP(ctx, hipStreamSynchronize(st));
     for (size_t k = 0; k < sj.size(); ++k) {
       zpq_unblock_job& j = jobs[sj[k]];
-      memcpy(j.sha1, &dg[20 * k], 20);
-      if (verify && ps[sj[k]].has_sha && memcmp(j.sha1, ps[sj[k]].sha, 20) != 0) { j.status = ZPQ_ERR_CHECKSUM; if (!first_err) first_err = ZPQ_ERR_CHECKSUM; }
+      const Parsed& P = ps[sj[k]];
+      if (ss[k] == 0) memcpy(j.sha1, &dg[20 * k], 20);
+      if (verify && P.seg_sha[21 * (size_t)ss[k]] && memcmp(&dg[20 * k], &P.seg_sha[21 * (size_t)ss[k] + 1], 20) != 0) { j.status = ZPQ_ERR_CHECKSUM; if (!first_err) first_err = ZPQ_ERR_CHECKSUM; }
     }
   }
   return first_err;

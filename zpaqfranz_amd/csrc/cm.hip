@@ -124,6 +124,7 @@ struct CmJobDev {
   const u8* in; u32 in_len;
   u8* out; u32 out_cap;
   u32* result;                    // [0]=bytes produced, [1]=status
+  u32* seg; u32 nseg;             // segments of the block (null: one): u32[nseg] input bytes each, then u32[nseg] (result) output end of each
 };
 
 __device__ __forceinline__ int clamp2k(int x) { return x < -2048 ? -2048 : x > 2047 ? 2047 : x; }
@@ -394,23 +395,30 @@ __global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode)
       if (y) high = mid; else low = mid + 1;
       while ((high ^ low) < 0x1000000u) { put(high >> 24); high = high << 8 | 255; low <<= 8; low += (low == 0); }
     };
-    for (u32 i = 0; i < J.in_len && !J.vm.err; ++i) {
-      const u32 c = J.in[i];
-      enc(0, 0);
-      for (int b = 7; b >= 0; --b) {
-        const u32 p = (u32)pr.predict() * 2 + 1;
-        const int y = (c >> b) & 1;
-        enc(y, p);
-        pr.update(y);
+    // a block's segments one after the other: the model carries on, the coder ends each with its end-of-segment symbol
+    const u32 nseg = J.seg ? J.nseg : 1u;
+    u32 i = 0;
+    for (u32 s = 0; s < nseg && !J.vm.err; ++s) {
+      const u32 send = J.seg ? i + J.seg[s] : J.in_len;
+      for (; i < send && i < J.in_len && !J.vm.err; ++i) {
+        const u32 c = J.in[i];
+        enc(0, 0);
+        for (int b = 7; b >= 0; --b) {
+          const u32 p = (u32)pr.predict() * 2 + 1;
+          const int y = (c >> b) & 1;
+          enc(y, p);
+          pr.update(y);
+        }
       }
+      enc(1, 0);
+      put(0); put(0); put(0); put(0);
+      if (J.seg) J.seg[nseg + s] = op;
     }
-    enc(1, 0);
-    put(0); put(0); put(0); put(0);
     if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
   } else {
-    u32 ip = 0, curr = 0;
+    u32 ip = 0, curr = 0, send = J.in_len;
     bool bad = false;
-    auto get = [&]() -> u32 { if (ip < J.in_len) return J.in[ip++]; bad = true; return 0; };
+    auto get = [&]() -> u32 { if (ip < send) return J.in[ip++]; bad = true; return 0; };
     auto dec = [&](u32 p) -> int {               // Decoder::decode, ZSFX/libzpaq.cpp:2096-2114
       if (curr < low || curr > high) { bad = true; return 1; }
       const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
@@ -419,17 +427,24 @@ __global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode)
       while ((high ^ low) < 0x1000000u) { high = high << 8 | 255; low <<= 8; low += (low == 0); curr = curr << 8 | get(); }
       return y;
     };
-    for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
-    while (!bad && !J.vm.err) {
-      if (dec(0)) { if (curr != 0) bad = true; break; }
-      u32 c = 1;
-      while (c < 256) {
-        const u32 p = (u32)pr.predict() * 2 + 1;
-        c += c + (u32)dec(p);
-        pr.update((int)(c & 1));
+    const u32 nseg = J.seg ? J.nseg : 1u;
+    for (u32 s = 0; s < nseg; ++s) {             // (Decoder::decompress: `curr == 0` starts a segment, ZSFX/libzpaq.cpp:2122-2126)
+      if (J.seg) { send = ip + J.seg[s]; if (send > J.in_len) send = J.in_len; }
+      curr = 0;
+      for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
+      while (!bad && !J.vm.err) {
+        if (dec(0)) { if (curr != 0) bad = true; break; }
+        u32 c = 1;
+        while (c < 256) {
+          const u32 p = (u32)pr.predict() * 2 + 1;
+          c += c + (u32)dec(p);
+          pr.update((int)(c & 1));
+        }
+        if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
+        J.out[op++] = (u8)(c - 256);
       }
-      if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
-      J.out[op++] = (u8)(c - 256);
+      if (bad || J.vm.err || status != ZPQ_OK) break;
+      if (J.seg) { if (ip != send) { bad = true; break; } J.seg[nseg + s] = op; }     // a segment uses exactly its own bytes
     }
     if (bad) status = ZPQ_ERR_FORMAT;
   }
@@ -833,23 +848,29 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
       if (y) high = mid; else low = mid + 1;
       while ((high ^ low) < 0x1000000u) { put(high >> 24); high = high << 8 | 255; low <<= 8; low += (low == 0); }
     };
-    for (u32 i = 0; i < J.in_len && !pr.vmerr; ++i) {
-      const u32 c = J.in[i];
-      enc(0, 0);
-      for (int b = 7; b >= 0; --b) {
-        const u32 p = (u32)pr.predict() * 2 + 1;
-        const int y = (int)((c >> b) & 1);
-        enc(y, p);
-        pr.update(y, z);
+    const u32 nseg = J.seg ? J.nseg : 1u;         // segments: as in cm_code_kernel
+    u32 i = 0;
+    for (u32 s = 0; s < nseg && !pr.vmerr; ++s) {
+      const u32 send = J.seg ? i + J.seg[s] : J.in_len;
+      for (; i < send && i < J.in_len && !pr.vmerr; ++i) {
+        const u32 c = J.in[i];
+        enc(0, 0);
+        for (int b = 7; b >= 0; --b) {
+          const u32 p = (u32)pr.predict() * 2 + 1;
+          const int y = (int)((c >> b) & 1);
+          enc(y, p);
+          pr.update(y, z);
+        }
       }
+      enc(1, 0);
+      put(0); put(0); put(0); put(0);
+      if (J.seg && lane == 0) J.seg[nseg + s] = op;
     }
-    enc(1, 0);
-    put(0); put(0); put(0); put(0);
     if (op > J.out_cap) status = ZPQ_ERR_CAPACITY;
   } else {
-    u32 ip = 0, curr = 0;
+    u32 ip = 0, curr = 0, send = J.in_len;
     bool bad = false;
-    auto get = [&]() -> u32 { if (ip < J.in_len) return J.in[ip++]; bad = true; return 0; };
+    auto get = [&]() -> u32 { if (ip < send) return J.in[ip++]; bad = true; return 0; };
     auto dec = [&](u32 p) -> int {               // Decoder::decode, ZSFX/libzpaq.cpp:2096-2114
       if (curr < low || curr > high) { bad = true; return 1; }
       const u32 mid = low + (u32)(((u64)(high - low) * p) >> 16);
@@ -858,18 +879,25 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
       while ((high ^ low) < 0x1000000u) { high = high << 8 | 255; low <<= 8; low += (low == 0); curr = curr << 8 | get(); }
       return y;
     };
-    for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
-    while (!bad && !pr.vmerr) {
-      if (dec(0)) { if (curr != 0) bad = true; break; }
-      u32 c = 1;
-      while (c < 256) {
-        const u32 p = (u32)pr.predict() * 2 + 1;
-        c += c + (u32)dec(p);
-        pr.update((int)(c & 1), z);
+    const u32 nseg = J.seg ? J.nseg : 1u;         // segments: as in cm_code_kernel
+    for (u32 s = 0; s < nseg; ++s) {
+      if (J.seg) { send = ip + J.seg[s]; if (send > J.in_len) send = J.in_len; }
+      curr = 0;
+      for (int i = 0; i < 4; ++i) curr = curr << 8 | get();
+      while (!bad && !pr.vmerr) {
+        if (dec(0)) { if (curr != 0) bad = true; break; }
+        u32 c = 1;
+        while (c < 256) {
+          const u32 p = (u32)pr.predict() * 2 + 1;
+          c += c + (u32)dec(p);
+          pr.update((int)(c & 1), z);
+        }
+        if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
+        if (lane == 0) J.out[op] = (u8)(c - 256);
+        ++op;
       }
-      if (op >= J.out_cap) { status = ZPQ_ERR_CAPACITY; break; }   // caller asked for a prefix only
-      if (lane == 0) J.out[op] = (u8)(c - 256);
-      ++op;
+      if (bad || pr.vmerr || status != ZPQ_OK) break;
+      if (J.seg) { if (ip != send) { bad = true; break; } if (lane == 0) J.seg[nseg + s] = op; }
     }
     if (bad) status = ZPQ_ERR_FORMAT;
   }
@@ -911,11 +939,19 @@ __global__ __launch_bounds__(256) void cm_init_kernel(const InitJob* jobs) {
 
 // Generic post-processor: runs a PCOMP program once per decoded byte and once with 2^32-1 at the end
 // (PostProcessor::write state 5, ZSFX/libzpaq.cpp:2221-2224).
-__global__ __launch_bounds__(64) void pcomp_run_kernel(Vm* vms, const u8* in, u32 n, u32* result) {
+// seg (null: one segment of n bytes): u32[nseg] input bytes per segment of the block, then u32[nseg] (result) the output end
+// of each: the machine keeps its state from segment to segment (Decompresser::decompress initialises it for the first only).
+__global__ __launch_bounds__(64) void pcomp_run_kernel(Vm* vms, const u8* in, u32 n, u32* result, u32* seg, u32 nseg) {
   if (threadIdx.x != 0) return;
   Vm& z = vms[0];
-  for (u32 i = 0; i < n && !z.err; ++i) vm_run(z, in[i]);
-  if (!z.err) vm_run(z, 0xffffffffu);
+  const u32 ns = seg ? nseg : 1u;
+  u32 i = 0;
+  for (u32 s = 0; s < ns && !z.err; ++s) {
+    const u32 send = seg ? i + seg[s] : n;
+    for (; i < send && i < n && !z.err; ++i) vm_run(z, in[i]);
+    if (!z.err) vm_run(z, 0xffffffffu);
+    if (seg) seg[nseg + s] = z.out_len;
+  }
   result[0] = z.out_len;
   result[1] = z.err ? (u32)ZPQ_ERR_FORMAT : (z.out_len > z.out_cap ? (u32)ZPQ_ERR_CAPACITY : 0u);
 }
@@ -969,7 +1005,19 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   size_t ncomp_all = 0;
   for (size_t k = 0; k < nb; ++k) ncomp_all += ph[idx[k]].n;
   const bool want_prof = getenv("ZPQ_CM_PROF") != nullptr;
-  size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4) + al256(nb * 64);
+  size_t nseg_all = 0;                                // segment tables of the blocks that have more than one
+  for (size_t k = 0; k < nb; ++k) {
+    const zpq_cm_job& j = jobs[idx[k]];
+    if (j.nseg > 1) {
+      if (!j.seg_len || !j.seg_out_end) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: %u segments without seg_len / seg_out_end", idx[k], j.nseg);
+      u64 sum = 0;
+      for (u32 s = 0; s < j.nseg; ++s) sum += j.seg_len[s];
+      if (sum != j.n) return zpq_fail(ctx, ZPQ_ERR_ARG, "job %zu: the segments' lengths do not add up to n", idx[k]);
+      nseg_all += j.nseg;
+    }
+  }
+  size_t meta = al256(nb * sizeof(CmJobDev)) + al256(nb * sizeof(zpq_spec_job)) + al256(nb * 8) + al256(ncomp_all * sizeof(InitJob)) + al256(nb * 4) + al256(nb * 64) +
+                al256(nseg_all * 8);
   size_t big = 0;
   for (size_t k = 0; k < nb; ++k) {
     size_t b = 0;
@@ -988,7 +1036,9 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   auto take_meta = [&](size_t x) { const size_t r = mo; mo += al256(x); return r; };
   auto take_big = [&](size_t x) { u8* r = bp; bp += al256(x); return r; };
   const size_t o_jobs = take_meta(nb * sizeof(CmJobDev)), o_sjobs = take_meta(nb * sizeof(zpq_spec_job)), o_res = take_meta(nb * 8),
-               o_init = take_meta(ncomp_all * sizeof(InitJob)), o_cnt = take_meta(nb * 4), o_prof = take_meta(nb * 64);
+               o_init = take_meta(ncomp_all * sizeof(InitJob)), o_cnt = take_meta(nb * 4), o_prof = take_meta(nb * 64), o_seg = take_meta(nseg_all * 8);
+  size_t seg_at = 0;                                  // u32 words into the segment region
+  std::vector<size_t> seg_of(nb, 0);
   CmJobDev* hj = (CmJobDev*)(hm.data() + o_jobs);
   zpq_spec_job* hs = (zpq_spec_job*)(hm.data() + o_sjobs);
   InitJob* hinit = (InitJob*)(hm.data() + o_init);
@@ -1082,6 +1132,15 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
     S.R = (u64)(uintptr_t)J.vm.R; S.in = (u64)(uintptr_t)J.in; S.out = (u64)(uintptr_t)J.out; S.result = (u64)(uintptr_t)J.result;
     S.in_len = J.in_len; S.out_cap = J.out_cap;
     S.prof = want_prof ? (u64)(uintptr_t)(arena + o_prof + 64 * k) : 0;
+    J.seg = nullptr; J.nseg = 0; S.seg = 0; S.nseg = 0;
+    if (jobs[i].nseg > 1) {
+      u32* hseg = (u32*)(hm.data() + o_seg) + seg_at;
+      for (u32 s = 0; s < jobs[i].nseg; ++s) hseg[s] = jobs[i].seg_len[s];
+      J.seg = (u32*)(arena + o_seg) + seg_at; J.nseg = jobs[i].nseg;
+      S.seg = (u64)(uintptr_t)J.seg; S.nseg = J.nseg;
+      seg_of[k] = seg_at;
+      seg_at += 2 * (size_t)jobs[i].nseg;
+    }
   }
   // which kernel codes which block: blocks sharing a header share one specialised kernel; the rest take the generic ones
   std::vector<int> group(nb, -1);
@@ -1183,9 +1242,14 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
     fprintf(stderr, "[cm stats] cumulative cycles: find=%llu loads=%llu leaves=%llu dependents=%llu update=%llu vm=%llu total=%llu bytes=%llu\n",
             c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
   }
+  std::vector<u32> segs(2 * nseg_all);
+  if (nseg_all) ZPQ_HIP(ctx, hipMemcpy(segs.data(), arena + o_seg, nseg_all * 8, hipMemcpyDeviceToHost));
   for (size_t k = 0; k < nb; ++k) {
-    jobs[idx[k]].out_len = res[2 * k];
-    jobs[idx[k]].status = (int32_t)res[2 * k + 1];
+    zpq_cm_job& j = jobs[idx[k]];
+    j.out_len = res[2 * k];
+    j.status = (int32_t)res[2 * k + 1];
+    if (j.nseg > 1)                                   // (a block that stopped early leaves the later entries at the bytes produced)
+      for (u32 s = 0; s < j.nseg; ++s) { const u32 e = segs[seg_of[k] + j.nseg + s]; j.seg_out_end[s] = j.status == ZPQ_OK || e ? e : j.out_len; }
   }
   return ZPQ_OK;
 }
@@ -1271,11 +1335,23 @@ int zpq_cm_decode_dev(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs) { return run
 
 int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm, const uint8_t* d_in,
                       uint32_t n, uint8_t* d_out, uint32_t out_cap, uint32_t* out_len) {
+  return zpq_pcomp_run_segments_dev(ctx, pcomp, psize, ph, pm, d_in, n, nullptr, 0, d_out, out_cap, nullptr, out_len);
+}
+
+int zpq_pcomp_run_segments_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32_t ph, uint32_t pm, const uint8_t* d_in,
+                               uint32_t n, const uint32_t* seg_len, uint32_t nseg, uint8_t* d_out, uint32_t out_cap,
+                               uint32_t* seg_out_end, uint32_t* out_len) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (ph > 24 || pm > 30) return zpq_fail(ctx, ZPQ_ERR_METHOD, "PCOMP memory 2^%u/2^%u too large", ph, pm);
+  if (nseg > 1) {
+    if (!seg_len || !seg_out_end) return zpq_fail(ctx, ZPQ_ERR_ARG, "%u segments without seg_len / seg_out_end", nseg);
+    u64 sum = 0;
+    for (u32 s = 0; s < nseg; ++s) sum += seg_len[s];
+    if (sum != n) return zpq_fail(ctx, ZPQ_ERR_ARG, "the segments' lengths do not add up to n");
+  } else nseg = 0;
   hipStream_t st = ctx->stream;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t bytes = al(sizeof(Vm)) + al(8) + al(1024) + al((size_t)4 << ph) + al((size_t)1 << pm) + al(psize + 8);
+  const size_t bytes = al(sizeof(Vm)) + al(8) + al(1024) + al((size_t)4 << ph) + al((size_t)1 << pm) + al(psize + 8) + al(8 * (size_t)nseg);
   u8* arena = (u8*)zpq_scratch(ctx, 0, bytes + 1024);
   if (!arena) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "pcomp memory");
   ZPQ_HIP(ctx, hipMemsetAsync(arena, 0, bytes, st));
@@ -1289,20 +1365,23 @@ int zpq_pcomp_run_dev(zpq_ctx* ctx, const uint8_t* pcomp, uint32_t psize, uint32
   v.H = (u32*)take((size_t)4 << ph); v.hmask = (1u << ph) - 1;
   v.M = take((size_t)1 << pm); v.mmask = (1u << pm) - 1;
   u8* prog = take(psize + 8);
+  u32* d_seg = nseg ? (u32*)take(8 * (size_t)nseg) : nullptr;
   v.prog = prog; v.plen = psize;
   v.out = d_out; v.out_cap = out_cap;
   ZPQ_HIP(ctx, hipMemcpyAsync(prog, pcomp, psize, hipMemcpyHostToDevice, st));
+  if (nseg) ZPQ_HIP(ctx, hipMemcpyAsync(d_seg, seg_len, 4 * (size_t)nseg, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipMemcpyAsync(d_vm, &v, sizeof v, hipMemcpyHostToDevice, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   // the program translated to machine code (cm_jit.hip); the interpreter only when that is not to be had
   // (the closing 0 of the stored program is not part of it)
   const u32 plen = psize && pcomp[psize - 1] == 0 ? psize - 1 : psize;
-  if (getenv("ZPQ_CM_GENERIC") || zpq_pcomp_spec_run(ctx, st, pcomp, plen, ph, pm, d_in, n, d_out, out_cap, v.H, v.M, v.R, d_res) != ZPQ_OK) {
-    ZPQ_LAUNCH(ctx, "pcomp_run_kernel", st, pcomp_run_kernel, dim3(1), dim3(64), d_vm, d_in, n, d_res);
+  if (getenv("ZPQ_CM_GENERIC") || zpq_pcomp_spec_run(ctx, st, pcomp, plen, ph, pm, d_in, n, d_out, out_cap, v.H, v.M, v.R, d_res, d_seg, nseg) != ZPQ_OK) {
+    ZPQ_LAUNCH(ctx, "pcomp_run_kernel", st, pcomp_run_kernel, dim3(1), dim3(64), d_vm, d_in, n, d_res, d_seg, nseg);
     ZPQ_HIP(ctx, hipGetLastError());
   }
   u32 res[2];
   ZPQ_HIP(ctx, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, st));
+  if (nseg) ZPQ_HIP(ctx, hipMemcpyAsync(seg_out_end, d_seg + nseg, 4 * (size_t)nseg, hipMemcpyDeviceToHost, st));
   ZPQ_HIP(ctx, hipStreamSynchronize(st));
   *out_len = res[0];
   if (res[1]) return zpq_fail(ctx, (int)res[1], "PCOMP run failed");

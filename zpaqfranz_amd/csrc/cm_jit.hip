@@ -447,7 +447,9 @@ typedef g_u32* zh_ptr;
 #define ZDEV __device__ inline __attribute__((always_inline))
 struct ZVm { u32 a, b, c, d, f, err, g, lim; };
 //@@PCOMP@@
-extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n, u8* out, u32 cap, u32* H, u8* M, u32* R, u32* result) {
+// seg (null: one segment of n bytes): u32[nseg] input bytes per segment of the block, then u32[nseg] (result) the output end
+// of each -- the machine keeps its state from segment to segment and sees 2^32-1 at the end of each (PostProcessor::write)
+extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n, u8* out, u32 cap, u32* H, u8* M, u32* R, u32* result, u32* seg, u32 nseg) {
   if (threadIdx.x) return;
   // budget of backward jumps for the WHOLE segment (a program that spins is a format error, not a hung GPU): what the
   // post-processors in use need is a small multiple of the bytes they read and write
@@ -455,8 +457,14 @@ extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n,
   ZVm z = {0, 0, 0, 0, 0, 0, 0, lim > 0x7fffffffull ? 0x7fffffffu : (u32)lim};
   u32 op = 0;
   const g_u8* gin = (const g_u8*)in;
-  for (u32 i = 0; i < n && !z.err; ++i) z_pcomp(gin[i], z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
-  if (!z.err) z_pcomp(0xffffffffu, z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
+  const u32 ns = seg ? nseg : 1u;
+  u32 i = 0;
+  for (u32 s = 0; s < ns && !z.err; ++s) {
+    const u32 send = seg ? i + seg[s] : n;
+    for (; i < send && i < n && !z.err; ++i) z_pcomp(gin[i], z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
+    if (!z.err) z_pcomp(0xffffffffu, z, (g_u8*)M, (g_u32*)R, (zh_ptr)H, (g_u8*)out, cap, op);
+    if (seg) seg[nseg + s] = op;
+  }
   result[0] = op;
   result[1] = z.err ? (u32)-6 : (op > cap ? (u32)-4 : 0u);
 }
@@ -469,7 +477,7 @@ size_t modules_loaded() { return g_mods.size() + g_pmods.size(); }       // unde
 
 // Runs pcomp[0..psize) over d_in[0..n) on the device; H, M, R are zeroed device arrays of 2^ph words, 2^pm bytes, 256 words.
 int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize, u32 ph, u32 pm, const u8* d_in, u32 n, u8* d_out, u32 out_cap,
-                       u32* d_H, u8* d_M, u32* d_R, u32* d_result) {
+                       u32* d_H, u8* d_M, u32* d_R, u32* d_result, u32* d_seg, u32 nseg) {
   std::vector<u8> code(pcomp, pcomp + psize);
   std::string src = "#define ZHMASK " + itos((1u << ph) - 1) + "u\n#define ZMMASK " + itos((1u << pm) - 1) + "u\n#define ZGUARD z.lim\n";
   std::string body = kPcompSrc;
@@ -495,7 +503,7 @@ int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize,
     auto ins = g_pmods.insert({{ctx->device, src}, pmod});
     if (!ins.second) { (void)hipModuleUnload(pmod.mod); pmod = ins.first->second; }
   }
-  void* args[] = {(void*)&d_in, (void*)&n, (void*)&d_out, (void*)&out_cap, (void*)&d_H, (void*)&d_M, (void*)&d_R, (void*)&d_result};
+  void* args[] = {(void*)&d_in, (void*)&n, (void*)&d_out, (void*)&out_cap, (void*)&d_H, (void*)&d_M, (void*)&d_R, (void*)&d_result, (void*)&d_seg, (void*)&nseg};
   ZpqProfScope prof(ctx, "pcomp_spec", st);
   ZPQ_HIP(ctx, hipModuleLaunchKernel(pmod.fn, 1, 1, 1, 64, 1, 1, 0, st, args, nullptr));
   return ZPQ_OK;

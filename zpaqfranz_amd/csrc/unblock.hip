@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void unframe_walk_kernel(const WalkJob* __restr
   else if (p < n && a[p] == 254) { I.has_sha = 0; ++p; }
   else return done(ZPQ_ERR_FORMAT);
   if (p >= n) return done(ZPQ_ERR_FORMAT);
-  if (a[p] != 255) return done(ZPQ_ERR_METHOD);      // another segment follows
+  if (a[p] != 255) return done(1);                   // another segment follows: host path (its framing is parsed there)
   I.consumed = p + 1;
   done(ZPQ_OK);
 }
@@ -286,7 +286,7 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
     shaoff[i] = (u64)(uintptr_t)jobs[i].out;
     if (I.status == 1) { host_path.push_back(i); continue; }
     if (I.status != ZPQ_OK) {
-      jobs[i].status = zpq_fail(ctx, I.status, "block %zu: %s", i, I.status == ZPQ_ERR_METHOD ? "more than one segment" : zpq_strerror(I.status));
+      jobs[i].status = zpq_fail(ctx, I.status, "block %zu: %s", i, zpq_strerror(I.status));
       if (!first_err) first_err = jobs[i].status;
       continue;
     }
@@ -353,6 +353,8 @@ extern "C" int zpq_decompress_blocks_dev(zpq_ctx* ctx, zpq_unblock_job* jobs, si
   for (size_t i = 0; i < njobs; ++i) {
     if (fj[i].kind == 0xffffffffu) continue;
     jobs[i].out_len = fo[i].out_len; jobs[i].status = fo[i].status; memcpy(jobs[i].sha1, fo[i].sha1, 20);
+    jobs[i].nseg = 1;
+    if (jobs[i].seg_out_end && jobs[i].seg_cap) jobs[i].seg_out_end[0] = jobs[i].out_len;
     if (jobs[i].status && !first_err) first_err = jobs[i].status;
   }
   // 4. the rest: host-parsed (still GPU-decoded), one copy of the block to the host each

@@ -194,11 +194,11 @@ int zpq_cm_spec_launch(zpq_ctx* ctx, zpq_cm_spec* k, hipStream_t st, const void*
 // any PCOMP program translated to device code and run over d_in (cm_jit.hip); H/M/R: zeroed device arrays; d_result: [0] bytes
 // produced, [1] status
 int zpq_pcomp_spec_run(zpq_ctx* ctx, hipStream_t st, const u8* pcomp, u32 psize, u32 ph, u32 pm, const u8* d_in, u32 n, u8* d_out, u32 out_cap,
-                       u32* d_H, u8* d_M, u32* d_R, u32* d_result);
+                       u32* d_H, u8* d_M, u32* d_R, u32* d_result, u32* d_seg = nullptr, u32 nseg = 0);
 // device-side records of the specialised coder (layout shared with cm_spec_src.inc)
 struct zpq_spec_comp { u64 cm, ht; u32 type, a1, a2, a3, a4, a5, limit, cm_mask, ht_mask, csize, pad0, pad1; };
-struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap; u64 prof; };
-static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 80, "layout shared with the generated kernels");
+struct zpq_spec_job { u64 comp, p0, H, M, R, in, out, result; u32 in_len, out_cap; u64 prof; u64 seg; u32 nseg, pad; };   // seg: u32[2 * nseg], input bytes per segment then the output end of each (0: one segment)
+static_assert(sizeof(zpq_spec_comp) == 64 && sizeof(zpq_spec_job) == 96, "layout shared with the generated kernels");
 
 // twin files (twins.hip): rep[f] = earliest extent with the same bytes (compared), else f; off / len are host arrays
 int zpq_twins_find(zpq_ctx* ctx, hipStream_t st, const u8* d_base, const u64* off, const u64* len, size_t n, u64 min_bytes, u32* rep,

@@ -38,12 +38,14 @@ class BlockJob(C.Structure):
 
 class UnblockJob(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("n", C.c_uint32), ("out", C.c_void_p), ("out_cap", C.c_uint32),
-                ("out_len", C.c_uint32), ("consumed", C.c_uint32), ("status", C.c_int32), ("sha1", C.c_uint8 * 20)]
+                ("out_len", C.c_uint32), ("consumed", C.c_uint32), ("status", C.c_int32), ("sha1", C.c_uint8 * 20),
+                ("nseg", C.c_uint32), ("seg_cap", C.c_uint32), ("seg_out_end", C.POINTER(C.c_uint32))]
 
 
 class CmJob(C.Structure):
     _fields_ = [("header", C.c_char_p), ("header_len", C.c_uint32), ("d_in", C.c_void_p), ("n", C.c_uint32),
-                ("d_out", C.c_void_p), ("out_cap", C.c_uint32), ("out_len", C.c_uint32), ("status", C.c_int32)]
+                ("d_out", C.c_void_p), ("out_cap", C.c_uint32), ("out_len", C.c_uint32), ("status", C.c_int32),
+                ("nseg", C.c_uint32), ("seg_len", C.POINTER(C.c_uint32)), ("seg_out_end", C.POINTER(C.c_uint32))]
 
 
 _lib = None
@@ -463,6 +465,28 @@ class Engine:
             for b in ins + outs:
                 b.free()
         return res
+
+    def cm_code_segments(self, header, segments, out_cap, encode):
+        """One block of several segments (the model carries on from one to the next): segments = the bytes of each
+        (encode) or each one's coded stream (decode) -> (status, [output of each segment])."""
+        job = (CmJob * 1)()
+        data = b"".join(segments)
+        d_in = self.upload(data); d_out = self.alloc(out_cap)
+        k = len(segments)
+        lens = (C.c_uint32 * k)(*[len(x) for x in segments]); ends = (C.c_uint32 * k)()
+        job[0].header, job[0].header_len = bytes(header), len(header)
+        job[0].d_in, job[0].n, job[0].d_out, job[0].out_cap = d_in.ptr, len(data), d_out.ptr, out_cap
+        job[0].nseg, job[0].seg_len, job[0].seg_out_end = k, lens, ends
+        try:
+            fn = self.L.zpq_cm_encode_dev if encode else self.L.zpq_cm_decode_dev
+            rc = fn(self.ctx, job, 1)
+            if rc != 0 and job[0].status == 0:
+                self._ck(rc)
+            out = d_out.download(min(job[0].out_len, out_cap))
+            cuts = [0] + [min(int(e), len(out)) for e in ends] if k > 1 else [0, len(out)]
+            return job[0].status, [out[cuts[i]:cuts[i + 1]] for i in range(k)]
+        finally:
+            d_in.free(); d_out.free()
 
     def pcomp_run(self, pcomp, ph, pm, data, out_cap):
         d_in = self.upload(data); d_out = self.alloc(out_cap)

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -216,6 +217,19 @@ struct Decompresser::Impl {
   unsigned segments = 0;
   bool first_was_pass = false;    // the block's first segment opened with 0 (no post-processor program)
   uint64_t usize_hint = 0;
+  // A block whose later segments continue the first one's model or post-processor (ZSFX/libzpaq.cpp:2307-2337) is read to
+  // its end and decoded in ONE device job when its first segment is asked for: `ahead` holds the bytes read past the first
+  // segment (findFilename / readComment / readSegmentEnd take them from there), seg_plain the decoded segments.
+  std::deque<uint8_t> ahead;
+  std::vector<std::vector<uint8_t>> seg_plain;
+  bool block_decoded = false;
+  int next(Reader* in) { if (!ahead.empty()) { const int c = ahead.front(); ahead.pop_front(); return c; } return in->get(); }
+  int next_read(Reader* in, char* buf, int k) {
+    int got = 0;
+    while (got < k && !ahead.empty()) { buf[got++] = (char)ahead.front(); ahead.pop_front(); }
+    if (got < k) { const int r = in->read(buf + got, k - got); if (r > 0) got += r; }
+    return got;
+  }
 };
 
 Decompresser::Decompresser() : d_(new Impl), in_(0), out_(0), sha_(0) {}
@@ -227,7 +241,7 @@ bool Decompresser::findBlock(double* memptr) {
   // ZSFX/libzpaq.cpp:2239-2262: the block starts right after the 13-byte tag, wherever that is
   uint8_t win[13]; size_t have = 0;
   for (;;) {
-    const int c = in_->get();
+    const int c = d.next(in_);
     if (c < 0) return false;
     if (have < 13) win[have++] = (uint8_t)c;
     else { memmove(win, win + 1, 12); win[12] = (uint8_t)c; }
@@ -235,11 +249,11 @@ bool Decompresser::findBlock(double* memptr) {
   }
   d.head.assign(kTag, kTag + 13);
   uint8_t h[7];
-  for (int i = 0; i < 7; ++i) { const int c = in_->get(); if (c < 0) error("unexpected end of block header"); h[i] = (uint8_t)c; }
+  for (int i = 0; i < 7; ++i) { const int c = d.next(in_); if (c < 0) error("unexpected end of block header"); h[i] = (uint8_t)c; }
   if (h[0] != 'z' || h[1] != 'P' || h[2] != 'Q' || (h[3] != 1 && h[3] != 2) || h[4] != 1) error("unsupported ZPAQ level or type");
   d.head.insert(d.head.end(), h, h + 7);
   const size_t hsize = h[5] | (size_t)h[6] << 8;
-  for (size_t i = 0; i < hsize; ++i) { const int c = in_->get(); if (c < 0) error("unexpected end of block header"); d.head.push_back((uint8_t)c); }
+  for (size_t i = 0; i < hsize; ++i) { const int c = d.next(in_); if (c < 0) error("unexpected end of block header"); d.head.push_back((uint8_t)c); }
   if (hsize < 7) error("block header too short");
   const uint8_t* z = &d.head[18];              // hsize[2] hh hm ph pm n ...
   d.ncomp = z[6];
@@ -265,6 +279,7 @@ bool Decompresser::findBlock(double* memptr) {
     *memptr = mem;
   }
   d.state = 1; d.segments = 0; d.first_was_pass = false;
+  d.block_decoded = false; d.seg_plain.clear();
   return true;
 }
 
@@ -275,13 +290,13 @@ void Decompresser::hcomp(Writer* out2) {
 bool Decompresser::findFilename(Writer* filename) {
   Impl& d = *d_;
   if (d.state != 1) error("findFilename: not at a segment boundary");
-  const int c = in_->get();
+  const int c = d.next(in_);
   if (c == 255) { d.state = 0; return false; }                 // end of block
   if (c != 1) error("missing segment or end of block");
   ++d.segments;
   d.seg.assign(1, 1);
   for (;;) {
-    const int b = in_->get();
+    const int b = d.next(in_);
     if (b < 0) error("unexpected end of input");
     d.seg.push_back((uint8_t)b);
     if (b == 0) break;
@@ -296,14 +311,14 @@ void Decompresser::readComment(Writer* comment) {
   if (d.state != 2) error("readComment: no segment open");
   d.usize_hint = 0; bool digits = true;
   for (;;) {
-    const int b = in_->get();
+    const int b = d.next(in_);
     if (b < 0) error("unexpected end of input");
     d.seg.push_back((uint8_t)b);
     if (b == 0) break;
     if (digits && b >= '0' && b <= '9') d.usize_hint = d.usize_hint * 10 + (uint64_t)(b - '0'); else digits = false;
     if (comment) comment->put(b);
   }
-  const int r = in_->get();
+  const int r = d.next(in_);
   if (r != 0) error("missing reserved byte");
   d.seg.push_back(0);
   d.payload.clear(); d.plain.clear(); d.given = 0; d.decoded = false; d.have_marker = false;
@@ -313,8 +328,9 @@ void Decompresser::readComment(Writer* comment) {
 namespace {
 // reads the coded bytes of the open segment and the 253/254 record that closes it (the same walk
 // Decompresser::decompress / Decoder::skip do, ZSFX/libzpaq.cpp:2139-2160, 2339-2366)
-void read_payload(Reader* in, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t (&marker)[21]) {
-  auto get = [&]() -> int { const int c = in->get(); if (c < 0) error("unexpected end of compressed data"); return c; };
+template <class Next, class NextRead>
+void read_payload(Next next, NextRead next_read, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t (&marker)[21]) {
+  auto get = [&]() -> int { const int c = next(); if (c < 0) error("unexpected end of compressed data"); return c; };
   int c;
   if (ncomp) {
     uint32_t curr = 0;
@@ -328,7 +344,7 @@ void read_payload(Reader* in, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t
       if (!k) break;
       const size_t at = pay.size();
       pay.resize(at + k);
-      if (in->read((char*)&pay[at], (int)k) != (int)k) error("unexpected end of compressed data");
+      if (next_read((char*)&pay[at], (int)k) != (int)k) error("unexpected end of compressed data");
     }
     c = get();
   }
@@ -338,45 +354,109 @@ void read_payload(Reader* in, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t
 }
 }  // namespace
 
+namespace {
+// one framed block through the batched device call; seg_ends: room for the block's segments (result: where each ends in out)
+void decode_block(const std::vector<uint8_t>& blk_padded, size_t cap, std::vector<uint8_t>& plain, std::vector<uint32_t>* seg_ends) {
+  for (;;) {
+    plain.resize(cap + 64);
+    DecompressBatcher::Item it;
+    memset(&it.job, 0, sizeof it.job);
+    it.done = false; it.rc = 0;
+    it.job.in = blk_padded.data(); it.job.n = (uint32_t)(blk_padded.size() - 64);
+    it.job.out = plain.data(); it.job.out_cap = (uint32_t)plain.size();
+    if (seg_ends) { it.job.seg_cap = (uint32_t)seg_ends->size(); it.job.seg_out_end = seg_ends->data(); }
+    decompress_batcher().submit(&it);                             // N decompressThreads -> one launch
+    const int st = it.job.status ? it.job.status : it.rc;
+    if (st == ZPQ_ERR_CAPACITY && seg_ends && cap < ((size_t)1 << 31)) { cap *= 4; continue; }     // (no size in the comments: the guess was too small)
+    if (st != ZPQ_OK) {                                           // a batch can fail before it touches its jobs
+      std::string m = std::string("Decompresser: ") + zpq_strerror(st);
+      error(m.c_str());
+    }
+    plain.resize(it.job.out_len);
+    if (seg_ends && it.job.nseg != seg_ends->size()) error("Decompresser: segment count of the block differs from its framing");
+    return;
+  }
+}
+}  // namespace
+
 bool Decompresser::decompress(int n) {
   Impl& d = *d_;
   if (d.state != 3 && d.state != 4) error("decompress: no segment open");
+  auto nx = [&]() { return d.next(in_); };
+  auto nr = [&](char* buf, int k) { return d.next_read(in_, buf, k); };
   if (!d.decoded) {
-    if (!d.have_marker) { read_payload(in_, d.ncomp, d.payload, d.marker); d.have_marker = true; d.state = 4; }
+    if (!d.have_marker) { read_payload(nx, nr, d.ncomp, d.payload, d.marker); d.have_marker = true; d.state = 4; }
     if (d.segments > 1) {
-      // a later segment of the block continues the first one's decoder: without a model and without a post-processor
-      // program that is a plain copy of the stored bytes (ZSFX/libzpaq.cpp:2307-2337); anything else would need the
-      // first segment's predictor / PCOMP state
-      if (d.ncomp || !d.first_was_pass) error("blocks that continue a model or a post-processor across segments are not supported by the GPU engine");
-      d.plain.clear();
-      for (size_t p = 0; p + 4 <= d.payload.size();) {
-        const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
-        p += 4;
-        if (!k) break;
-        d.plain.insert(d.plain.end(), d.payload.begin() + p, d.payload.begin() + p + k);
-        p += k;
+      if (d.block_decoded) {
+        if (d.segments > d.seg_plain.size()) error("Decompresser: segment beyond the decoded block");
+        d.plain = d.seg_plain[d.segments - 1];
+      } else {
+        // without a model and without a post-processor program a later segment is a plain copy of its stored bytes; anything
+        // else continues the first segment's decoder, which was not run: the reference refuses that as well
+        // (ZSFX/libzpaq.cpp:2309: "decompression after skipped segment")
+        if (d.ncomp || !d.first_was_pass) error("decompression after skipped segment");
+        d.plain.clear();
+        for (size_t p = 0; p + 4 <= d.payload.size();) {
+          const size_t k = (size_t)d.payload[p] << 24 | (size_t)d.payload[p + 1] << 16 | (size_t)d.payload[p + 2] << 8 | d.payload[p + 3];
+          p += 4;
+          if (!k) break;
+          d.plain.insert(d.plain.end(), d.payload.begin() + p, d.payload.begin() + p + k);
+          p += k;
+        }
       }
     } else {
       std::vector<uint8_t> blk(d.head);
       blk.insert(blk.end(), d.seg.begin(), d.seg.end());
       blk.insert(blk.end(), d.payload.begin(), d.payload.end());
       if (d.marker[0]) { blk.push_back(253); blk.insert(blk.end(), d.marker + 1, d.marker + 21); } else blk.push_back(254);
-      blk.push_back(255);
-      blk.resize(blk.size() + 64);                                  // readable padding (include/zpaqhip.h)
-      size_t cap = d.usize_hint ? (size_t)d.usize_hint : d.payload.size() * 64 + 65536;
-      d.plain.resize(cap + 64);
-      DecompressBatcher::Item it;
-      memset(&it.job, 0, sizeof it.job);
-      it.done = false; it.rc = 0;
-      it.job.in = blk.data(); it.job.n = (uint32_t)(blk.size() - 64);
-      it.job.out = d.plain.data(); it.job.out_cap = (uint32_t)d.plain.size();
-      decompress_batcher().submit(&it);                             // N decompressThreads -> one launch
-      if (it.rc != ZPQ_OK || it.job.status != ZPQ_OK) {             // a batch can fail before it touches its jobs
-        std::string m = std::string("Decompresser: ") + zpq_strerror(it.job.status ? it.job.status : it.rc);
-        error(m.c_str());
-      }
-      d.plain.resize(it.job.out_len);
       d.first_was_pass = d.ncomp == 0 && !d.payload.empty() && d.payload.size() > 4 && d.payload[4] == 0;
+      // Does another segment follow that depends on this one (a model, or a post-processor program: both carry on,
+      // ZSFX/libzpaq.cpp:2312-2317)?  Then the whole block is read now and decoded by one device job.
+      std::vector<uint8_t> rest;                                    // the bytes after this segment, up to and including 255
+      size_t nseg = 1, hint_sum = d.usize_hint, coded = d.payload.size();
+      bool hints = d.usize_hint != 0;
+      if (d.ncomp || !d.first_was_pass) {
+        int c = nx();
+        if (c < 0) error("unexpected end of input");
+        rest.push_back((uint8_t)c);
+        while (c == 1) {
+          auto take = [&]() -> int { const int b = nx(); if (b < 0) error("unexpected end of input"); rest.push_back((uint8_t)b); return b; };
+          while (take() != 0) {}                                    // file name
+          size_t v = 0; bool digits = true, any = false;            // comment: the decimal size in front, if there is one
+          for (int b = take(); b != 0; b = take()) { if (digits && b >= '0' && b <= '9') { v = v * 10 + (size_t)(b - '0'); any = true; } else digits = false; }
+          if (any) hint_sum += v; else hints = false;
+          if (take() != 0) error("missing reserved byte");
+          std::vector<uint8_t> pay; uint8_t mk[21] = {0};
+          read_payload(nx, nr, d.ncomp, pay, mk);
+          coded += pay.size();
+          rest.insert(rest.end(), pay.begin(), pay.end());
+          if (mk[0]) { rest.push_back(253); rest.insert(rest.end(), mk + 1, mk + 21); } else rest.push_back(254);
+          ++nseg;
+          c = take();
+        }
+        if (c != 255) error("missing segment or end of block");
+      }
+      if (nseg == 1) {
+        for (size_t q = rest.size(); q-- > 0;) d.ahead.push_front(rest[q]);       // (the 255 goes back for findFilename)
+        blk.push_back(255);
+        blk.resize(blk.size() + 64);                                  // readable padding (include/zpaqhip.h)
+        decode_block(blk, d.usize_hint ? (size_t)d.usize_hint : d.payload.size() * 64 + 65536, d.plain, nullptr);
+      } else {
+        blk.insert(blk.end(), rest.begin(), rest.end());
+        blk.resize(blk.size() + 64);
+        std::vector<uint8_t> all;
+        std::vector<uint32_t> ends(nseg, 0);
+        decode_block(blk, hints ? hint_sum + 64 : coded * 64 + 65536, all, &ends);
+        d.seg_plain.assign(nseg, std::vector<uint8_t>());
+        for (size_t q = 0; q < nseg; ++q) {
+          const size_t from = q ? ends[q - 1] : 0;
+          if (ends[q] < from || ends[q] > all.size()) error("Decompresser: segment ends out of order");
+          d.seg_plain[q].assign(all.begin() + from, all.begin() + ends[q]);
+        }
+        d.block_decoded = true;
+        d.plain = d.seg_plain[0];
+        for (size_t q = rest.size(); q-- > 0;) d.ahead.push_front(rest[q]);       // the later segments are served from here
+      }
     }
     d.decoded = true; d.given = 0;
   }
@@ -446,7 +526,7 @@ void Decompresser::readSegmentEnd(char* sha1string) {
   Impl& d = *d_;
   if (d.state != 3 && d.state != 4) error("readSegmentEnd: no segment open");
   if (!d.have_marker) {                                                            // segment skipped undecoded
-    read_payload(in_, d.ncomp, d.payload, d.marker); d.have_marker = true;
+    read_payload([&]() { return d.next(in_); }, [&](char* buf, int k) { return d.next_read(in_, buf, k); }, d.ncomp, d.payload, d.marker); d.have_marker = true;
     if (d.segments == 1) d.first_was_pass = d.ncomp == 0 && d.payload.size() > 4 && d.payload[4] == 0;
   }
   if (sha1string) memcpy(sha1string, d.marker, 21);
@@ -479,6 +559,11 @@ struct Compressor::Impl {
   int state = 0;                  // 0 INIT, 1 BLOCK1, 2 SEG1, 3 BLOCK2, 4 SEG2 (ZSFX/libzpaq.h:1369)
   unsigned segments = 0;
   bool pp_done = false;
+  // A block with a context model is coded by ONE device job when it is closed: a later segment continues the first one's
+  // model (the Encoder's Predictor is initialised by startBlock only), so the segments' headers, bytes and end markers
+  // wait here until endBlock.  (Blocks without a model are written as they come.)
+  struct Seg { std::vector<uint8_t> head, data; uint8_t marker[21]; };
+  std::vector<Seg> segs;
 };
 
 Compressor::Compressor() : d_(new Impl), out_(0), in_(0) {}
@@ -510,7 +595,7 @@ void Compressor::startBlock(const char* hcomp) {
   d_->pcomp.clear();
   out_->put('z'); out_->put('P'); out_->put('Q'); out_->put(1 + (d_->header[6] == 0)); out_->put(1);
   out_->write((const char*)d_->header.data(), (int)d_->header.size());
-  d_->state = 1; d_->segments = 0; d_->pp_done = false;
+  d_->state = 1; d_->segments = 0; d_->pp_done = false; d_->segs.clear();
 }
 
 void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
@@ -527,7 +612,7 @@ void Compressor::startBlock(const char* config, int* args, Writer* pcomp_cmd) {
   d_->pcomp.assign(p.begin(), p.begin() + pl);
   out_->put('z'); out_->put('P'); out_->put('Q'); out_->put(1 + (d_->header[6] == 0)); out_->put(1);
   out_->write((const char*)d_->header.data(), (int)d_->header.size());
-  d_->state = 1; d_->segments = 0; d_->pp_done = false;
+  d_->state = 1; d_->segments = 0; d_->pp_done = false; d_->segs.clear();
 }
 
 void Compressor::hcomp(Writer* out2) { if (out2) out2->write((const char*)d_->header.data(), (int)d_->header.size()); }
@@ -539,12 +624,23 @@ bool Compressor::pcomp(Writer* out2) {
 
 void Compressor::startSegment(const char* filename, const char* comment) {
   if (d_->state != 1 && d_->state != 3) error("startSegment: no block open");
-  out_->put(1);
-  if (filename) out_->write(filename, (int)strlen(filename));
-  out_->put(0);
-  if (comment) out_->write(comment, (int)strlen(comment));
-  out_->put(0);
-  out_->put(0);
+  if (d_->header[6]) {                        // with a model: kept until endBlock
+    d_->segs.emplace_back();
+    std::vector<uint8_t>& h = d_->segs.back().head;
+    h.push_back(1);
+    if (filename) h.insert(h.end(), filename, filename + strlen(filename));
+    h.push_back(0);
+    if (comment) h.insert(h.end(), comment, comment + strlen(comment));
+    h.push_back(0);
+    h.push_back(0);
+  } else {
+    out_->put(1);
+    if (filename) out_->write(filename, (int)strlen(filename));
+    out_->put(0);
+    if (comment) out_->write(comment, (int)strlen(comment));
+    out_->put(0);
+    out_->put(0);
+  }
   d_->data.clear();
   ++d_->segments;
   d_->state = d_->state == 1 ? 2 : 4;
@@ -597,26 +693,13 @@ void Compressor::endSegment(const char* sha1string) {
     }
     out_->put(0); out_->put(0); out_->put(0); out_->put(0);
   } else {
-    if (d.segments > 1) error("Compressor: a second segment would continue the first one's context model; one segment per block on the GPU engine");
-    EngineHolder& e = engine();
-    std::lock_guard<std::mutex> g(e.mu);
-    zpq_ctx* ctx = e.get();
-    const size_t n = d.data.size(), cap = n + n / 8 + 4096;
-    void *d_in = nullptr, *d_out = nullptr;
-    int rc = zpq_dev_alloc(ctx, n + 64, &d_in);
-    if (rc == ZPQ_OK) rc = zpq_dev_alloc(ctx, cap + 64, &d_out);
-    if (rc != ZPQ_OK) { if (d_in) zpq_dev_free(ctx, d_in); fail(ctx, rc, "Compressor"); }
-    if (n) rc = zpq_h2d(ctx, d_in, d.data.data(), n);
-    zpq_cm_job j;
-    memset(&j, 0, sizeof j);
-    j.header = d.header.data(); j.header_len = (uint32_t)d.header.size();
-    j.d_in = (const uint8_t*)d_in; j.n = (uint32_t)n; j.d_out = (uint8_t*)d_out; j.out_cap = (uint32_t)cap;
-    if (rc == ZPQ_OK) rc = zpq_cm_encode_dev(ctx, &j, 1);
-    std::vector<uint8_t> coded;
-    if (rc == ZPQ_OK && j.status == ZPQ_OK) { coded.resize(j.out_len); if (j.out_len) rc = zpq_d2h(ctx, coded.data(), d_out, j.out_len); }
-    zpq_dev_free(ctx, d_in); zpq_dev_free(ctx, d_out);
-    if (rc != ZPQ_OK || j.status != ZPQ_OK) fail(ctx, rc ? rc : j.status, "Compressor: context-model coder");
-    out_->write((const char*)coded.data(), (int)coded.size());    // includes the end-of-segment symbol and the four 0 bytes
+    Impl::Seg& sg = d.segs.back();
+    sg.data.swap(d.data);
+    sg.marker[0] = sha1string ? 1 : 0;
+    if (sha1string) memcpy(sg.marker + 1, sha1string, 20);
+    d.data.clear();
+    d.state = 3;
+    return;
   }
   if (sha1string) { out_->put(253); out_->write(sha1string, 20); }
   else out_->put(254);
@@ -637,9 +720,50 @@ char* Compressor::endSegmentChecksum(int64_t* size, bool dosha1) {
 }
 
 void Compressor::endBlock() {
-  if (d_->state != 3) error("endBlock: no block to close");
+  Impl& d = *d_;
+  if (d.state != 3) error("endBlock: no block to close");
+  if (!d.segs.empty()) {
+    // every segment of the block through the context-model coder in one job: the model carries on from one to the next, the
+    // coder ends each with its end-of-segment symbol and the four 0 bytes
+    EngineHolder& e = engine();
+    std::lock_guard<std::mutex> g(e.mu);
+    zpq_ctx* ctx = e.get();
+    size_t n = 0;
+    std::vector<uint32_t> lens(d.segs.size()), ends(d.segs.size(), 0);
+    for (size_t q = 0; q < d.segs.size(); ++q) { lens[q] = (uint32_t)d.segs[q].data.size(); n += d.segs[q].data.size(); }
+    if (n > 0xfff00000ull) error("Compressor: block too large for one device job");
+    const size_t cap = n + n / 8 + 4096 + 16 * d.segs.size();
+    std::vector<uint8_t> all(n);
+    for (size_t q = 0, at = 0; q < d.segs.size(); at += d.segs[q].data.size(), ++q)
+      if (!d.segs[q].data.empty()) memcpy(&all[at], d.segs[q].data.data(), d.segs[q].data.size());
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc = zpq_dev_alloc(ctx, n + 64, &d_in);
+    if (rc == ZPQ_OK) rc = zpq_dev_alloc(ctx, cap + 64, &d_out);
+    if (rc != ZPQ_OK) { if (d_in) zpq_dev_free(ctx, d_in); fail(ctx, rc, "Compressor"); }
+    if (n) rc = zpq_h2d(ctx, d_in, all.data(), n);
+    zpq_cm_job j;
+    memset(&j, 0, sizeof j);
+    j.header = d.header.data(); j.header_len = (uint32_t)d.header.size();
+    j.d_in = (const uint8_t*)d_in; j.n = (uint32_t)n; j.d_out = (uint8_t*)d_out; j.out_cap = (uint32_t)cap;
+    if (d.segs.size() > 1) { j.nseg = (uint32_t)d.segs.size(); j.seg_len = lens.data(); j.seg_out_end = ends.data(); }
+    if (rc == ZPQ_OK) rc = zpq_cm_encode_dev(ctx, &j, 1);
+    std::vector<uint8_t> coded;
+    if (rc == ZPQ_OK && j.status == ZPQ_OK) { coded.resize(j.out_len); if (j.out_len) rc = zpq_d2h(ctx, coded.data(), d_out, j.out_len); }
+    zpq_dev_free(ctx, d_in); zpq_dev_free(ctx, d_out);
+    if (rc != ZPQ_OK || j.status != ZPQ_OK) fail(ctx, rc ? rc : j.status, "Compressor: context-model coder");
+    if (d.segs.size() == 1) ends[0] = j.out_len;
+    for (size_t q = 0; q < d.segs.size(); ++q) {
+      const Impl::Seg& sg = d.segs[q];
+      const size_t from = q ? ends[q - 1] : 0;
+      if (ends[q] < from || ends[q] > coded.size()) error("Compressor: coded segments out of order");
+      out_->write((const char*)sg.head.data(), (int)sg.head.size());
+      out_->write((const char*)coded.data() + from, (int)(ends[q] - from));      // includes the end-of-segment symbol and the four 0 bytes
+      if (sg.marker[0]) { out_->put(253); out_->write((const char*)sg.marker + 1, 20); } else out_->put(254);
+    }
+    d.segs.clear();
+  }
   out_->put(255);
-  d_->state = 0;
+  d.state = 0;
 }
 
 }  // namespace libzpaq

@@ -13,7 +13,7 @@
 //
 // What runs where: the byte work (LZ77 levels 1 / 2, BWT, E8E9, the context-mixing coder, stored framing, block
 // SHA-1 and their inverses) runs in HIP kernels behind the C ABI of include/zpaqhip.h.  Method strings outside the
-// family the engine implements (byte-aligned LZ77 with the hash-table finder, BWT+E8E9 above 16 MiB, more than 255
+// family the engine implements (a secondary LZ77 context, BWT+E8E9 above 16 MiB, more than 255
 // components) end in libzpaq::error("...") -- there is no CPU fallback compiled into this library; the host keeps
 // its CPU libzpaq for those if it wants.
 //
@@ -118,10 +118,12 @@ void decompress(Reader* in, Writer* out);
 // Block-at-a-time reader with the reference's interface and call sequence (ZSFX/libzpaq.h:1243-1264; used as in
 // ZSFX/zsfx.cpp:1783-1801: setInput, setOutput, findBlock, {findFilename, readComment, decompress(n)*, readSegmentEnd}*).
 // The segment is decoded by the engine on the first decompress() call and then handed out n bytes at a time.
-// Blocks with several segments are read when they are stored without a model and without a post-processor program
-// (method 0 streaming archives: segments are independent there); a second segment that would continue a
-// context model or a PCOMP machine across files ends in error(): the journaling format zpaqfranz writes has one
-// segment per block.
+// Blocks with several segments (streaming archives with more than one file per block; the journaling format zpaqfranz
+// writes has one segment per block): without a model and without a post-processor program every segment is a copy of
+// its stored bytes; otherwise the later segments continue the first one's model / PCOMP machine (ZSFX/libzpaq.cpp:
+// 2307-2337), so the WHOLE block is read from the Reader and decoded by one device job when its first segment is
+// decompressed, and the later segments are handed out from that result (decompressing one after skipping the first
+// ends in error("decompression after skipped segment"), as in the reference).
 class Decompresser {
  public:
   Decompresser();
@@ -146,9 +148,11 @@ class Decompresser {
 };
 
 // Streaming writer with the reference's interface (ZSFX/libzpaq.h:1340-1371, contract :426-531): what
-// libzpaq::compress() and callers with their own block structure use.  The segment's bytes are collected on the host
-// and coded when the segment ends (arithmetic coder + context model on the GPU for models with components, stored
-// sub-blocks otherwise); what reaches the Writer is byte for byte what the reference's Compressor writes.
+// libzpaq::compress() and callers with their own block structure use.  Without a model a segment's bytes are written
+// as stored sub-blocks when it ends.  With a model the block's segments are collected on the host and coded by ONE
+// device job at endBlock() -- a later segment continues the first one's model (the Encoder's Predictor is initialised
+// by startBlock only) -- so nothing of such a block reaches the Writer before endBlock(); then it is byte for byte what
+// the reference's Compressor writes.
 class Compressor {
  public:
   Compressor();
