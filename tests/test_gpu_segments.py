@@ -45,6 +45,8 @@ def driver(tmp_path_factory):
     from zpaqfranz_amd import build
     here = build.HERE                      # (the product's directory; the emulated engine's when the suite runs on the CPU)
     drv = str(tmp_path_factory.mktemp("segdrv") / "segments_driver")
+    if os.environ.get("ZPQ_EMU_ASAN") == "1":
+        pytest.skip("a g++-linked driver does not link against the AddressSanitizer build of the emulated engine")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "zpaqfranz_amd", "shim"), os.path.join(ROOT, "tests", "cpp", "segments_driver.cpp"),
                            "-L" + here, "-lzpaq_gpu", "-lzpaqhip", "-Wl,-rpath," + here, "-o", drv])
     return drv
@@ -176,3 +178,46 @@ def test_shim_compressor_and_decompresser_classes_over_blocks_of_segments(eng, d
     h = orc.ref_compile(cmconfigs.ALL["mid"], [0] * 9)[0]
     two = orc.ref_cm_encode_segments(h, [b"\0" + files[0][1], files[1][1]])
     assert two[1] != orc.ref_cm_encode(h, files[1][1])
+
+
+def test_damaged_blocks_of_segments_end_in_a_status(eng):
+    """Flipped bytes, cuts, a stored length that runs past the block (and past 2^32 when added to its position), a segment count
+    beyond the limit: every one ends in a status -- or, where the damage hit a name or a comment, in the right bytes -- never in
+    reads or writes outside the buffers (the emulated engine runs this under AddressSanitizer: tools/emu/asan.sh)."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    files = _files()
+    total = sum(len(d) for _, d in files)
+    want = [d for _, d in files]
+    h = orc.ref_compile(cmconfigs.ALL["mid"], [0] * 9)[0]
+    coded = orc.ref_cm_encode_segments(h, [(b"\0" if i == 0 else b"") + d for i, (_, d) in enumerate(files)])
+    hdr, pc = orc.ref_compile(DELTA_CFG.replace("comp 0 0 0 0 1\n  0 icm 5", "comp 0 0 0 0 0"), [0] * 9)
+    prev = 0
+    streams = []
+    for i, (_, d) in enumerate(files):
+        t = bytearray()
+        for x in d:
+            t.append((x - prev) & 255); prev = x
+        streams.append((b"\x01" + pc if i == 0 else b"") + bytes(t))
+    for blk in (_frame(h, files, coded), _frame(hdr, files, streams, stored=True)):
+        for trial in range(40):
+            b = bytearray(blk)
+            kind = trial % 4
+            if kind == 0:
+                for _ in range(1 + trial % 3):
+                    b[int(rng.integers(13, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                b = b[:int(rng.integers(20, len(b)))]
+            elif kind == 2:
+                at = int(rng.integers(13, len(b) - 4))
+                b[at:at + 4] = bytes([255, 255, 255, int(rng.integers(0, 256))])
+            else:
+                at = int(rng.integers(13, len(b)))
+                b[at:at] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8))
+            rc, job, parts = _unblock(eng, bytes(b), total + 64, len(files))
+            assert rc != 0 or parts == want or job.nseg != len(files), (trial, kind)
+    # more segments than the engine takes in one block
+    many = [("f", b"")] * 70000
+    blk = _frame(hdr, many, [b"\0"] + [b""] * 69999, shas=False, stored=True)
+    rc, job, _ = _unblock(eng, blk, 64, 1)
+    assert rc != 0 and job.status != 0

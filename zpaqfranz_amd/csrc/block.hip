@@ -516,7 +516,7 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
           const u32 k = (u32)a[p] << 24 | (u32)a[p + 1] << 16 | (u32)a[p + 2] << 8 | a[p + 3];
           p += 4;
           if (!k) break;
-          if (p + k > n) { ok = false; break; }
+          if ((u64)p + k > n) { ok = false; break; }
           P.payload.insert(P.payload.end(), a + p, a + p + k);
           p += k;
         }
