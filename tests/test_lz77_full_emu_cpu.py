@@ -1,8 +1,8 @@
-"""zpq_lz77_encode_dev() ITSELF on the CPU: tests/cpp/lz77_full_emu.cpp compiles zpaqfranz_amd/csrc/lz77_enc.hip and radix.hip
-whole -- host code and every kernel -- over a stand-in HIP runtime (tests/cpp/fake_hip.h: device memory is host memory, a
-launch runs every workgroup on the fibre emulator).  The code stream must be the oracle's, byte for byte, on every path the
-environment selects: table states with speculative segments (the default), one wave per block, and the experimental
-candidate tables (ZPQ_LZ_CAND=1) with segments, direct, the long-run hand-off and the hand-written radix sort underneath.
+"""zpq_lz77_encode_dev() ITSELF on the CPU: tests/cpp/lz77_full_emu.cpp compiles zpaqfranz_amd/csrc/lz77_enc.hip whole -- host
+code and every kernel -- over a stand-in HIP runtime (tests/cpp/fake_hip.h: device memory is host memory, a launch runs every
+workgroup on the fibre emulator).  The code stream must be the oracle's, byte for byte, on every path the environment selects:
+table states with speculative segments (the default; one and several segments per block, with the seam and stitch walks and the
+token packers behind them) and one workgroup of four waves per block writing the stream itself.
 The switches are read once per process, hence one process per setting."""
 import os
 import subprocess
