@@ -1,9 +1,10 @@
-"""Cycles per phase of the LZ77 table walks (engine built with -DZPQ_LZ_PROFILE under tools/_prof): one process per setting."""
+"""Cycles per phase of the LZ77 table walks (engine built with -DZPQ_LZ_PROFILE under tools/_prof, or the directory ZPQ_PROF_DIR
+names: a tools/make_variant.sh variant built with that flag): one process per setting."""
 import ctypes, os, subprocess, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 CHILD = r'''
 import ctypes, sys, os, time
-sys.path.insert(0, os.path.join(%(root)r, "tools", "_prof")); sys.path.insert(1, os.path.join(%(root)r, "tests"))
+sys.path.insert(0, os.environ.get("ZPQ_PROF_DIR") or os.path.join(%(root)r, "tools", "_prof")); sys.path.insert(1, os.path.join(%(root)r, "tests"))
 import datagen
 from zpaqfranz_amd import Engine
 e = Engine(0)
