@@ -221,3 +221,34 @@ def test_damaged_blocks_of_segments_end_in_a_status(eng):
     blk = _frame(hdr, many, [b"\0"] + [b""] * 69999, shas=False, stored=True)
     rc, job, _ = _unblock(eng, blk, 64, 1)
     assert rc != 0 and job.status != 0
+
+
+def test_shim_decompresser_on_damaged_archives_of_segments(eng, driver, tmp_path):
+    """The shim reads a block of continuing segments to its end before it decodes the first one: cut, flipped and padded archives
+    end in libzpaq::error() (exit code 1 of the driver) or in segments whose checksums the caller can compare -- not in a crash
+    and not in a wait for bytes that never come."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    files = _files()
+    h = orc.ref_compile(cmconfigs.ALL["mid"], [0] * 9)[0]
+    coded = orc.ref_cm_encode_segments(h, [(b"\0" if i == 0 else b"") + d for i, (_, d) in enumerate(files)])
+    blk = _frame(h, files, coded)
+    out = tmp_path / "o"
+    out.mkdir()
+    for trial in range(12):
+        b = bytearray(blk)
+        if trial % 3 == 0:
+            b = b[:int(rng.integers(30, len(b) - 1))]
+        elif trial % 3 == 1:
+            b[int(rng.integers(13, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        else:
+            at = int(rng.integers(13, len(b)))
+            b[at:at] = bytes(rng.integers(0, 256, size=5, dtype=np.uint8))
+        arc = tmp_path / ("bad%d.zpaq" % trial)
+        arc.write_bytes(bytes(b))
+        r = subprocess.run([driver, "d", str(arc), str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode in (0, 1), (trial, r.returncode, r.stderr[-300:])
+        if r.returncode == 0:                     # decoded: whatever differs shows in the checksums the driver prints
+            for l in r.stdout.strip().splitlines():
+                f = l.split(" ")
+                assert len(f) == 6
