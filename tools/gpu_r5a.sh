@@ -1,9 +1,10 @@
-# Round 5, FIRST GPU call (about 9 minutes): what the tree does on config 4 and on the headline, and the two candidates written
+# Round 5, FIRST GPU call (about 12 minutes): what the tree does on config 4 and on the headline, and the two candidates written
 # at the end of round 4 beside it -- each with its parity subset.  Before the call, here:
 #   tools/make_prof.sh
 #   tools/make_variant.sh emit tools/proto/lz77_vector_emitter.patch
 #   tools/make_variant.sh emit_prof -DZPQ_LZ_PROFILE tools/proto/lz77_vector_emitter.patch
 #   tools/make_variant.sh pack tools/proto/lz77_pack_literals_in_token_kernel.patch
+#   tools/make_variant.sh maskspec tools/proto/lz77_spec_kernel_mask_evaluator.patch
 # Adopt a candidate only if its parity subset is green AND its number is better; delete its patch otherwise (DESIGN §5 has the list).
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1 ZPQ_BENCH_NO_PLAIN=1
@@ -22,6 +23,8 @@ echo "[$(( $(date +%s) - S0 )) s] config 4"
 timeout 240 python bench.py --no-cpu-baseline --workload silesia_x256_m1 2>gpurun_out/${T}_err3.txt | tail -1 | line headline_tree | tee gpurun_out/${T}_headline_tree.txt
 timeout 240 python tools/run_variant.py pack bench.py --no-cpu-baseline --workload silesia_x256_m1 2>gpurun_out/${T}_err4.txt | tail -1 | line headline_pack | tee gpurun_out/${T}_headline_pack.txt
 timeout 120 python tools/run_variant.py pack -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -k "$LZ" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_pack.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_pack.log; tail -2 gpurun_out/${T}_tests_pack.log
-# the six tests for blocks of several segments have never run on the chip
+timeout 240 python tools/run_variant.py maskspec bench.py --no-cpu-baseline --workload silesia_x256_m1 2>gpurun_out/${T}_err5.txt | tail -1 | line headline_maskspec | tee gpurun_out/${T}_headline_maskspec.txt
+timeout 120 python tools/run_variant.py maskspec -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -k "$LZ" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_maskspec.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_maskspec.log; tail -2 gpurun_out/${T}_tests_maskspec.log
+# the seven tests for blocks of several segments have never run on the chip
 timeout 200 python -m pytest tests/test_gpu_segments.py tests/test_gpu_cm_spec.py -m gpu -k "segment" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_segments.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_segments.log; tail -2 gpurun_out/${T}_tests_segments.log
 echo "[$(( $(date +%s) - S0 )) s] done"
