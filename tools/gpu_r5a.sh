@@ -25,6 +25,6 @@ timeout 240 python tools/run_variant.py pack bench.py --no-cpu-baseline --worklo
 timeout 120 python tools/run_variant.py pack -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -k "$LZ" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_pack.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_pack.log; tail -2 gpurun_out/${T}_tests_pack.log
 timeout 240 python tools/run_variant.py maskspec bench.py --no-cpu-baseline --workload silesia_x256_m1 2>gpurun_out/${T}_err5.txt | tail -1 | line headline_maskspec | tee gpurun_out/${T}_headline_maskspec.txt
 timeout 120 python tools/run_variant.py maskspec -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -k "$LZ" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_maskspec.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_maskspec.log; tail -2 gpurun_out/${T}_tests_maskspec.log
-# the eight tests for blocks of several segments have never run on the chip
+# the seven tests for blocks of several segments have never run on the chip
 timeout 200 python -m pytest tests/test_gpu_segments.py tests/test_gpu_cm_spec.py -m gpu -k "segment" -x -q -p no:cacheprovider > gpurun_out/${T}_tests_segments.log 2>&1; echo "rc=$?" >> gpurun_out/${T}_tests_segments.log; tail -2 gpurun_out/${T}_tests_segments.log
 echo "[$(( $(date +%s) - S0 )) s] done"
