@@ -61,3 +61,37 @@ def test_one_run_with_a_rare_second_equals_two_runs():
         thin_seen += thin
         differing += want[0] != want[1]
     assert thin_seen > 500 and differing > 100          # the rare path and decisions that depend on (lit > 0) were both exercised
+
+
+def test_one_bit_per_xor_byte_is_all_the_evaluator_needs():
+    """The four-wave kernel's evaluator (lz77_waves.inc, LEAN) keeps of a candidate's 32 XOR bytes one bit each: bit 8b + w of M
+    is set when byte b of word w differs.  From M alone: the length (first byte that differs, in byte order) and the reference's
+    in[p+blen-1] == in[i+blen-1] for any blen - 1 < 32.  The arithmetic, restated: bit 7 of every byte of
+    ((x & 0x7f7f7f7f) + 0x7f7f7f7f) | x is set exactly when that byte of x is not zero (no carry leaves a byte)."""
+    rng = random.Random(11)
+
+    def nz(x):
+        return ((((x & 0x7f7f7f7f) + 0x7f7f7f7f) & 0xffffffff) | x) & 0xffffffff
+
+    for _ in range(20000):
+        # XOR of two 32-byte strings that agree on a random prefix and here and there behind it
+        same = rng.choice((0, 1, 3, 4, 7, 8, 15, 16, 17, 31, 32))
+        xor = bytes(0 if (i < same or rng.random() < 0.4) else rng.randrange(1, 256) for i in range(32))
+        words = [int.from_bytes(xor[4 * w:4 * w + 4], "little") for w in range(8)]
+        for w in range(8):
+            flags = nz(words[w])
+            assert [(flags >> (8 * b + 7)) & 1 for b in range(4)] == [int(xor[4 * w + b] != 0) for b in range(4)]
+        M = 0
+        for w in range(8):
+            M |= (nz(words[w]) >> (7 - w)) & (0x01010101 << w)
+        length = 32
+        for b in range(4):
+            byte = (M >> (8 * b)) & 255
+            first = 4 * (((byte | 0x100) & -(byte | 0x100)).bit_length() - 1) + b          # 4 * ctz(byte | 0x100) + b
+            length = min(length, first)
+        want = next((i for i in range(32) if xor[i]), 32)
+        assert length == want, (xor.hex(), length, want)
+        for idx in range(32):
+            w = idx >> 2
+            eqb = ((M >> (((idx & 3) << 3) | (w & 7))) & 1) == 0
+            assert eqb == (xor[idx] == 0)
