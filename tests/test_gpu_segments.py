@@ -252,3 +252,76 @@ def test_shim_decompresser_on_damaged_archives_of_segments(eng, driver, tmp_path
             for l in r.stdout.strip().splitlines():
                 f = l.split(" ")
                 assert len(f) == 6
+
+
+def test_shim_findblock_searches_like_the_reference(eng, driver, tmp_path):
+    """Decompresser::findBlock as the reference searches (ZSFX/libzpaq.cpp:2239-2262): four rolling hashes over the last 16
+    bytes, pre-seeded with the tag -- (i) a stream written without Compressor::writeTag() (it begins with "zPQ") is a block,
+    (ii) a tag that is not followed by "zPQ" is just bytes and the scan goes on to the real block behind it, (iii) several
+    blocks, the second without its tag but behind bytes that end in the tag.  The real libzpaq::decompress() reads the same
+    streams to the same bytes."""
+    files = _files()
+    h = orc.ref_compile(cmconfigs.ALL["mid"], [0] * 9)[0]
+    coded = orc.ref_cm_encode_segments(h, [(b"\0" if i == 0 else b"") + d for i, (_, d) in enumerate(files)])
+    blk = _frame(h, files, coded)
+    assert blk[:13] == TAG and blk[13:16] == b"zPQ"
+    one = _frame(h, files[:1], [orc.ref_cm_encode(h, b"\0" + files[0][1])])
+    lookalike = b"garbage" + TAG + b"zPx" + bytes(range(40)) + TAG[:12] + b"\x00zPQ" + TAG + TAG[:5]
+    cases = {
+        "notag": (blk[13:], [files]),
+        "lookalike": (lookalike + blk, [files]),
+        # the second block sits behind bytes that end in the tag; the third has no tag and no tag in front of it: never found
+        "two": (one + b"junk" + TAG[3:] + TAG + one[13:] + lookalike + blk[13:], [files[:1], files[:1]]),
+        "two_b": (blk[13:] + lookalike + TAG + one[13:], [files, files[:1]]),
+    }
+    for name, (arc_bytes, want_blocks) in cases.items():
+        whole = b"".join(d for fs in want_blocks for _, d in fs)
+        assert orc.ref_decompress(arc_bytes, len(whole) + 64) == whole, name              # what the real reference makes of the stream
+        arc = tmp_path / (name + ".zpaq")
+        arc.write_bytes(arc_bytes)
+        out = tmp_path / ("o_" + name)
+        out.mkdir()
+        r = subprocess.run([driver, "d", str(arc), str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr)
+        lines = [l.split(" ") for l in r.stdout.strip().splitlines()]
+        want = [(b, s, n, d) for b, fs in enumerate(want_blocks) for s, (n, d) in enumerate(fs)]
+        assert len(lines) == len(want), (name, r.stdout)
+        for l, (b, s, n, d) in zip(lines, want):
+            assert l[:3] == [str(b), str(s), n] and int(l[3]) == len(d) and l[4] == l[5] == hashlib.sha1(d).hexdigest(), (name, l)
+    # a level byte that is neither 1 nor 2 behind "zPQ" is an error, not a reason to keep scanning (ZSFX/libzpaq.cpp:2256)
+    arc = tmp_path / "level.zpaq"
+    arc.write_bytes(b"zPQ\x03\x01" + blk[18:])
+    r = subprocess.run([driver, "d", str(arc), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "level" in r.stderr
+
+
+def test_shim_delivers_the_whole_segments_in_front_of_a_damaged_tail(eng, driver, tmp_path):
+    """A block of continuing segments cut inside its third segment (or with a wrong byte where the fourth should begin): the
+    reference decodes segment by segment and fails where the damage is (findFilename / the decoder), so the segments in front
+    arrive.  The shim reads ahead to decode the block in one device job -- it must still deliver them, and report the damage
+    when the caller gets there."""
+    files = _files()
+    h = orc.ref_compile(cmconfigs.ALL["mid"], [0] * 9)[0]
+    coded = orc.ref_cm_encode_segments(h, [(b"\0" if i == 0 else b"") + d for i, (_, d) in enumerate(files)])
+    blk = _frame(h, files, coded)
+    # where every segment starts: 1 name 0 comment 0 0
+    starts, at = [], 13 + 5 + len(h)
+    for (name, data), c in zip(files, coded):
+        starts.append(at)
+        at += 1 + len(name) + 1 + len(str(len(data))) + 2 + len(c) + 21
+    assert blk[at] == 255 and all(blk[s] == 1 for s in starts)
+    cut3 = blk[:starts[3] + 9]                               # ends inside the fourth segment's header
+    cut2 = blk[:starts[2] + 12 + len(coded[2]) // 2]         # ends inside the third segment's coded bytes
+    wrong = bytearray(blk); wrong[starts[3]] = 7             # neither a segment nor the end of the block
+    for name, arc_bytes, whole in (("cut3", cut3, 3), ("cut2", cut2, 2), ("wrong", bytes(wrong), 3)):
+        arc = tmp_path / (name + ".zpaq")
+        arc.write_bytes(arc_bytes)
+        out = tmp_path / ("o_" + name)
+        out.mkdir()
+        r = subprocess.run([driver, "d", str(arc), str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 1, (name, r.returncode, r.stdout, r.stderr)
+        lines = [l.split(" ") for l in r.stdout.strip().splitlines()]
+        assert len(lines) == whole, (name, r.stdout, r.stderr)
+        for k, l in enumerate(lines):
+            n, d = files[k]
+            assert l[:3] == ["0", str(k), n] and l[4] == l[5] == hashlib.sha1(d).hexdigest(), (name, l)

@@ -654,8 +654,14 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
       // end-of-segment input after each (the programs compressBlock writes would also do segment by segment on the native
       // decoders, but what carries over is for the program to say: the ZPAQL machine is the definition)
       if (P.seg_dec_end.size() != P.nseg || P.seg_dec_end[P.nseg - 1] != dec_len) { fail_job(ZPQ_ERR_FORMAT); continue; }
+      bool ends_ok = true;                 // what the coder reported must ascend (the SHA-1 extents are cut from it)
+      for (u32 q = 1; q < P.nseg; ++q) ends_ok &= P.seg_dec_end[q] >= P.seg_dec_end[q - 1];
+      if (!ends_ok) { fail_job(ZPQ_ERR_FORMAT); continue; }
       P.seg_out_end.assign(P.nseg, 0);
       if (pre[0] == 0) {
+        // the post-processor's type byte lies in the FIRST segment (the reference: "Unexpected EOS", PostProcessor::write state 0,
+        // ZSFX/libzpaq.cpp:2187-2192); a first segment of 0 decoded bytes would wrap every segment end below
+        if (P.seg_dec_end[0] < 1) { fail_job(ZPQ_ERR_FORMAT); continue; }
         const u32 len = dec_len - 1;
         if (len > jobs[i].out_cap) { fail_job(ZPQ_ERR_CAPACITY); continue; }
         if (len) ZPQ_HIP(ctx, hipMemcpyAsync(outp[i], d_dec + 1, len, hipMemcpyDeviceToDevice, st));
@@ -675,6 +681,10 @@ int zpq_decompress_hostparsed(zpq_ctx* ctx, zpq_unblock_job* jobs, size_t njobs,
         if (rc) { fail_job(rc); continue; }
         jobs[i].out_len = olen;
       } else { fail_job(ZPQ_ERR_FORMAT); continue; }
+      // the segment ends cut the SHA-1 extents below: ascending and inside the output, whoever computed them
+      bool out_ok = P.seg_out_end[P.nseg - 1] <= jobs[i].out_len;
+      for (u32 q = 1; q < P.nseg; ++q) out_ok &= P.seg_out_end[q] >= P.seg_out_end[q - 1];
+      if (!out_ok) { fail_job(ZPQ_ERR_FORMAT); continue; }
       for (u32 q = 0; q < P.nseg && q < jobs[i].seg_cap; ++q) if (jobs[i].seg_out_end) jobs[i].seg_out_end[q] = P.seg_out_end[q];
     } else if (pre[0] == 0) {                           // PASS
       const u32 len = dec_len - 1;

@@ -234,29 +234,42 @@ struct Decompresser::Impl {
 
 Decompresser::Decompresser() : d_(new Impl), in_(0), out_(0), sha_(0) {}
 Decompresser::~Decompresser() { delete d_; }
+// What was read from the Reader and not yet consumed (ZSFX/libzpaq.h:1256; callers compute archive offsets as
+// in.tell() - d.buffered(), ZSFX/zsfx.cpp:1434, 1592, 1597): the bytes the look-ahead of decompress() put back.
+int Decompresser::buffered() { return (int)d_->ahead.size(); }
+void Decompresser::setInput(Reader* in) { in_ = in; d_->ahead.clear(); }     // (bytes read ahead belong to the Reader they came from)
 
 bool Decompresser::findBlock(double* memptr) {
   if (!in_) error("Decompresser: no input");
   Impl& d = *d_;
-  // ZSFX/libzpaq.cpp:2239-2262: the block starts right after the 13-byte tag, wherever that is
-  uint8_t win[13]; size_t have = 0;
-  for (;;) {
-    const int c = d.next(in_);
-    if (c < 0) return false;
-    if (have < 13) win[have++] = (uint8_t)c;
-    else { memmove(win, win + 1, 12); win[12] = (uint8_t)c; }
-    if (have == 13 && memcmp(win, kTag, 13) == 0) break;
+  // ZSFX/libzpaq.cpp:2239-2262: four rolling hashes over the last 16 bytes (their multipliers 12, 20, 28, 44 all hold a
+  // factor 4, so the sixteenth power is 0 mod 2^32 and older bytes drop out), looked at after every byte, equal to those of
+  // the 13-byte tag followed by "zPQ".  They start as if the tag had just been read: a stream that BEGINS with "zPQ" is a
+  // block (Compressor::writeTag() is optional).  A tag that is not followed by "zPQ" is just bytes: the scan goes on.
+  uint32_t h1 = 0x3D49B113u, h2 = 0x29EB7F93u, h3 = 0x2614BE13u, h4 = 0x3828EB13u;
+  int c;
+  while ((c = d.next(in_)) >= 0) {
+    h1 = h1 * 12 + (uint32_t)c; h2 = h2 * 20 + (uint32_t)c; h3 = h3 * 28 + (uint32_t)c; h4 = h4 * 44 + (uint32_t)c;
+    if (h1 == 0xB16B88F1u && h2 == 0xFF5376F1u && h3 == 0x72AC5BF1u && h4 == 0x2F909AF1u) break;
   }
+  if (c < 0) return false;
+  // (the engine's block jobs carry the tag: what is handed on is tag + "zPQ" whether or not the stream had the tag)
   d.head.assign(kTag, kTag + 13);
-  uint8_t h[7];
-  for (int i = 0; i < 7; ++i) { const int c = d.next(in_); if (c < 0) error("unexpected end of block header"); h[i] = (uint8_t)c; }
-  if (h[0] != 'z' || h[1] != 'P' || h[2] != 'Q' || (h[3] != 1 && h[3] != 2) || h[4] != 1) error("unsupported ZPAQ level or type");
+  uint8_t h[7] = {'z', 'P', 'Q', 0, 0, 0, 0};
+  for (int i = 3; i < 7; ++i) {
+    const int b = d.next(in_);
+    if (i == 3 && b != 1 && b != 2) error("unsupported ZPAQ level");
+    if (i == 4 && b != 1) error("unsupported ZPAQL type");
+    if (b < 0) error("unexpected end of block header");
+    h[i] = (uint8_t)b;
+  }
   d.head.insert(d.head.end(), h, h + 7);
   const size_t hsize = h[5] | (size_t)h[6] << 8;
   for (size_t i = 0; i < hsize; ++i) { const int c = d.next(in_); if (c < 0) error("unexpected end of block header"); d.head.push_back((uint8_t)c); }
   if (hsize < 7) error("block header too short");
   const uint8_t* z = &d.head[18];              // hsize[2] hh hm ph pm n ...
   d.ncomp = z[6];
+  if (h[3] == 1 && d.ncomp == 0) error("ZPAQ level 1 requires at least 1 component");     // ZSFX/libzpaq.cpp:2258-2259
   if (memptr) {                                 // ZPAQL::memory(), ZSFX/libzpaq.cpp:1001-1030
     double mem = 4.0 * (1u << z[2]) + (double)(1u << z[3]) + 4.0 * (1u << z[4]) + (double)(1u << z[5]) + (double)hsize + 512;
     size_t cp = 7;
@@ -315,7 +328,7 @@ void Decompresser::readComment(Writer* comment) {
     if (b < 0) error("unexpected end of input");
     d.seg.push_back((uint8_t)b);
     if (b == 0) break;
-    if (digits && b >= '0' && b <= '9') d.usize_hint = d.usize_hint * 10 + (uint64_t)(b - '0'); else digits = false;
+    if (digits && b >= '0' && b <= '9' && d.usize_hint < (1ull << 40)) d.usize_hint = d.usize_hint * 10 + (uint64_t)(b - '0'); else digits = false;
     if (comment) comment->put(b);
   }
   const int r = d.next(in_);
@@ -329,34 +342,52 @@ namespace {
 // reads the coded bytes of the open segment and the 253/254 record that closes it (the same walk
 // Decompresser::decompress / Decoder::skip do, ZSFX/libzpaq.cpp:2139-2160, 2339-2366)
 template <class Next, class NextRead>
-void read_payload(Next next, NextRead next_read, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t (&marker)[21]) {
-  auto get = [&]() -> int { const int c = next(); if (c < 0) error("unexpected end of compressed data"); return c; };
+const char* try_read_payload(Next next, NextRead next_read, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t (&marker)[21]) {
+  // returns 0, or what is wrong with the stream (the caller decides whether that is an error() now or later)
+  static const char* const kEof = "unexpected end of compressed data";
   int c;
+#define ZPQ_GET() do { c = next(); if (c < 0) return kEof; } while (0)
   if (ncomp) {
     uint32_t curr = 0;
-    while (curr == 0) { c = get(); pay.push_back((uint8_t)c); curr = (uint32_t)c; }
-    while (curr) { c = get(); pay.push_back((uint8_t)c); curr = curr << 8 | (uint32_t)c; }
-    for (c = get(); c == 0; c = get()) pay.push_back(0);        // the coder's own last byte may be 0 as well
+    while (curr == 0) { ZPQ_GET(); pay.push_back((uint8_t)c); curr = (uint32_t)c; }
+    while (curr) { ZPQ_GET(); pay.push_back((uint8_t)c); curr = curr << 8 | (uint32_t)c; }
+    for (;;) { ZPQ_GET(); if (c != 0) break; pay.push_back(0); }        // the coder's own last byte may be 0 as well
   } else {
     for (;;) {
       uint32_t k = 0;
-      for (int i = 0; i < 4; ++i) { c = get(); pay.push_back((uint8_t)c); k = k << 8 | (uint32_t)c; }
+      for (int i = 0; i < 4; ++i) { ZPQ_GET(); pay.push_back((uint8_t)c); k = k << 8 | (uint32_t)c; }
       if (!k) break;
       const size_t at = pay.size();
       pay.resize(at + k);
-      if (next_read((char*)&pay[at], (int)k) != (int)k) error("unexpected end of compressed data");
+      const int got = next_read((char*)&pay[at], (int)k);
+      if (got != (int)k) { pay.resize(at + (got > 0 ? (size_t)got : 0)); return kEof; }
     }
-    c = get();
+    ZPQ_GET();
   }
-  if (c == 253) { marker[0] = 1; for (int i = 1; i <= 20; ++i) marker[i] = (uint8_t)get(); }
+  if (c == 253) {
+    marker[0] = 1;
+    for (int i = 1; i <= 20; ++i) {
+      c = next();
+      if (c < 0) { pay.push_back(253); pay.insert(pay.end(), marker + 1, marker + i); return kEof; }     // (kept, as below)
+      marker[i] = (uint8_t)c;
+    }
+  }
   else if (c == 254) marker[0] = 0;
-  else error("missing end of segment marker");
+  else { pay.push_back((uint8_t)c); return "missing end of segment marker"; }     // (kept: a soft caller puts every byte read back)
+#undef ZPQ_GET
+  return 0;
+}
+template <class Next, class NextRead>
+void read_payload(Next next, NextRead next_read, uint32_t ncomp, std::vector<uint8_t>& pay, uint8_t (&marker)[21]) {
+  if (const char* what = try_read_payload(next, next_read, ncomp, pay, marker)) error(what);
 }
 }  // namespace
 
 namespace {
 // one framed block through the batched device call; seg_ends: room for the block's segments (result: where each ends in out)
 void decode_block(const std::vector<uint8_t>& blk_padded, size_t cap, std::vector<uint8_t>& plain, std::vector<uint32_t>* seg_ends) {
+  const size_t kCapMax = 0xffffffffu - 128;       // out_cap is a uint32_t (+ 64 bytes of padding)
+  if (cap > kCapMax) cap = kCapMax;               // (a size hint out of a comment is whatever the archive says)
   for (;;) {
     plain.resize(cap + 64);
     DecompressBatcher::Item it;
@@ -367,7 +398,8 @@ void decode_block(const std::vector<uint8_t>& blk_padded, size_t cap, std::vecto
     if (seg_ends) { it.job.seg_cap = (uint32_t)seg_ends->size(); it.job.seg_out_end = seg_ends->data(); }
     decompress_batcher().submit(&it);                             // N decompressThreads -> one launch
     const int st = it.job.status ? it.job.status : it.rc;
-    if (st == ZPQ_ERR_CAPACITY && seg_ends && cap < ((size_t)1 << 31)) { cap *= 4; continue; }     // (no size in the comments: the guess was too small)
+    // (no usable size in the comments: the guess was too small; a job's capacity is 32 bits wide, so is the last try)
+    if (st == ZPQ_ERR_CAPACITY && cap < kCapMax) { cap = cap > kCapMax / 4 ? kCapMax : cap * 4; continue; }
     if (st != ZPQ_OK) {                                           // a batch can fail before it touches its jobs
       std::string m = std::string("Decompresser: ") + zpq_strerror(st);
       error(m.c_str());
@@ -413,28 +445,41 @@ bool Decompresser::decompress(int n) {
       // Does another segment follow that depends on this one (a model, or a post-processor program: both carry on,
       // ZSFX/libzpaq.cpp:2312-2317)?  Then the whole block is read now and decoded by one device job.
       std::vector<uint8_t> rest;                                    // the bytes after this segment, up to and including 255
+      bool cut = false; size_t cut_at = 0;                          // the framing behind the first segment is damaged at rest[cut_at]
       size_t nseg = 1, hint_sum = d.usize_hint, coded = d.payload.size();
       bool hints = d.usize_hint != 0;
       if (d.ncomp || !d.first_was_pass) {
-        int c = nx();
-        if (c < 0) error("unexpected end of input");
-        rest.push_back((uint8_t)c);
-        while (c == 1) {
-          auto take = [&]() -> int { const int b = nx(); if (b < 0) error("unexpected end of input"); rest.push_back((uint8_t)b); return b; };
-          while (take() != 0) {}                                    // file name
+        // Nothing wrong with the framing BEHIND the first segment is an error of this call: the reference delivers the segment
+        // and fails at the next findFilename() (ZSFX/libzpaq.cpp:2269-2289).  So the look-ahead only collects: every byte it takes
+        // goes into `rest`, and where the stream ends or stops making sense the block is cut after its last whole segment -- the
+        // bytes go back for findFilename() / readComment() / readSegmentEnd() to read again and to report.
+        size_t whole = 0;                                           // bytes of `rest` that are whole later segments
+        size_t hint_ok = hint_sum, coded_ok = coded; bool hints_ok = hints;
+        bool bad = false;
+        auto take = [&]() -> int { const int b = nx(); if (b < 0) bad = true; else rest.push_back((uint8_t)b); return b; };
+        int c = take();
+        while (!bad && c == 1) {
+          for (int b = take(); !bad && b != 0; b = take()) {}       // file name
           size_t v = 0; bool digits = true, any = false;            // comment: the decimal size in front, if there is one
-          for (int b = take(); b != 0; b = take()) { if (digits && b >= '0' && b <= '9') { v = v * 10 + (size_t)(b - '0'); any = true; } else digits = false; }
+          for (int b = bad ? 0 : take(); !bad && b != 0; b = take()) { if (digits && b >= '0' && b <= '9' && v < ((size_t)1 << 40)) { v = v * 10 + (size_t)(b - '0'); any = true; } else digits = false; }
+          if (bad || take() != 0) { bad = true; break; }            // (the reserved byte)
           if (any) hint_sum += v; else hints = false;
-          if (take() != 0) error("missing reserved byte");
           std::vector<uint8_t> pay; uint8_t mk[21] = {0};
-          read_payload(nx, nr, d.ncomp, pay, mk);
+          const char* what = try_read_payload(nx, nr, d.ncomp, pay, mk);
           coded += pay.size();
           rest.insert(rest.end(), pay.begin(), pay.end());
+          if (what) { bad = true; break; }
           if (mk[0]) { rest.push_back(253); rest.insert(rest.end(), mk + 1, mk + 21); } else rest.push_back(254);
           ++nseg;
+          whole = rest.size(); hint_ok = hint_sum; coded_ok = coded; hints_ok = hints;
           c = take();
         }
-        if (c != 255) error("missing segment or end of block");
+        if (bad || c != 255) {
+          // cut after the last whole segment: the device job gets those (closed with a 255 of its own), the stream keeps the rest
+          hint_sum = hint_ok; coded = coded_ok; hints = hints_ok;
+          cut_at = whole ? whole : 0;
+          cut = true;
+        }
       }
       if (nseg == 1) {
         for (size_t q = rest.size(); q-- > 0;) d.ahead.push_front(rest[q]);       // (the 255 goes back for findFilename)
@@ -442,7 +487,9 @@ bool Decompresser::decompress(int n) {
         blk.resize(blk.size() + 64);                                  // readable padding (include/zpaqhip.h)
         decode_block(blk, d.usize_hint ? (size_t)d.usize_hint : d.payload.size() * 64 + 65536, d.plain, nullptr);
       } else {
-        blk.insert(blk.end(), rest.begin(), rest.end());
+        // rest = [1 segment]... then 255, or -- cut -- whole segments followed by whatever the stream holds there
+        if (cut) { blk.insert(blk.end(), rest.begin(), rest.begin() + cut_at); blk.push_back(255); }
+        else blk.insert(blk.end(), rest.begin(), rest.end());
         blk.resize(blk.size() + 64);
         std::vector<uint8_t> all;
         std::vector<uint32_t> ends(nseg, 0);

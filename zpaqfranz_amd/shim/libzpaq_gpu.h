@@ -128,7 +128,7 @@ class Decompresser {
  public:
   Decompresser();
   ~Decompresser();
-  void setInput(Reader* in) { in_ = in; }
+  void setInput(Reader* in);
   bool findBlock(double* memptr = 0);       // false at end of input
   void hcomp(Writer* out2);                 // the block header (hsize .. HCOMP END), as stored
   bool findFilename(Writer* filename = 0);  // false at the end of the block
@@ -139,7 +139,7 @@ class Decompresser {
   bool pcomp(Writer* out2);                 // the PCOMP section (size, program); behind a context model the head of the stream is decoded for it
   void readSegmentEnd(char* sha1string = 0);// [0] = 1 if a SHA-1 follows in [1..20], else 0
   int stat(int) { return 0; }               // the reference reports predictor statistics here (debug builds only)
-  int buffered() { return 0; }
+  int buffered();                           // bytes read from the Reader and not consumed yet (the look-ahead of decompress())
  private:
   struct Impl;
   Impl* d_;
