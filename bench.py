@@ -652,14 +652,15 @@ def main_text_m2(a, rank, world, local, dev):
     # both leave most of the chip idle at times -- three steps on three engine contexts overlap them (measured per
     # step: 777 ms with two, 732 with three, 739 with four)
     depth = max(1, a.pipeline if a.pipeline is not None else 3)
-    engines = [Engine(local) for _ in range(depth)]
+    engines = [Engine(local)]          # the others are created after one job has been timed alone (single_job)
     eng = engines[0]
     blocks = text_blocks_dev(dev, a.text_bytes, rank)
     nb = len(blocks)
     total = sum(n for _, n in blocks)
     caps = [(eng.block_bound(n, b"", b"") + 63) & ~63 for _, n in blocks]
     ctxs = []
-    for e_ in engines:
+
+    def add_ctx(e_):
         outs_ = torch.zeros(sum(caps), dtype=torch.uint8, device=dev)
         jobs_ = (E.BlockJob * nb)()
         p_out = 0
@@ -669,6 +670,7 @@ def main_text_m2(a, rank, world, local, dev):
             jobs_[k].out = outs_.data_ptr() + p_out; jobs_[k].out_cap = caps[k]
             p_out += caps[k]
         ctxs.append((e_, jobs_, outs_))
+    add_ctx(eng)
     jobs, outs = ctxs[0][1], ctxs[0][2]
     torch.cuda.synchronize()
 
@@ -713,9 +715,22 @@ def main_text_m2(a, rank, world, local, dev):
             e_.sync()
     steps = a.steps if a.steps is not None else 6
     warm = a.warmup if a.warmup is not None else 1
-    stagger = 0.0
-    for c in range(depth):              # one untimed step per context sizes its scratch; the last one gives the stagger
-        t_ = time.perf_counter(); step(c); stagger = time.perf_counter() - t_
+    # one job alone with one context alive (sizing step, warm step, two timed ones): the one-archive figure, and the kernel
+    # durations the roofline is computed from
+    step(0); step(0)
+    eng.profile(not a.no_kernel_timing)
+    ts, ob_ = [], 0
+    for _ in range(2):
+        barrier(); t_ = time.perf_counter(); ob_ = step(0); barrier(); ts.append(time.perf_counter() - t_)
+    kern_alone, n_alone = eng.profile_report(), len(ts)
+    eng.profile(False)
+    stagger = min(ts)
+    single = {"ms": round(min(ts) * 1e3, 3), "value": round(ob_ / 1e6 / min(ts), 3), "unit": "MB/s", "runs_ms": [round(t * 1e3, 1) for t in ts],
+              "contexts_alive": 1, "note": "one whole job with nothing else on the chip; its floor is the SHA-1 of a 64 MiB block on one wave (~0.87 s)"}
+    for c in range(1, depth):           # the other contexts; one untimed step each sizes its scratch
+        engines.append(Engine(local))
+        add_ctx(engines[-1])
+        step(c)
     run_steps(warm)
     for e_ in engines:
         e_.profile(not a.no_kernel_timing)
@@ -742,13 +757,28 @@ def main_text_m2(a, rank, world, local, dev):
                "sa_lcp_kernel": total * (1 + 4 + 4) + 2 * total, "lz77_sa_walk_kernel": 16 * total, "sha1_chain_kernel": total}
         sa_ms = sum(m for k_, (c_, m) in kern.items() if k_.startswith("sa_")) / steps
 
-        def roof(k):
-            cnt, ms = kern[k]
-            ach = alg[k] / 1e9 / (ms / steps / 1e3)
-            return {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": None, "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": round(cnt / steps, 2),
-                    "algorithmic_bytes_per_step": int(alg[k]), "ms_per_step": round(ms / steps, 3)}
-        dom = max((k for k in kern if k in alg), key=lambda k: kern[k][1], default=None)
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", "traffic_text_m2.json")      # PMC bytes per launch (tools/gpu_traffic.sh, profiles/summarize.py)
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("bytes_per_launch", {})
+
+        def roof(k, src=None, nsteps=None, how=None):
+            src = kern if src is None else src
+            nsteps = steps if nsteps is None else nsteps
+            cnt, ms = src[k]
+            ach = alg[k] / 1e9 / (ms / nsteps / 1e3)
+            r = {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                 "traffic": traffic.get(k), "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": round(cnt / nsteps, 2),
+                 "algorithmic_bytes_per_step": int(alg[k]), "ms_per_step": round(ms / nsteps, 3)}
+            if traffic.get(k):
+                r["traffic_over_algorithmic"] = round(traffic[k] * (cnt / nsteps) / alg[k], 3)
+            if how:
+                r["measured"] = how
+            return r
+        # `roofline`: the chip-filling kernel with the most time in a job that ran alone; the block checksum chain (one wave per
+        # 64 MiB block: what bounds one job's latency) is `roofline_longest_chain`
+        how = "one job alone, %d runs (single_job)" % n_alone
+        dom = max((k for k in kern_alone if k in alg and k != "sha1_chain_kernel"), key=lambda k: kern_alone[k][1], default=None)
         res = {"metric": "MB/s compressed output at -m2 (LZ77 over a suffix array), %d bytes of text in 64 MiB - 4 KiB blocks" % total,
                "value": round(out_bytes / 1e6 / sec, 3), "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
@@ -756,9 +786,13 @@ def main_text_m2(a, rank, world, local, dev):
                "config": {"workload": "text_m2", "input_bytes": total * world, "blocks": nb * world, "block_bytes": bs,
                           "method": "2 -> x6,1,4,0,7,27,1", "ratio": round(out_bytes / (total * world), 4)},
                "input_GBps": round(total * world / 1e9 / sec, 3), "steps_in_flight": depth, "ms_per_step_serial": round(stagger * 1e3, 3),
+               "single_job": single,
                "suffix_array_ms_per_step": round(sa_ms, 2),
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof(dom) if dom else None,
+               "kernels_ms_per_job_alone": {k: round(v[1] / n_alone, 3) for k, v in sorted(kern_alone.items(), key=lambda kv: -kv[1][1])},
+               "roofline": roof(dom, kern_alone, n_alone, how) if dom else None,
+               "roofline_in_flight": roof(dom) if dom and dom in kern else None,
+               "roofline_longest_chain": roof("sha1_chain_kernel", kern_alone, n_alone, how) if "sha1_chain_kernel" in kern_alone else None,
                **({"roofline_all": [roof(k) for k in sorted((k for k in kern if k in alg), key=lambda k: -kern[k][1])]} if a.roofline_all else {})}
         if world == 1 and not a.no_verify:
             # every block back through the device decoder (stored SHA-1 checked), bytes compared with the input
@@ -933,10 +967,10 @@ def compact_line(d, top=6):
     out.update({k: v for k, v in d.items() if k.startswith("verified") or k.endswith("_failures") or k == "method_expansion_checked"})
     if "config" in d:
         out["config"] = {k: v for k, v in d["config"].items() if k in ("workload", "input_bytes", "files", "blocks", "method", "ratio", "unique_bytes", "out_bytes")}
-    for rk in ("roofline", "roofline_chip_filling"):
+    for rk in ("roofline", "roofline_in_flight", "roofline_longest_chain"):
         r = d.get(rk)
         if r:
-            out[rk] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "waves") if k in r}
+            out[rk] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "avg_launch_ms", "launches_per_step", "ms_per_step", "waves", "measured") if k in r}
     if d.get("roofline_end_to_end"):
         out["roofline_end_to_end"] = {k: d["roofline_end_to_end"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_step")}
     if d.get("kernels_ms_per_step"):
@@ -944,7 +978,7 @@ def compact_line(d, top=6):
     cb = d.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
-    for k in ("blake3_verify", "no_fold", "every_byte_hashed"):
+    for k in ("blake3_verify", "no_fold", "every_byte_hashed", "twin_fold_on", "single_job"):
         if isinstance(d.get(k), dict):
             out[k] = {kk: vv for kk, vv in d[k].items() if kk != "note"}
     return out
@@ -1058,9 +1092,11 @@ def main():
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run bit-identity check against the oracle")
-    ap.add_argument("--no-twins", action="store_true",
-                    help="add workloads: no twin-file fold -- every file is fragmented and hashed even when its bytes equal an earlier file's "
-                         "(the default run reports this variant beside the headline as 'every_byte_hashed')")
+    ap.add_argument("--twins", action="store_true",
+                    help="timed region WITH the twin-file fold (files whose bytes equal an earlier file's are found by comparison and take its "
+                         "fragment records).  Default since round 5: fold OFF in the timed region -- every byte goes through the fragment loop "
+                         "and SHA-1, as in Jidac::add -- and the fold's figure is reported beside it as 'twin_fold_on' / 'value_twin_fold'")
+    ap.add_argument("--no-twins", action="store_true", help="(the default; kept for older command lines)")
     a = ap.parse_args()
     run_all = a.workload in (None, "all")
     if run_all:
@@ -1098,7 +1134,7 @@ def main():
         if a.scale != 1.0:
             cmd += ["--scale", str(a.scale)]
         for flag, on in (("--no-cpu-baseline", a.no_cpu_baseline), ("--no-verify", a.no_verify), ("--no-kernel-timing", a.no_kernel_timing),
-                         ("--no-twins", a.no_twins)):
+                         ("--twins", a.twins)):
             if on:
                 cmd.append(flag)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -1112,8 +1148,8 @@ def main():
             sys.stderr.write("[bench.py] %s: %s\n" % (w, json.dumps(d)))
         # order matters to a reader who only sees the END of the line: details first, then the headline's own roofline /
         # cpu_baseline, the every-byte-hashed figure and one row per workload
-        tail = {k: res.pop(k) for k in ("roofline_chip_filling", "roofline_longest_chain", "roofline_end_to_end", "roofline", "cpu_baseline",
-                                         "every_byte_hashed") if k in res}
+        tail = {k: res.pop(k) for k in ("roofline_in_flight", "roofline_longest_chain", "roofline_end_to_end", "roofline", "cpu_baseline",
+                                         "single_job", "every_byte_hashed", "twin_fold_on", "value_twin_fold") if k in res}
         res["workloads"] = {w: compact_line(d) for w, d in others.items()}
         res.update(tail)
         if "every_byte_hashed" in res:
@@ -1176,14 +1212,18 @@ def main():
         depth = max(1, min(depth, int((free_b - (24 << 30)) // (16 << 30))))
     # `pipeline` steps in flight on as many engine contexts and threads; with several ranks the collectives of the
     # steps in flight are issued in one fixed order on every rank (CollectiveOrder)
-    engines, pipes = [], []
-    for k_ in range(depth):
-        engines.append(eng if k_ == 0 else Engine(local))
-        pipes.append(Pipeline(engines[-1], dev, layout, rank, world, a.force_collectives))
-    for p_ in pipes:
+    # ... created AFTER one job has been timed with a single context alive (`single_job`: idle contexts oversubscribe the
+    # hardware queues and cost a lone job what they give the twelve)
+    engines, pipes = [eng], []
+
+    def add_pipe(e_):
+        p_ = Pipeline(e_, dev, layout, rank, world, a.force_collectives)
         p_.no_block_sha1 = a.no_block_sha1
-        p_.use_twins = not a.no_twins
+        p_.use_twins = a.twins
         p_.balance_blocks = shared and world > 1      # one corpus over several ranks: the d blocks are dealt out, not left to rank 0
+        pipes.append(p_)
+        return p_
+    add_pipe(eng)
     ex_pipe = None
     if a.workload == "extract_m1":
         import hashlib
@@ -1192,16 +1232,24 @@ def main():
         pipes[0].step()                                     # the archive to extract (untimed)
         sha = [hashlib.sha256(b).digest() for _, b in corpus]
         ex_pipe = ExtractPipeline(eng, dev, pipes[0], layout, sha * a.copies)
-        ex_pipe.use_twins = not a.no_twins
+        ex_pipe.use_twins = not a.no_twins          # (extract keeps its fold of equal restored files unless --no-twins)
         layout["data"] = None; del pipes[0].verify_blocks  # the originals are not needed any more
         for p_ in pipes:
             p_.data = None
         torch.cuda.empty_cache()
         # several extract jobs in flight (own context, own output): a job is as long as its longest serial chain -- the
         # SHA-256 of the 51 MB member on one wave, the SHA-1 of a 16 MiB block -- and leaves most of the chip idle
-        runners = [ex_pipe] + [ex_pipe.clone_for(e_) for e_ in engines[1:]]
+        runners = [ex_pipe]
     else:
         runners = pipes
+
+    def more_contexts():
+        for _ in range(1, depth):
+            engines.append(Engine(local))
+            if ex_pipe is not None:
+                runners.append(ex_pipe.clone_for(engines[-1]))
+            else:
+                add_pipe(engines[-1])
 
     def barrier():
         if dist.is_initialized():
@@ -1252,12 +1300,28 @@ def main():
 
     stagger = [0.0]
     last_pipe = [runners[0]]     # the context that ran the last step (its results are the ones dumped / verified)
-    if depth > 1 and len(runners) > 1:            # one untimed serial step per context sizes its scratch; a second, warm one gives the stagger
-        for p_ in runners:
+    single, kern_alone, n_alone = None, {}, 0
+    if depth > 1:
+        # ONE JOB ALONE, one context alive: the one-archive figure (ZSFX/zsfx.cpp:2147-2148: one process, one archive) and the
+        # kernel durations `roofline` is computed from (a kernel's time beside eleven other jobs is a latency under
+        # contention, not what the kernel does on the chip).  Sizing step, warm step, then two timed ones.
+        one = (lambda: runners[0].step(None, 0, False)) if ex_pipe is None else (lambda: runners[0].step())
+        one(); one()
+        eng.profile(not a.no_kernel_timing)
+        ts, ob_ = [], 0
+        for _ in range(2):
+            barrier(); t_ = time.perf_counter(); ob_ = one(); barrier(); ts.append(time.perf_counter() - t_)
+        kern_alone, n_alone = eng.profile_report(), len(ts)
+        eng.profile(False)
+        stagger[0] = min(ts)
+        single = {"ms": round(min(ts) * 1e3, 3), "value": round(ob_ / 1e6 / min(ts), 3), "unit": "MB/s", "runs_ms": [round(t * 1e3, 1) for t in ts],
+                  "contexts_alive": 1,
+                  "note": "one whole job with nothing else on the chip: the one-archive latency; its floor is the longest serial chain "
+                          "(add: SHA-1 of a 16 MiB d block on one wave, 406 instructions per 64 bytes at 4 cycles = ~215 ms; extract: "
+                          "SHA-256 of the longest file)"}
+        more_contexts()
+        for p_ in runners[1:]:         # one untimed serial step per further context sizes its scratch
             p_.step()
-        for _ in range(2):        # one job alone, twice (the first still pays for scratch the sizing steps of the OTHER contexts freed): the shorter counts
-            t_ = time.perf_counter(); runners[0].step(); d_ = time.perf_counter() - t_
-            stagger[0] = d_ if not stagger[0] else min(stagger[0], d_)
     run_steps(warm)
     for e_ in engines:
         e_.profile(not a.no_kernel_timing)
@@ -1319,20 +1383,30 @@ def main():
             metric = ("MB/s compressed output (bit-identical .zpaq) at -m1, Silesia x%d" % a.copies) if a.workload == "silesia_x256_m1" else \
                      ("MB/s compressed output (bit-identical .zpaq) at -m1, %d unique 16 MiB units x%d duplication per GPU" % (a.units, a.dup))
         traffic = {}
-        tf = os.path.join(ROOT, "profiles", "traffic.json")     # PMC bytes per launch from the last rocprofv3 --pmc run
-        if os.path.exists(tf) and a.workload == "silesia_x256_m1":
+        # PMC bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) from the rocprofv3 --pmc passes of this workload (tools/gpu_traffic.sh,
+        # profiles/summarize.py): profiles/traffic.json for the headline, traffic_<workload>.json for the others
+        tf = os.path.join(ROOT, "profiles", "traffic.json" if a.workload == "silesia_x256_m1" else "traffic_%s.json" % a.workload)
+        if os.path.exists(tf):
             traffic = json.load(open(tf)).get("bytes_per_launch", {})
+        traffic_key = {"sha1_extents_kernel": "sha1_extents_staged_kernel"}     # (names the kernel trace gives to what the event scopes call ...)
 
-        def roof(k):
-            cnt, ms = kern[k]
+        def roof(k, src=None, nsteps=None, how=None):
+            src = kern if src is None else src
+            nsteps = steps if nsteps is None else nsteps
+            cnt, ms = src[k]
             per = ms / cnt
             ab = alg.get(k)          # algorithmic bytes of the kernel per STEP (a step may launch it more than once)
             if not ab:
                 return None
-            ach = ab / 1e9 / (ms / steps / 1e3)
+            ach = ab / 1e9 / (ms / nsteps / 1e3)
+            tr = traffic.get(k, traffic.get(traffic_key.get(k, k)))
             r = {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(k), "avg_launch_ms": round(per, 4),
-                 "launches_per_step": round(cnt / steps, 2), "algorithmic_bytes_per_step": int(ab), "ms_per_step": round(ms / steps, 3)}
+                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tr, "avg_launch_ms": round(per, 4),
+                 "launches_per_step": round(cnt / nsteps, 2), "algorithmic_bytes_per_step": int(ab), "ms_per_step": round(ms / nsteps, 3)}
+            if tr:
+                r["traffic_over_algorithmic"] = round(tr * (cnt / nsteps) / ab, 3)
+            if how:
+                r["measured"] = how
             if k in VALU_OPS_PER_BYTE:
                 ceil = LANE_OPS_PER_S / VALU_OPS_PER_BYTE[k] / 1e9
                 r["integer_issue_ceiling_GBps"] = round(ceil, 1)
@@ -1341,18 +1415,21 @@ def main():
                 r["waves"] = int(waves[k])
                 r["note"] = "serial chain(s): %d waves of 1024 SIMDs; one instruction per ~4 cycles per wave" % waves[k]
             return r
-        # `roofline` is the kernel with the most GPU time per step, whatever its wave count (on the folded corpus that is a
-        # serial chain of a few waves: block checksums or LZ77 segments -- what bounds one job's latency); the chip-filling
-        # kernel with the most time is reported beside it as roofline_chip_filling
+        # `roofline` = the CHIP-FILLING kernel with the most time per step, from the durations of a job that ran ALONE (HIP
+        # events on the kernel's own stream, `single_job`): a kernel time that fits inside ms_per_step, not a latency stretched
+        # by eleven other jobs.  `roofline_in_flight` = the same kernel's events in the timed region (what contention does to
+        # it); `roofline_longest_chain` = the few-wave kernel with the most time alone (block checksum chains: what bounds ONE
+        # job's latency, not the chip's throughput).  With one step in flight (dup8) the timed region IS the job alone.
         simds = 1024
-        fill = [k for k in kern if alg.get(k) and waves.get(k, simds) >= simds]
-        chains = [k for k in kern if alg.get(k) and waves.get(k, simds) < simds]
-        dom = max((k for k in kern if alg.get(k)), key=lambda k: kern[k][1], default=None)
-        roof_dom = roof(dom) if dom else None
-        dom_fill = max(fill, key=lambda k: kern[k][1], default=None)
-        roof_fill = roof(dom_fill) if dom_fill else None
-        roof_chain = roof(max(chains, key=lambda k: kern[k][1])) if chains else None
-        roof_all = [r for r in (roof(k) for k in sorted(kern, key=lambda k: -kern[k][1])) if r] if a.roofline_all else None
+        base, nbase = (kern_alone, n_alone) if kern_alone else (kern, steps)
+        how = ("one job alone, %d runs (single_job)" % n_alone) if kern_alone else "the timed region (one step in flight)"
+        fill = [k for k in base if alg.get(k) and waves.get(k, simds) >= simds]
+        chains = [k for k in base if alg.get(k) and waves.get(k, simds) < simds]
+        dom_fill = max(fill, key=lambda k: base[k][1], default=None)
+        roof_dom = roof(dom_fill, base, nbase, how) if dom_fill else None
+        roof_fill = roof(dom_fill) if (dom_fill and kern_alone and dom_fill in kern) else None
+        roof_chain = roof(max(chains, key=lambda k: base[k][1]), base, nbase, how) if chains else None
+        roof_all = [r for r in (roof(k, base, nbase, how) for k in sorted(base, key=lambda k: -base[k][1])) if r] if a.roofline_all else None
         e2e = alg_step / 1e9 / sec
         res = {"metric": metric, "value": round(out_bytes / 1e6 / sec, 3),
                "unit": "MB/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(sec * 1e3, 3),
@@ -1364,9 +1441,10 @@ def main():
                "identity": "per d block and per table: every block, fragment boundary, SHA-1 and the dedup map equal the reference-derived oracle; "
                            "whole-archive identity is not provable here (block cut rule, R,t hint and file order of the missing zpaqfranz.cpp are unpinned)",
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
-               "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),
+               "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),      # = single_job.ms
                "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-               "roofline": roof_dom, "roofline_chip_filling": roof_fill, "roofline_longest_chain": roof_chain,
+               "roofline": roof_dom, "roofline_in_flight": roof_fill, "roofline_longest_chain": roof_chain, "single_job": single,
+               **({"kernels_ms_per_job_alone": {k: round(v[1] / n_alone, 3) for k, v in sorted(kern_alone.items(), key=lambda kv: -kv[1][1])}} if kern_alone else {}),
                **({"roofline_all": roof_all} if roof_all else {}),
                "roofline_end_to_end": {"bound": "hbm", "achieved": round(e2e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 5),
                                        "algorithmic_bytes_per_step": int(alg_step),
@@ -1412,22 +1490,33 @@ def main():
                                     note="files whose bytes equal an earlier file's are found by comparing every byte on the device (HBM-bound) "
                                          "before anything is hashed; only the representatives go through the fragment loop and SHA-1, twins take "
                                          "their records: identical tables for any input (zpq_fragment_sha1_dev, csrc/twins.hip)")
-        if a.workload == "silesia_x256_m1" and pipe.use_twins and world == 1 and not a.force_collectives and not a.dump_archive and not os.environ.get("ZPQ_BENCH_NO_PLAIN"):
-            # the same job with the fold off: all 54 GB through the fragment loop and SHA-1 (what every round before measured)
+        if (a.workload == "silesia_x256_m1" and world == 1 and not a.force_collectives and not a.dump_archive
+                and not (os.environ.get("ZPQ_BENCH_NO_VARIANT") or os.environ.get("ZPQ_BENCH_NO_PLAIN"))):
+            # the same job with the twin fold the other way round: by default that is fold ON (files equal to an earlier file are
+            # found by comparing every byte and take its records: the corpus-shaped optimisation, reported beside the headline)
+            main_fold = pipes[0].use_twins
             for p_ in pipes:
-                p_.use_twins = False
+                p_.use_twins = not main_fold
             try:
                 run_steps(len(pipes))
                 barrier(); tb = time.perf_counter()
                 n2 = max(2 * len(pipes), min(steps, 24))      # (at least two rounds of every context: a steady state, not one job's latency)
                 ob2 = run_steps(n2)
                 barrier(); sec2 = (time.perf_counter() - tb) / n2
-                res["every_byte_hashed"] = {"ms_per_step": round(sec2 * 1e3, 3), "value": round(ob2 / 1e6 / sec2, 3), "unit": "MB/s", "steps": n2,
-                                            "input_GBps": round(in_bytes / 1e9 / sec2, 3),
-                                            "note": "twin fold off (--no-twins): every file fragmented and SHA-1'd; same tables, same blocks"}
+                var = {"ms_per_step": round(sec2 * 1e3, 3), "value": round(ob2 / 1e6 / sec2, 3), "unit": "MB/s", "steps": n2,
+                       "input_GBps": round(in_bytes / 1e9 / sec2, 3)}
+                if main_fold:
+                    res["every_byte_hashed"] = dict(var, note="twin fold off: every file fragmented and SHA-1'd; same tables, same blocks")
+                else:
+                    tws = pipes[0].twin_stats or {}
+                    res["twin_fold_on"] = dict(var, **{k: tws[k] for k in ("twins", "twin_bytes") if k in tws},
+                                               note="same job with the twin fold (--twins): files whose bytes equal an earlier file's are found by "
+                                                    "comparing every byte on the device and take its fragment records; same tables, same blocks; "
+                                                    "corpus-shaped (x256 replication), hence not the headline")
+                    res["value_twin_fold"] = var["value"]
             finally:
                 for p_ in pipes:
-                    p_.use_twins = True
+                    p_.use_twins = main_fold
         if world == 1 and not a.no_cpu_baseline:
             base = b"".join(b for _, b in corpus)
             if a.workload == "silesia_x256_m1":
