@@ -151,7 +151,7 @@ def silesia_layout(dev, corpus, copies):
     for c in range(copies):
         for s in sizes:
             off.append(off[-1] + s)
-    return dict(data=data, file_off=off, total=total, unit=unit, sizes=sizes, copies=copies, kind="silesia")
+    return dict(data=data, file_off=off, total=total, unit=unit, sizes=sizes, copies=copies, kind="silesia", names=[n for n, _ in corpus])
 
 
 UNIT = 1 << 24
@@ -210,8 +210,34 @@ class Pipeline:
         self.twin_stats = None
         torch.cuda.synchronize()
 
+    VERSION_DATE = 20240101000000
+
+    def file_names(self):
+        """names in the order the files lie in HBM, ascending (what zpqj_add_dev asks for)"""
+        L = self.layout
+        if L["kind"] == "silesia":
+            return ["c%04d/%s" % (c, n) for c in range(L["copies"]) for n in L["names"]]
+        return ["f%06d" % i for i in range(self.nfiles)]
+
+    def step_product(self, keep=True):
+        """One C-ABI call: zpqj_add_dev (shim/jidac_gpu.cpp) -- device-resident files in, the whole journaling archive (c, d, h, i
+        blocks) out; the product's own orchestration of what step() does call by call.  Returns the archive's length."""
+        E = self.E
+        if getattr(self, "devfiles", None) is None:
+            self.devfiles = E.DevFiles(self.file_names(), self.file_off, version_date=self.VERSION_DATE)
+        ptr, n, st = E.jidac_add_dev(self.eng, b"", self.data.data_ptr(), self.devfiles, self.VERSION_DATE, "14", twins=self.use_twins, raw=True)
+        try:
+            self.archive = C.string_at(ptr, n) if keep else None
+        finally:
+            E.load_shim().zpqj_free(C.c_void_p(ptr))
+        self.stats = dict(fragments=st["fragments"], unique_fragments=st["new_fragments"], blocks=st["d_blocks"], unique_bytes=st["unique_bytes"],
+                          out_bytes=int(n), d_bytes=st["d_bytes"])
+        return int(n)
+
     def step(self, order=None, idx=0, keep=True):
         """keep: hold on to the block inputs / outputs of this step for the verification (costs their memory until the next step)"""
+        if getattr(self, "product", False):
+            return self.step_product(keep)
         self.keep_outputs = keep
         if not keep:
             self.verify_blocks = None
@@ -473,6 +499,95 @@ def verify_add(pipe, layout, corpus, threads):
         oks = list(ex.map(blk, range(nb)))
     res["verified_all_blocks"] = bool(all(oks))
     res["verified_blocks"] = "%d of %d" % (sum(oks), nb)
+    return res
+
+
+def split_archive(arc):
+    """[(name, comment, start, end, payload bytes)] of the blocks of a journaling archive whose blocks have no context model
+    (stored sub-blocks): tag, zPQ level type, header, 1 name 0 comment 0 0, {len[4] bytes}... 0[4], 253 sha1[20] | 254, 255."""
+    out, p, n = [], 0, len(arc)
+    while p < n:
+        s0 = p
+        assert arc[p + 13:p + 16] == b"zPQ", "no block at %d" % p
+        hs = arc[p + 18] | arc[p + 19] << 8
+        assert arc[p + 24] == 0, "block with a context model"
+        p += 20 + hs
+        assert arc[p] == 1
+        e = arc.index(b"\0", p + 1); name = arc[p + 1:e]
+        e2 = arc.index(b"\0", e + 1); comment = arc[e + 1:e2]
+        p = e2 + 2
+        pay = bytearray()
+        while True:
+            k = int.from_bytes(arc[p:p + 4], "big"); p += 4
+            if not k:
+                break
+            pay += arc[p:p + k]; p += k
+        p += 21 if arc[p] == 253 else 1
+        assert arc[p] == 255
+        p += 1
+        out.append((name, comment, s0, p, bytes(pay)))
+    return out
+
+
+def verify_product(pipe, archive, threads):
+    """The archive zpqj_add_dev returned in the timed region against (a) the call-by-call orchestration of the same job (pipe.last /
+    pipe.verify_blocks, which verify_add checks against the oracle): its d blocks byte for byte, its h blocks = the fragment
+    ids and sizes, its i blocks = every file's name and pointer list; (b) the REAL reference decoder, which walks every c, h
+    and i block (the d blocks are the bytes of (a))."""
+    import orc
+    res = {}
+    blocks = split_archive(archive)
+    kinds = "".join(chr(b[0][17]) for b in blocks)
+    nb = kinds.count("d")
+    res["archive_blocks"] = {k: kinds.count(k) for k in "cdhi"}
+    ok_layout = kinds == "c" + "d" * nb + "h" * nb + "i" * kinds.count("i") and kinds.count("i") >= 1
+    want = pipe.framed_blocks()
+    got_d = [archive[b[2]:b[3]] for b in blocks if chr(b[0][17]) == "d"]
+    res["verified_product_d_blocks"] = bool(ok_layout and len(want) == len(got_d) and all(w[1] == g for w, g in zip(want, got_d)))
+    # reference decoder over the index blocks
+    ok_ref = True
+    if orc.have_ref():
+        for b in blocks:
+            if chr(b[0][17]) == "d":
+                continue
+            r = orc.ref_decompress_block(archive[b[2]:b[3]], len(b[4]) * 8 + 65536)
+            ok_ref = ok_ref and r["sha1_ok"] == 1 and r["consumed"] == b[3] - b[2] and r["filename"] == b[0]
+    res["verified_index_blocks_by_reference_decoder"] = bool(ok_ref and orc.have_ref())
+    L = pipe.last
+    nf, first, lens, P = L["nf"], L["first"][:L["nf"]].astype(np.int64), L["lens"], L["plan"]
+    uniq = P["uniq_idx"]
+    fid = np.zeros(nf, dtype=np.int64); fid[uniq] = 1 + np.arange(len(uniq)); fid = fid[first]      # fragment id of every file fragment
+    dig = pipe.digests[: nf * 20].cpu().numpy().reshape(nf, 20)
+    # c block: the d blocks' bytes; h blocks: bsize + (sha1, usize) per fragment of its d block
+    cb = [b for b in blocks if chr(b[0][17]) == "c"][0]
+    ok = ok_layout and int.from_bytes(orc.ref_decompress_block(archive[cb[2]:cb[3]], 65536)["data"] if orc.have_ref() else b"", "little") == sum(len(g) for g in got_d)
+    st = P["starts"]
+    hb = [b for b in blocks if chr(b[0][17]) == "h"]
+    for k, b in enumerate(hb):
+        body = orc.ref_decompress_block(archive[b[2]:b[3]], len(b[4]) * 2 + 65536)["data"] if orc.have_ref() else b""
+        u = uniq[st[k]:st[k + 1]]
+        wantb = len(got_d[k]).to_bytes(4, "little") + b"".join(bytes(dig[i]) + int(lens[i]).to_bytes(4, "little") for i in u.tolist())
+        ok = ok and body == wantb and int(b[0][18:]) == int(st[k]) + 1
+    res["verified_product_h_blocks"] = bool(ok)
+    # i blocks: date[8] name 0 na[4] attr ni[4] ptr[ni][4] per file, in name order
+    names = pipe.file_names()
+    ffile = pipe.frag_file[:nf].cpu().numpy()
+    bounds = np.searchsorted(ffile, np.arange(pipe.nfiles + 1))
+    ok, f = True, 0
+    for b in blocks:
+        if chr(b[0][17]) != "i":
+            continue
+        body = orc.ref_decompress_block(archive[b[2]:b[3]], 1 << 22)["data"] if orc.have_ref() else b""
+        q = 0
+        while q < len(body) and ok:
+            e = body.index(b"\0", q + 8)
+            na = int.from_bytes(body[e + 1:e + 5], "little")
+            ni = int.from_bytes(body[e + 5 + na:e + 9 + na], "little")
+            ptr = np.frombuffer(body, dtype="<u4", count=ni, offset=e + 9 + na)
+            ok = f < pipe.nfiles and body[q + 8:e].decode() == names[f] and np.array_equal(ptr.astype(np.int64), fid[bounds[f]:bounds[f + 1]])
+            q = e + 9 + na + 4 * ni
+            f += 1
+    res["verified_product_i_blocks"] = bool(ok and f == pipe.nfiles)
     return res
 
 
@@ -1088,6 +1203,9 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="test only: every rank uses GPU 0 (with --dist-backend gloo)")
     ap.add_argument("--force-collectives", action="store_true", help="single rank: run the multi-rank code path (RCCL all-gathers with world size 1)")
     ap.add_argument("--dump-archive", default=None, help="test only: rank 0 writes the stitched d blocks of the last step to this file")
+    ap.add_argument("--python-pipeline", action="store_true",
+                    help="add workloads, one rank: time the call-by-call orchestration in Python (fragment -> dedup -> plan -> gather -> "
+                         "compressBlock, d blocks only) instead of the product's one-call zpqj_add_dev (the default: whole archive incl. c/h/i)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
@@ -1215,12 +1333,15 @@ def main():
     # ... created AFTER one job has been timed with a single context alive (`single_job`: idle contexts oversubscribe the
     # hardware queues and cost a lone job what they give the twelve)
     engines, pipes = [eng], []
+    # one rank: the timed step is ONE C-ABI call of the product, zpqj_add_dev (files resident in HBM in, c/d/h/i archive out)
+    product = a.workload in ("silesia_x256_m1", "dup8_m1") and world == 1 and not a.force_collectives and not a.python_pipeline
 
     def add_pipe(e_):
         p_ = Pipeline(e_, dev, layout, rank, world, a.force_collectives)
         p_.no_block_sha1 = a.no_block_sha1
         p_.use_twins = a.twins
         p_.balance_blocks = shared and world > 1      # one corpus over several ranks: the d blocks are dealt out, not left to rank 0
+        p_.product = product
         pipes.append(p_)
         return p_
     add_pipe(eng)
@@ -1336,6 +1457,15 @@ def main():
         for k_, (c_, m_) in e_.profile_report().items():
             kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
         e_.profile(False)
+    product_stats, product_archive = None, None
+    if product and isinstance(pipe, Pipeline):
+        # the same job once more through the call-by-call orchestration (untimed): its tables and d blocks are what verify_add
+        # checks against the oracle, and what the archive the product returned in the timed region is compared with
+        product_stats, product_archive = dict(pipe.stats), pipe.archive
+        pipe.product = False
+        pipe.step()
+        pipe.product = True
+        pipe.stats = dict(pipe.stats, out_bytes=product_stats["out_bytes"], d_bytes=product_stats["d_bytes"])
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1438,6 +1568,8 @@ def main():
                           **({"corpus": "one Silesia x%d split by file range over %d ranks" % (a.copies, world)} if shared else {}),
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
+               "timed_step": ("one C-ABI call: zpqj_add_dev (files resident in HBM in, whole journaling archive -- c, d, h, i blocks -- out to host memory)"
+                              if product else "call-by-call orchestration in bench.py (d blocks only)"),
                "identity": "per d block and per table: every block, fragment boundary, SHA-1 and the dedup map equal the reference-derived oracle; "
                            "whole-archive identity is not provable here (block cut rule, R,t hint and file order of the missing zpaqfranz.cpp are unpinned)",
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
@@ -1485,6 +1617,8 @@ def main():
                 res["verified_all_blocks"] = True           # every d block decoded with its stored SHA-1 matching (step() raises otherwise)
             else:
                 res.update(verify_add(pipe, layout, corpus, threads))
+                if product_archive is not None:
+                    res.update(verify_product(pipe, product_archive, threads))
         if not extract:
             res["twin_fold"] = dict(enabled=bool(pipe.use_twins), **(pipe.twin_stats or {}),
                                     note="files whose bytes equal an earlier file's are found by comparing every byte on the device (HBM-bound) "

@@ -72,6 +72,12 @@ int zpq_profile_report(zpq_ctx* ctx, char* buf, size_t cap);
 /* ---- device memory helpers (for hosts without their own allocator) ------------------------ */
 int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr);
 int zpq_dev_free(zpq_ctx* ctx, void* dptr);
+/* The same, but the block goes back to the CONTEXT and is handed out again by the next call it fits (blocks up to 1 GiB,
+ * at most 6 GiB idle per context; zpq_destroy releases them): hipFree waits for the whole device, which a job running
+ * beside eleven others cannot afford per call -- the reference's counterpart is the StringBuffer a compress job keeps
+ * (ZSFX/libzpaq.h:1377-1494).  One job at a time per context, like every call on a context. */
+int zpq_dev_alloc_pooled(zpq_ctx* ctx, size_t bytes, void** dptr);
+int zpq_dev_free_pooled(zpq_ctx* ctx, void* dptr);
 int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes);

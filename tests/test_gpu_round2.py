@@ -443,6 +443,67 @@ def test_jidac_add_multi_is_identical_to_single_context(eng):
             e.close()
 
 
+def test_jidac_add_dev_equals_the_host_pointer_add(eng):
+    """zpqj_add_dev (files already in HBM, back to back in name order) returns the archive zpqj_add / zpqj_add_opts return for
+    the same files from host pointers -- byte for byte: first version, a second version on top of it, with the checksum
+    attributes, with the twin fold off -- and the real reference decoder walks it; names out of order are refused."""
+    from zpaqfranz_amd import engine as E
+    shared = datagen.mixed(2 << 20, 71)
+    files = [("a/one", datagen.text_like(1200000, 72)), ("a/two", shared + datagen.binary_like(300000, 73)), ("b/three", shared),
+             ("b/three.copy", shared), ("c/empty", b""), ("d/four", datagen.mixed(2 << 20, 74)), ("e/five", datagen.random_bytes(500000, 75))]
+    assert [n for n, _ in files] == sorted(n for n, _ in files)
+
+    def resident(fs):
+        off = [0]
+        for _, d in fs:
+            off.append(off[-1] + len(d))
+        return eng.upload(b"".join(d for _, d in fs)), E.DevFiles([n for n, _ in fs], off, version_date=20240101120000)
+    buf, df = resident(files)
+    try:
+        want, st_w = E.jidac_add(eng, b"", files, 20240101120000)
+        got, st_g = E.jidac_add_dev(eng, b"", buf.ptr, df, 20240101120000)
+        assert got == want and st_g == st_w
+        plain, st_p = E.jidac_add_dev(eng, b"", buf.ptr, df, 20240101120000, twins=False)       # every byte hashed: same archive
+        assert plain == want and st_p == st_w
+        want_c, _ = E.jidac_add(eng, b"", files, 20240101120000, checksums=True, hint=True)
+        got_c, _ = E.jidac_add_dev(eng, b"", buf.ptr, df, 20240101120000, checksums=True, hint=True)
+        assert got_c == want_c and got_c != want
+        assert E.jidac_extract(eng, got) == {n: d for n, d in files}
+        # a second version on top
+        files2 = list(files) + [("g/new", datagen.text_like(300000, 76) + shared[:400000])]
+        files2[0] = ("a/one", files[0][1][:300000] + b"EDIT" + files[0][1][300000:])
+        buf2, df2 = resident(files2)
+        try:
+            df2.dates = (C.c_int64 * len(files2))(*([20240202120000] * len(files2)))
+            v2w, _ = E.jidac_add(eng, want, files2, 20240202120000)
+            v2g, _ = E.jidac_add_dev(eng, want, buf2.ptr, df2, 20240202120000)
+            assert v2g == v2w
+            assert E.jidac_extract(eng, want + v2g) == {n: d for n, d in files2}
+        finally:
+            buf2.free()
+        # names that do not ascend: refused (the buffer order would not be the order the files are walked in)
+        bad = E.DevFiles(["b", "a"], [0, 10, 20], version_date=1)
+        with pytest.raises(E.ZpqError):
+            E.jidac_add_dev(eng, b"", buf.ptr, bad, 20240101120000)
+        if orc.have_ref():
+            total = sum(len(d) for _, d in files)
+            blocks, off = [], 0
+            while off < len(got):
+                b = orc.ref_decompress_block(got[off:], total + 65536)
+                assert b["sha1_ok"] == 1
+                blocks.append(b); off += b["consumed"]
+            assert "".join(chr(b["filename"][17]) for b in blocks).startswith("cd")
+            # bench.py's own walker of such archives (verification outside its timed region) sees the same blocks
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            mine = bench.split_archive(got)
+            assert [(m[0], m[3] - m[2]) for m in mine] == [(b["filename"], b["consumed"]) for b in blocks]
+            assert all(m[4] == b"\0" + b["data"] for m, b in zip(mine, blocks) if chr(m[0][17]) in "ch")      # (method 0: the PASS byte, then the bytes)
+    finally:
+        buf.free()
+
+
 def test_jidac_rejects_hostile_archives(eng):
     from zpaqfranz_amd import engine as E, ZpqError
     files = [("x", datagen.mixed(400000, 71)), ("y", datagen.text_like(100000, 72))]

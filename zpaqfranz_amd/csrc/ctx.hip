@@ -144,6 +144,7 @@ void zpq_destroy(zpq_ctx* ctx) {
   for (int i = 0; i < ZPQ_SCRATCH_SLOTS; ++i)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (const zpq_ctx::PoolBlock& b : ctx->pool) (void)hipFree(b.p);
   (void)hipEventDestroy(ctx->ev);
   (void)hipEventDestroy(ctx->ev2);
   (void)hipStreamDestroy(ctx->stream);
@@ -224,6 +225,53 @@ int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr) {
 int zpq_dev_free(zpq_ctx* ctx, void* dptr) {
   ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZPQ_HIP(ctx, hipFree(dptr));
+  return ZPQ_OK;
+}
+// Device memory that goes back to the context instead of the driver: hipFree waits for the whole device and hipMalloc maps
+// pages, which a job that runs twelve at a time beside others cannot afford per call.  Blocks up to 1 GiB are kept (at most 6 GiB
+// per context, the largest evicted first when that is exceeded) and handed out again to requests they fit without wasting
+// more than half; zpq_destroy releases them.  Called by one job at a time per context, like everything else of a context.
+int zpq_dev_alloc_pooled(zpq_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return ZPQ_ERR_ARG;
+  ZPQ_HIP(ctx, hipSetDevice(ctx->device));
+  if (!bytes) bytes = 1;
+  size_t best = ctx->pool.size();
+  for (size_t i = 0; i < ctx->pool.size(); ++i) {
+    const zpq_ctx::PoolBlock& b = ctx->pool[i];
+    if (!b.in_use && b.cap >= bytes && b.cap / 2 <= bytes + (1u << 20) && (best == ctx->pool.size() || b.cap < ctx->pool[best].cap)) best = i;
+  }
+  if (best != ctx->pool.size()) { ctx->pool[best].in_use = true; *dptr = ctx->pool[best].p; return ZPQ_OK; }
+  const size_t cap = bytes <= ((size_t)1 << 30) ? ((bytes + bytes / 8 + 65535) & ~(size_t)65535) : bytes;
+  if (hipMalloc(dptr, cap) != hipSuccess) {
+    // make room: give the idle blocks back to the driver and try once more
+    ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = ctx->pool.size(); i-- > 0;)
+      if (!ctx->pool[i].in_use) { (void)hipFree(ctx->pool[i].p); ctx->pool.erase(ctx->pool.begin() + (long)i); }
+    if (hipMalloc(dptr, cap) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", cap);
+  }
+  if (bytes <= ((size_t)1 << 30)) ctx->pool.push_back({*dptr, cap, true});
+  return ZPQ_OK;
+}
+int zpq_dev_free_pooled(zpq_ctx* ctx, void* dptr) {
+  if (!ctx) return ZPQ_ERR_ARG;
+  if (!dptr) return ZPQ_OK;
+  size_t idle = 0;
+  bool mine = false;
+  for (zpq_ctx::PoolBlock& b : ctx->pool) {
+    if (b.p == dptr) { b.in_use = false; mine = true; }
+    if (!b.in_use) idle += b.cap;
+  }
+  if (!mine) return zpq_dev_free(ctx, dptr);          // larger than the pool keeps
+  while (idle > ((size_t)6 << 30)) {                    // over the limit: the largest idle block goes back to the driver
+    size_t big = ctx->pool.size();
+    for (size_t i = 0; i < ctx->pool.size(); ++i)
+      if (!ctx->pool[i].in_use && (big == ctx->pool.size() || ctx->pool[i].cap > ctx->pool[big].cap)) big = i;
+    if (big == ctx->pool.size()) break;
+    ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    idle -= ctx->pool[big].cap;
+    (void)hipFree(ctx->pool[big].p);
+    ctx->pool.erase(ctx->pool.begin() + (long)big);
+  }
   return ZPQ_OK;
 }
 int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {

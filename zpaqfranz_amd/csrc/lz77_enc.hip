@@ -756,14 +756,18 @@ __device__ __forceinline__ void put_match(u32* out, u64 bitpos, u32 len, u32 off
 }
 
 // One workgroup per block: scans token costs, records each token's start bit and writes run
-// headers and match codes.  Literal bytes are written by lz77_pack_literals_kernel.
+// headers, match codes and the literal bytes: a gap of up to kShortGap bytes by the thread that owns the token behind it
+// (seven bytes per OR), a longer one by the whole workgroup once the tile's tokens are placed.
+constexpr u32 kShortGap = 56;
 __global__ __launch_bounds__(1024) void lz77_pack_tokens_kernel(const LzJobDev* __restrict__ jobs) {
   const LzJobDev J = jobs[blockIdx.x];
   const u32 ntok = J.result[0];
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ u64 wsum[16];
   __shared__ u64 carry_s;
-  if (tid == 0) carry_s = 0;
+  __shared__ u32 lg_from[1024], lg_len[1024], lg_n;
+  __shared__ u64 lg_bit[1024];
+  if (tid == 0) { carry_s = 0; lg_n = 0; }
   __syncthreads();
   u32* out32 = (u32*)J.out;
   // items 0..ntok-1 = (gap before match t, match t); item ntok = trailing literal gap
@@ -796,9 +800,32 @@ __global__ __launch_bounds__(1024) void lz77_pack_tokens_kernel(const LzJobDev* 
         bp += lit_run_header_bits(r) + 8ull * r; g -= r;
       }
       if (t < ntok) put_match(out32, bp, len, off, J.rb);
+      if (gap && gap <= kShortGap) {           // (one run: kShortGap < kMaxLiteral)
+        const u64 lb = start + lit_run_header_bits(gap);
+        for (u32 j = 0; j < gap; j += 7) {
+          const u32 c = gap - j < 7 ? gap - j : 7u;
+          or_bits(out32, lb + 8ull * j, load8((g_cu8*)J.in + gstart + j) & ((1ull << (8 * c)) - 1ull), 8 * c);
+        }
+      } else if (gap) {
+        const u32 k = atomicAdd(&lg_n, 1u);
+        lg_from[k] = gstart; lg_len[k] = gap; lg_bit[k] = start;
+      }
     }
     __syncthreads();
     if (tid == 1023) carry_s = carry + wbase + x;
+    // the long gaps of this tile, one after the other, a byte per thread and round (the run structure as the headers above)
+    const u32 nlong = lg_n;
+    for (u32 e = 0; e < nlong; ++e) {
+      const u32 from = lg_from[e], g = lg_len[e]; const u64 gb = lg_bit[e];
+      for (u32 r = tid; r < g; r += 1024) {
+        const u32 run = r / kMaxLiteral, within = r % kMaxLiteral;
+        const u32 runlen = (run < g / kMaxLiteral) ? kMaxLiteral : g % kMaxLiteral;
+        const u64 bpos = gb + (u64)run * (lit_run_header_bits(kMaxLiteral) + 8ull * kMaxLiteral) + lit_run_header_bits(runlen) + 8ull * within;
+        or_bits(out32, bpos, J.in[from + r], 8);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) lg_n = 0;
     __syncthreads();
   }
   if (tid == 0) {
@@ -807,30 +834,6 @@ __global__ __launch_bounds__(1024) void lz77_pack_tokens_kernel(const LzJobDev* 
     J.result[1] = (u32)bytes;
     if (bytes > J.out_cap) J.result[2] = 1;
   }
-}
-
-// Literal bytes: one thread per input position.
-__global__ __launch_bounds__(256) void lz77_pack_literals_kernel(const LzJobDev* __restrict__ jobs) {
-  const LzJobDev J = jobs[blockIdx.y];
-  const u32 x = blockIdx.x * 256u + threadIdx.x;
-  const u32 ntok = J.result[0];
-  // wave-uniform lower bound for the first position of this wave, then a short per-lane search
-  const u32 x0 = __builtin_amdgcn_readfirstlane(x);
-  if (x0 >= J.n) return;
-  u32 lo = 0, hi = ntok;  // first token with tok_pos > x0
-  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (J.tok_pos[mid] > x0) hi = mid; else lo = mid + 1; }
-  if (x >= J.n) return;
-  u32 t = lo;
-  while (t < ntok && J.tok_pos[t] <= x) ++t;  // <= 16 steps: matches are >= 4 bytes apart
-  const u32 gstart = t ? J.tok_pos[t - 1] + J.tok_len[t - 1] : 0u;
-  if (x < gstart) return;  // inside match t-1
-  const u32 gend = t < ntok ? J.tok_pos[t] : J.n;
-  const u32 g = gend - gstart, r = x - gstart;
-  const u32 run = r / kMaxLiteral, within = r % kMaxLiteral;
-  const u32 runlen = (run < g / kMaxLiteral) ? kMaxLiteral : g % kMaxLiteral;
-  const u64 bp = (u64)J.tok_bit[t] + (u64)run * (lit_run_header_bits(kMaxLiteral) + 8ull * kMaxLiteral) +
-                 lit_run_header_bits(runlen) + 8ull * within;
-  or_bits((u32*)J.out, bp, J.in[x], 8);
 }
 
 }  // namespace
@@ -855,10 +858,7 @@ int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u
   hipStream_t st = ctx->stream;
   ZPQ_LAUNCH(ctx, "lz77_pack_tokens_kernel", st, lz77_pack_tokens_kernel, dim3((unsigned)nj), dim3(1024), d_jobs);
   ZPQ_HIP(ctx, hipGetLastError());
-  if (max_n) {
-    ZPQ_LAUNCH(ctx, "lz77_pack_literals_kernel", st, lz77_pack_literals_kernel, dim3((max_n + 255) / 256, (unsigned)nj), dim3(256), d_jobs);
-    ZPQ_HIP(ctx, hipGetLastError());
-  }
+  (void)max_n;
   return ZPQ_OK;
 }
 

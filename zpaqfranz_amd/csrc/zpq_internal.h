@@ -28,6 +28,9 @@ struct zpq_ctx {
   size_t scratch_cap[ZPQ_SCRATCH_SLOTS];
   void* pinned;             // pinned host staging
   size_t pinned_cap;
+  // device blocks handed back by zpq_dev_free_pooled, kept for the next zpq_dev_alloc_pooled (ctx.hip)
+  struct PoolBlock { void* p; size_t cap; bool in_use; };
+  std::vector<PoolBlock> pool;
   // optional per-kernel event timing
   bool profiling;
   struct ProfRec { const char* name; hipEvent_t a, b; };

@@ -597,6 +597,8 @@ def load_shim():
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_shard_files.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        S.zpqj_add_dev.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64,
+                                   C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         _shim = S
     return _shim
 
@@ -714,6 +716,39 @@ def jidac_add(eng, archive, files, version_date, method="14", dates=None, checks
     S.zpqj_free(out)
     keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
     return data, dict(zip(keys, [int(x) for x in stats]))
+
+
+class DevFiles:
+    """The per-call tables of jidac_add_dev, built once for a set of files that stays in HBM (names, offsets, dates)."""
+
+    def __init__(self, names, file_off, dates=None, version_date=0):
+        n = len(names)
+        assert len(file_off) == n + 1
+        self.n = n
+        self.names = (C.c_char_p * max(1, n))(*[x.encode() for x in names])
+        self.off = (C.c_uint64 * (n + 1))(*file_off)
+        self.dates = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
+
+
+def jidac_add_dev(eng, archive, d_base, files, version_date, method="14", checksums=False, hint=False, twins=True, raw=False):
+    """zpqj_add_dev: the files are already in HBM -- `files` is a DevFiles (names ascending, file k at d_base + off[k] .. off[k + 1],
+    back to back).  Returns (bytes to append to the archive, stats dict); raw=True: (address, length, stats), the caller frees the
+    address with load_shim().zpqj_free (no copy of the archive into a Python bytes object)."""
+    S = load_shim()
+    out, out_len = C.c_void_p(), C.c_size_t(0)
+    stats = (C.c_uint64 * 6)()
+    flags = (1 if checksums else 0) | (2 if hint else 0) | (0 if twins else 4)
+    rc = S.zpqj_add_dev(eng.ctx, bytes(archive) if archive else None, len(archive) if archive else 0, files.names, C.c_void_p(d_base), files.off,
+                        files.dates, files.n, version_date, method.encode(), flags, C.byref(out), C.byref(out_len), stats)
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
+    st = dict(zip(keys, [int(x) for x in stats]))
+    if raw:
+        return out.value, out_len.value, st
+    data = C.string_at(out.value, out_len.value)
+    S.zpqj_free(out)
+    return data, st
 
 
 def jidac_verify(eng, archive):

@@ -76,6 +76,28 @@ int compress_host(zpq_ctx* ctx, const Bytes& in, const char* method, const std::
   return ZPQ_OK;
 }
 
+// Several small blocks (the c / h / i blocks of one add) through ONE zpq_compress_blocks call: a call costs launches and
+// host round trips whatever its size, and an add of thousands of files writes hundreds of index blocks.
+struct HostBlock { Bytes in; std::string method, name; };
+int compress_host_many(zpq_ctx* ctx, const std::vector<HostBlock>& hb, std::vector<Bytes>& outs) {
+  outs.assign(hb.size(), Bytes());
+  if (hb.empty()) return ZPQ_OK;
+  std::vector<zpq_block_job> jobs(hb.size());
+  static const uint8_t empty[1] = {0};
+  for (size_t k = 0; k < hb.size(); ++k) {
+    zpq_block_job& j = jobs[k];
+    memset(&j, 0, sizeof j);
+    outs[k].resize(zpq_block_bound(hb[k].in.size(), hb[k].name.c_str(), "jDC\x01"));
+    j.in = hb[k].in.empty() ? empty : hb[k].in.data(); j.n = (uint32_t)hb[k].in.size();
+    j.method = hb[k].method.c_str(); j.filename = hb[k].name.c_str(); j.comment = "jDC\x01"; j.dosha1 = 1;
+    j.out = outs[k].data(); j.out_cap = (uint32_t)outs[k].size();
+  }
+  const int rc = zpq_compress_blocks(ctx, jobs.data(), jobs.size());
+  if (rc) return rc;
+  for (size_t k = 0; k < hb.size(); ++k) { if (jobs[k].status) return jobs[k].status; outs[k].resize(jobs[k].out_len); }
+  return ZPQ_OK;
+}
+
 // ---- archive index as read back (HT / DT / Block of ZSFX/zsfx.cpp:651-698) ----------------------------------
 struct Frag { Sha1Key sha1; uint32_t usize; };
 struct DBlock { size_t offset; uint32_t csize; uint32_t first_frag; uint32_t nfrag; uint64_t usize; };
@@ -225,34 +247,42 @@ struct Shard {
   std::vector<uint32_t> crc; std::vector<uint64_t> xxh;      // per file, when asked for
   size_t nf = 0;
   int rc = ZPQ_OK;
-  ~Shard() { for (void* q : dev) if (q) zpq_dev_free(ctx, q); }
+  ~Shard() { for (void* q : dev) if (q) zpq_dev_free_pooled(ctx, q); }
 };
 
-int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes, const std::vector<size_t>& order, bool checksums) {
+// ext_base / ext_off: the files are already in HBM (zpqj_add_dev): file order[k] lies at ext_base + ext_off[k] .. ext_off[k + 1],
+// back to back in name order, the caller's buffer -- nothing is copied and nothing of it is freed here.
+int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes, const std::vector<size_t>& order, bool checksums,
+                   const uint8_t* ext_base = nullptr, const uint64_t* ext_off = nullptr, bool no_twins = false) {
   zpq_ctx* ctx = S.ctx;
   const size_t nfiles = S.f1 - S.f0;
-  S.off.assign(nfiles + 1, 0);
-  for (size_t k = 0; k < nfiles; ++k) S.off[k + 1] = S.off[k] + sizes[order[S.f0 + k]];
-  const uint64_t total = S.off[nfiles];
   int rc;
-  if ((rc = zpq_dev_alloc(ctx, total + 64, &S.d_data))) return rc;
-  S.dev.push_back(S.d_data);
-  for (size_t k = 0; k < nfiles; ++k)
-    if (sizes[order[S.f0 + k]] && (rc = zpq_h2d(ctx, (uint8_t*)S.d_data + S.off[k], datas[order[S.f0 + k]], sizes[order[S.f0 + k]]))) return rc;
-  if ((rc = zpq_dev_memset(ctx, (uint8_t*)S.d_data + total, 0, 64))) return rc;
+  if (ext_base) {
+    S.off.assign(ext_off + S.f0, ext_off + S.f1 + 1);
+    S.d_data = (void*)ext_base;
+  } else {
+    S.off.assign(nfiles + 1, 0);
+    for (size_t k = 0; k < nfiles; ++k) S.off[k + 1] = S.off[k] + sizes[order[S.f0 + k]];
+    const uint64_t total = S.off[nfiles];
+    if ((rc = zpq_dev_alloc_pooled(ctx, total + 64, &S.d_data))) return rc;
+    S.dev.push_back(S.d_data);
+    for (size_t k = 0; k < nfiles; ++k)
+      if (sizes[order[S.f0 + k]] && (rc = zpq_h2d(ctx, (uint8_t*)S.d_data + S.off[k], datas[order[S.f0 + k]], sizes[order[S.f0 + k]]))) return rc;
+    if ((rc = zpq_dev_memset(ctx, (uint8_t*)S.d_data + total, 0, 64))) return rc;
+  }
   zpq_fragment_params fp;
   zpq_fragment_params_default(&fp);
   const size_t cap = std::max<size_t>(1, zpq_fragment_capacity(S.off.data(), nfiles, &fp));
   void *d_foff, *d_flen, *d_ffile, *d_dig;
-  if ((rc = zpq_dev_alloc(ctx, cap * 8, &d_foff))) return rc; S.dev.push_back(d_foff);
-  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_flen))) return rc; S.dev.push_back(d_flen);
-  if ((rc = zpq_dev_alloc(ctx, cap * 4, &d_ffile))) return rc; S.dev.push_back(d_ffile);
-  if ((rc = zpq_dev_alloc(ctx, cap * 20 + 64, &d_dig))) return rc; S.dev.push_back(d_dig);
+  if ((rc = zpq_dev_alloc_pooled(ctx, cap * 8, &d_foff))) return rc; S.dev.push_back(d_foff);
+  if ((rc = zpq_dev_alloc_pooled(ctx, cap * 4, &d_flen))) return rc; S.dev.push_back(d_flen);
+  if ((rc = zpq_dev_alloc_pooled(ctx, cap * 4, &d_ffile))) return rc; S.dev.push_back(d_ffile);
+  if ((rc = zpq_dev_alloc_pooled(ctx, cap * 20 + 64, &d_dig))) return rc; S.dev.push_back(d_dig);
   size_t nf = 0;
   // fragment loop + SHA-1 of every fragment; files whose bytes equal an earlier file of this range (compared on the device,
   // csrc/twins.hip) are not walked again: their records are the earlier file's, moved
   if (nfiles && (rc = zpq_fragment_sha1_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, &fp, (uint64_t*)d_foff, (uint32_t*)d_flen,
-                                            (uint32_t*)d_ffile, (uint8_t*)d_dig, cap, &nf, 0, nullptr, nullptr))) return rc;
+                                            (uint32_t*)d_ffile, (uint8_t*)d_dig, cap, &nf, no_twins ? ZPQ_FS_NO_TWINS : 0u, nullptr, nullptr))) return rc;
   if (checksums && nfiles) {       // zpaqfranz stores XXHASH64 + CRC-32 of every file in its i-block attribute: same pass over HBM
     S.crc.resize(nfiles); S.xxh.resize(nfiles);
     if ((rc = zpq_file_checksums_dev(ctx, (const uint8_t*)S.d_data, S.off.data(), nfiles, S.crc.data(), S.xxh.data(), nullptr))) return rc;
@@ -296,9 +326,11 @@ int xchg_all(const Xchg& X, const Bytes& send, std::vector<Bytes>& got) {
 
 int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* const* datas,
              const uint64_t* sizes, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
-             uint8_t** out, size_t* out_len, uint64_t stats[6], uint32_t flags = 0, const Xchg* X = nullptr) {
+             uint8_t** out, size_t* out_len, uint64_t stats[6], uint32_t flags = 0, const Xchg* X = nullptr,
+             const uint8_t* ext_base = nullptr, const uint64_t* ext_off = nullptr) {
   *out = nullptr; *out_len = 0;
   if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
+  if (ext_base && (X || nctx != 1 || !ext_off)) return ZPQ_ERR_ARG;
   const size_t me = X ? (size_t)X->rank : 0;
   if (X) { if (X->world < 1 || X->rank < 0 || X->rank >= X->world || !X->fn) return ZPQ_ERR_ARG; nctx = (size_t)X->world; }
   const bool checksums = (flags & ZPQJ_FILE_CHECKSUMS) != 0;
@@ -313,6 +345,14 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   std::vector<size_t> order(nfiles);
   for (size_t i = 0; i < nfiles; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
+  std::vector<uint64_t> ext_sizes;
+  if (ext_base) {
+    // device-resident files lie back to back in the order they are processed in: name order
+    for (size_t i = 0; i < nfiles; ++i) if (order[i] != i || ext_off[i + 1] < ext_off[i]) return ZPQ_ERR_ARG;
+    ext_sizes.resize(nfiles);
+    for (size_t i = 0; i < nfiles; ++i) ext_sizes[i] = ext_off[i + 1] - ext_off[i];
+    sizes = ext_sizes.data();
+  }
   // 1. contiguous file ranges of about equal bytes, one per context; fragment + hash per range (one host thread each)
   std::vector<Shard> sh(nctx);
   {
@@ -322,7 +362,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums); });
+    const bool no_twins = (flags & ZPQJ_NO_TWINS) != 0;
+    if (nctx == 1) sh[0].rc = shard_fragment(sh[0], datas, sizes, order, checksums, ext_base, ext_off, no_twins);      // (no thread for one range)
+    else for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums, nullptr, nullptr, no_twins); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
   }
@@ -369,12 +411,12 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   int rc;
   if (nf) {
     void *d_dig = nullptr, *d_first = nullptr;
-    if ((rc = zpq_dev_alloc(ctx, nf * 20 + 64, &d_dig))) return rc;
-    if ((rc = zpq_dev_alloc(ctx, nf * 4, &d_first))) { zpq_dev_free(ctx, d_dig); return rc; }
+    if ((rc = zpq_dev_alloc_pooled(ctx, nf * 20 + 64, &d_dig))) return rc;
+    if ((rc = zpq_dev_alloc_pooled(ctx, nf * 4, &d_first))) { zpq_dev_free_pooled(ctx, d_dig); return rc; }
     rc = zpq_h2d(ctx, d_dig, dig.data(), nf * 20);
     if (!rc) rc = zpq_dedup_dev(ctx, (const uint8_t*)d_dig, nf, (uint32_t*)d_first);
     if (!rc) rc = zpq_d2h(ctx, first.data(), d_first, nf * 4);
-    zpq_dev_free(ctx, d_dig); zpq_dev_free(ctx, d_first);
+    zpq_dev_free_pooled(ctx, d_dig); zpq_dev_free_pooled(ctx, d_first);
     if (rc) return rc;
   }
   // fragment ids: known from earlier versions, else new (first occurrence in this batch)
@@ -419,12 +461,12 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     Bytes snd((size_t)cur[me]);
     if (!so.empty() && cur[me]) {
       zpq_ctx* c = ctxs[0];
-      struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{c, {}};
+      struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{c, {}};
       void *d_st, *d_so, *d_sl, *d_dso;
-      if ((rc = zpq_dev_alloc(c, cur[me] + 64, &d_st))) return rc; dev.p.push_back(d_st);
-      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
-      if ((rc = zpq_dev_alloc(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
-      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+      if ((rc = zpq_dev_alloc_pooled(c, cur[me] + 64, &d_st))) return rc; dev.p.push_back(d_st);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
       if ((rc = zpq_h2d(c, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(c, d_sl, sl.data(), sl.size() * 4)) ||
           (rc = zpq_h2d(c, d_dso, dso.data(), dso.size() * 8))) return rc;
       if ((rc = zpq_gather_dev(c, (const uint8_t*)sh[me].d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_st))) return rc;
@@ -438,7 +480,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     std::vector<size_t> mine;
     for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == r) mine.push_back(b);
     if (mine.empty()) return ZPQ_OK;
-    struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{c, {}};
+    struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{c, {}};
     std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(mine.size()); std::vector<uint32_t> bn(mine.size());
     struct Remote { size_t src_shard; uint64_t src_off; uint64_t dst_off; uint32_t len; };    // src_off: in the peer's buffer, or in its exchanged string
     std::vector<Remote> remote;
@@ -459,11 +501,11 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     }
     int rc;
     void *d_blk, *d_so = nullptr, *d_sl = nullptr, *d_dso = nullptr;
-    if ((rc = zpq_dev_alloc(c, pos + 64, &d_blk))) return rc; dev.p.push_back(d_blk);
+    if ((rc = zpq_dev_alloc_pooled(c, pos + 64, &d_blk))) return rc; dev.p.push_back(d_blk);
     if (!so.empty()) {
-      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
-      if ((rc = zpq_dev_alloc(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
-      if ((rc = zpq_dev_alloc(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+      if ((rc = zpq_dev_alloc_pooled(c, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
       if ((rc = zpq_h2d(c, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(c, d_sl, sl.data(), sl.size() * 4)) ||
           (rc = zpq_h2d(c, d_dso, dso.data(), dso.size() * 8))) return rc;
       if ((rc = zpq_gather_dev(c, (const uint8_t*)sh[r].d_data, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blk))) return rc;
@@ -489,7 +531,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       ooff[m] = opos; opos += (zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01") + 63) & ~(size_t)63;
     }
     void* d_out;
-    if ((rc = zpq_dev_alloc(c, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
+    if ((rc = zpq_dev_alloc_pooled(c, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
     // "method,R,t" per block (zpaq's add(); ZSFX/libzpaq.h:86-135): R from the order-1 hits of its fragments, t from the
     // text / exe votes -- one lane per fragment over the assembled blocks
     std::vector<std::string> mth(mine.size(), std::string(method));
@@ -500,9 +542,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
         for (size_t k = blocks[mine[m]].first; k < blocks[mine[m]].second; ++k) { fo.push_back(q); fl.push_back(flen[newfrags[k]]); fb.push_back(m); q += flen[newfrags[k]]; }
       }
       void *d_fo, *d_fl, *d_st;
-      if ((rc = zpq_dev_alloc(c, fo.size() * 8 + 64, &d_fo))) return rc; dev.p.push_back(d_fo);
-      if ((rc = zpq_dev_alloc(c, fo.size() * 4 + 64, &d_fl))) return rc; dev.p.push_back(d_fl);
-      if ((rc = zpq_dev_alloc(c, fo.size() * 16 + 64, &d_st))) return rc; dev.p.push_back(d_st);
+      if ((rc = zpq_dev_alloc_pooled(c, fo.size() * 8 + 64, &d_fo))) return rc; dev.p.push_back(d_fo);
+      if ((rc = zpq_dev_alloc_pooled(c, fo.size() * 4 + 64, &d_fl))) return rc; dev.p.push_back(d_fl);
+      if ((rc = zpq_dev_alloc_pooled(c, fo.size() * 16 + 64, &d_st))) return rc; dev.p.push_back(d_st);
       if ((rc = zpq_h2d(c, d_fo, fo.data(), fo.size() * 8)) || (rc = zpq_h2d(c, d_fl, fl.data(), fl.size() * 4))) return rc;
       if ((rc = zpq_fragment_stats_dev(c, (const uint8_t*)d_blk, (const uint64_t*)d_fo, (const uint32_t*)d_fl, fo.size(), (uint32_t*)d_st))) return rc;
       std::vector<uint32_t> st(fo.size() * 4);
@@ -558,18 +600,20 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   Bytes dpart;                                      // the d blocks, in block order whoever compressed them
   std::vector<uint32_t> dsize(blocks.size());
   for (size_t b = 0; b < blocks.size(); ++b) { dsize[b] = (uint32_t)dblock[b].size(); dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end()); }
-  // 4. c block, d blocks, h blocks, i blocks
-  Bytes outb, tmp;
-  put64(tmp, dpart.size());
-  if ((rc = compress_host(ctx, tmp, "0", block_name(version_date, 'c', first_new_id), outb))) return rc;
-  outb.insert(outb.end(), dpart.begin(), dpart.end());
+  // 4. c block, d blocks, h blocks, i blocks: the index blocks are put together first and compressed by ONE call
+  std::vector<HostBlock> hb;
+  {
+    Bytes t8; put64(t8, dpart.size());
+    hb.push_back({t8, "0", block_name(version_date, 'c', first_new_id)});
+  }
   for (size_t b = 0; b < blocks.size(); ++b) {
-    tmp.clear();
+    Bytes tmp;
+    tmp.reserve(4 + 24 * (blocks[b].second - blocks[b].first));
     put32(tmp, dsize[b]);
     for (size_t k = blocks[b].first; k < blocks[b].second; ++k) { const uint32_t f = newfrags[k]; tmp.insert(tmp.end(), &dig[20 * f], &dig[20 * f] + 20); put32(tmp, flen[f]); }
-    if ((rc = compress_host(ctx, tmp, "0", block_name(version_date, 'h', first_new_id + (uint32_t)blocks[b].first), outb))) return rc;
+    hb.push_back({std::move(tmp), "0", block_name(version_date, 'h', first_new_id + (uint32_t)blocks[b].first)});
   }
-  tmp.clear();
+  Bytes tmp;
   uint32_t inum = 1;
   size_t fi = 0;
   for (size_t k = 0; k < nfiles; ++k) {
@@ -590,15 +634,24 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     } else {
       put32(tmp, 3); tmp.push_back('u'); tmp.push_back(0xa4); tmp.push_back(0x81);   // unix mode 0100644
     }
-    std::vector<uint32_t> ptr;
-    while (fi < nf && ffile[fi] == k) ptr.push_back(id[fi++]);
-    put32(tmp, (uint32_t)ptr.size());
-    for (uint32_t q : ptr) put32(tmp, q);
+    size_t f1 = fi;
+    while (f1 < nf && ffile[f1] == k) ++f1;
+    put32(tmp, (uint32_t)(f1 - fi));
+    for (; fi < f1; ++fi) put32(tmp, id[fi]);
     if (tmp.size() > 16000 || k + 1 == nfiles) {       // zpaq flushes the index every ~16 KB
-      if ((rc = compress_host(ctx, tmp, "1", block_name(version_date, 'i', inum++), outb))) return rc;
-      tmp.clear();
+      hb.push_back({std::move(tmp), "1", block_name(version_date, 'i', inum++)});
+      tmp = Bytes();
     }
   }
+  std::vector<Bytes> hout;
+  if ((rc = compress_host_many(ctx, hb, hout))) return rc;
+  Bytes outb;
+  size_t need = dpart.size();
+  for (const Bytes& o : hout) need += o.size();
+  outb.reserve(need);
+  outb.insert(outb.end(), hout[0].begin(), hout[0].end());
+  outb.insert(outb.end(), dpart.begin(), dpart.end());
+  for (size_t k = 1; k < hout.size(); ++k) outb.insert(outb.end(), hout[k].begin(), hout[k].end());
   *out = (uint8_t*)malloc(outb.size() ? outb.size() : 1);
   if (!*out) return ZPQ_ERR_NOMEM;
   memcpy(*out, outb.data(), outb.size());
@@ -643,7 +696,7 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
   Index ix;
   int rc = read_index(ctx, archive, archive_len, ix);
   if (rc) return rc;
-  struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free(c, q); } } dev{ctx, {}};
+  struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{ctx, {}};
   const size_t nb = ix.blocks.size();
   // d blocks -> HBM
   std::vector<uint64_t> aoff(nb), poff(nb);
@@ -655,8 +708,8 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     poff[b] = ppos; ppos += (B.usize + 64 + 63) & ~(uint64_t)63;
   }
   void *d_arc = nullptr, *d_plain = nullptr;
-  if ((rc = zpq_dev_alloc(ctx, apos + 64, &d_arc))) return rc; dev.p.push_back(d_arc);
-  if ((rc = zpq_dev_alloc(ctx, ppos + 64, &d_plain))) return rc; dev.p.push_back(d_plain);
+  if ((rc = zpq_dev_alloc_pooled(ctx, apos + 64, &d_arc))) return rc; dev.p.push_back(d_arc);
+  if ((rc = zpq_dev_alloc_pooled(ctx, ppos + 64, &d_plain))) return rc; dev.p.push_back(d_plain);
   if ((rc = zpq_dev_memset(ctx, d_arc, 0, apos + 64))) return rc;
   std::vector<zpq_unblock_job> jobs(nb);
   for (size_t b = 0; b < nb; ++b) {
@@ -691,10 +744,10 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
   if (!voff.empty()) {
     void *d_voff, *d_vlen, *d_want, *d_got;
     const size_t nv = voff.size();
-    if ((rc = zpq_dev_alloc(ctx, nv * 8, &d_voff))) return rc; dev.p.push_back(d_voff);
-    if ((rc = zpq_dev_alloc(ctx, nv * 4, &d_vlen))) return rc; dev.p.push_back(d_vlen);
-    if ((rc = zpq_dev_alloc(ctx, nv * 20 + 64, &d_want))) return rc; dev.p.push_back(d_want);
-    if ((rc = zpq_dev_alloc(ctx, nv * 20 + 64, &d_got))) return rc; dev.p.push_back(d_got);
+    if ((rc = zpq_dev_alloc_pooled(ctx, nv * 8, &d_voff))) return rc; dev.p.push_back(d_voff);
+    if ((rc = zpq_dev_alloc_pooled(ctx, nv * 4, &d_vlen))) return rc; dev.p.push_back(d_vlen);
+    if ((rc = zpq_dev_alloc_pooled(ctx, nv * 20 + 64, &d_want))) return rc; dev.p.push_back(d_want);
+    if ((rc = zpq_dev_alloc_pooled(ctx, nv * 20 + 64, &d_got))) return rc; dev.p.push_back(d_got);
     if ((rc = zpq_h2d(ctx, d_voff, voff.data(), nv * 8)) || (rc = zpq_h2d(ctx, d_vlen, vlen.data(), nv * 4)) || (rc = zpq_h2d(ctx, d_want, want.data(), nv * 20))) return rc;
     if ((rc = zpq_sha1_extents_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_voff, (const uint32_t*)d_vlen, nv, (uint8_t*)d_got))) return rc;
     uint64_t mism = 0, firstbad = 0;
@@ -727,12 +780,12 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
   }
   void* d_blob = nullptr;
-  if ((rc = zpq_dev_alloc(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
+  if ((rc = zpq_dev_alloc_pooled(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
   if (!so.empty()) {
     void *d_so, *d_sl, *d_dso;
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
-    if ((rc = zpq_dev_alloc(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+    if ((rc = zpq_dev_alloc_pooled(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+    if ((rc = zpq_dev_alloc_pooled(ctx, so.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+    if ((rc = zpq_dev_alloc_pooled(ctx, so.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
     if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
         (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
     if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blob))) return rc;
@@ -811,6 +864,19 @@ int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allga
 }
 
 // mine[k] = 1 where rank `rank` of `world` must supply datas[k] to zpqj_add_sharded, else 0.
+// zpqj_add with the files already in HBM (device-resident extents in, c/d/h/i archive out): `names` ascend (strcmp) and file k
+// lies at d_base + file_off[k] .. file_off[k + 1], the files back to back in that order -- the order Jidac::add walks them in.
+// d_base: 16-byte aligned, 64 readable bytes behind the last file.  Nothing of the input crosses PCIe; what comes back is
+// the archive (host memory, zpqj_free).  One context; several calls on several contexts may be in flight at once.
+int zpqj_add_dev(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* d_base,
+                 const uint64_t* file_off, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
+                 uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
+  if (!out || !out_len) return ZPQ_ERR_ARG;
+  if (!ctx || !d_base || !file_off || !names || !dates) { *out = nullptr; *out_len = 0; return ZPQ_ERR_ARG; }
+  return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, nullptr, nullptr, dates, nfiles, version_date, method, out, out_len,
+                                       stats, flags, nullptr, d_base, file_off); });
+}
+
 int zpqj_shard_files(const char* const* names, const uint64_t* sizes, size_t nfiles, int world, int rank, uint8_t* mine) {
   if (world < 1 || rank < 0 || rank >= world || (nfiles && (!names || !sizes || !mine))) return ZPQ_ERR_ARG;
   return guarded([&] {

@@ -22,9 +22,18 @@ int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, si
 #define ZPQJ_FILE_CHECKSUMS 1u   /* store XXHASH64 + CRC-32 of every file in its i-block attribute (zpaqfranz's default) */
 #define ZPQJ_METHOD_HINT 2u      /* method "LB" (digits only): every d block gets "LB,R,t" from its fragments' statistics
                                   * (zpq_fragment_stats_dev), as zpaq's add() does; the detectors are unpinned */
+#define ZPQJ_NO_TWINS 4u         /* every file through the fragment loop and SHA-1, also one whose bytes equal an earlier file's
+                                  * (default: such files are found by comparing every byte on the device, csrc/twins.hip) */
 int zpqj_add_opts(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t archive_len, const char* const* names,
                   const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
                   int64_t version_date, const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]);
+/* zpqj_add_opts on one context with the files ALREADY IN HBM: `names` ascend (strcmp) and file k lies at d_base + file_off[k] ..
+ * file_off[k + 1], back to back in that order (ZPQ_ERR_ARG otherwise); d_base is 16-byte aligned with 64 readable bytes behind
+ * the last file.  The archive comes back in host memory (zpqj_free).  Jidac::add's loop over files -> fragments -> blocks
+ * (the missing zpaqfranz.cpp; its product is read back by ZSFX/zsfx.cpp:1384-1542) as one call that never moves the input. */
+int zpqj_add_dev(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* d_base,
+                 const uint64_t* file_off, const int64_t* dates, size_t nfiles, int64_t version_date, const char* method,
+                 uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]);
 /* The add across processes, one GPU each.  The caller supplies ONE collective: an all-gather of byte strings over its
  * ranks (MPI_Allgatherv, torch.distributed.all_gather_object, RCCL all_gather on padded buffers ...).  It must fill
  * recv[r] / recv_len[r] for every rank r (memory it owns, valid until its next call or the return of zpqj_add_sharded;
