@@ -23,12 +23,11 @@ sw "budget 128K" "ZPQ_FRAG_BUDGET=131072" | tee -a gpurun_out/${T}_sweep_frag_bu
 sw "budget 64K" "ZPQ_FRAG_BUDGET=65536" | tee -a gpurun_out/${T}_sweep_frag_budget.txt
 sw "budget 64K, resume 4 waves/CU" "ZPQ_FRAG_BUDGET=65536 ZPQ_FRAG_RESUME_WAVES=4" | tee -a gpurun_out/${T}_sweep_frag_budget.txt
 sw "budget 32K, resume 4 waves/CU" "ZPQ_FRAG_BUDGET=32768 ZPQ_FRAG_RESUME_WAVES=4" | tee -a gpurun_out/${T}_sweep_frag_budget.txt
-sw "budget 16K, resume 10 waves/CU" "ZPQ_FRAG_BUDGET=16384 ZPQ_FRAG_RESUME_WAVES=10" | tee -a gpurun_out/${T}_sweep_frag_budget.txt
 echo "[$(( $(date +%s) - S0 )) s] sweep"
 export -n ZPQ_BENCH_NO_VARIANT
 timeout 300 python bench.py --no-cpu-baseline --workload dup8_m1 2>gpurun_out/${T}_err3.txt | tail -1 | tee gpurun_out/${T}_dup8.json | line dup8
 echo "[$(( $(date +%s) - S0 )) s] dup8"
-bash tools/gpu_traffic.sh $T headline dup8_m1 extract_m1 text_m2
+bash tools/gpu_traffic.sh $T headline dup8_m1 extract_m1:notrace text_m2:notrace
 echo "[$(( $(date +%s) - S0 )) s] done"
 for f in 1 2 3; do [ -s gpurun_out/${T}_err$f.txt ] && { echo "== err$f"; tail -5 gpurun_out/${T}_err$f.txt; }; done
 tail -3 gpurun_out/${T}_last.err
