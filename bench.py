@@ -226,13 +226,21 @@ class Pipeline:
         if getattr(self, "devfiles", None) is None:
             self.devfiles = E.DevFiles(self.file_names(), self.file_off, version_date=self.VERSION_DATE)
         ptr, n, st = E.jidac_add_dev(self.eng, b"", self.data.data_ptr(), self.devfiles, self.VERSION_DATE, "14", twins=self.use_twins, raw=True)
-        try:
-            self.archive = C.string_at(ptr, n) if keep else None
-        finally:
+        self.drop_archive()
+        if keep:       # no copy (config 4's archive is several GB): a view of the memory the call returned, released by drop_archive()
+            self.archive_ptr = ptr
+            self.archive = memoryview((C.c_ubyte * n).from_address(ptr)).cast("B")
+        else:
             E.load_shim().zpqj_free(C.c_void_p(ptr))
         self.stats = dict(fragments=st["fragments"], unique_fragments=st["new_fragments"], blocks=st["d_blocks"], unique_bytes=st["unique_bytes"],
                           out_bytes=int(n), d_bytes=st["d_bytes"])
         return int(n)
+
+    def drop_archive(self):
+        if getattr(self, "archive_ptr", None):
+            self.archive = None
+            self.E.load_shim().zpqj_free(C.c_void_p(self.archive_ptr))
+            self.archive_ptr = None
 
     def step(self, order=None, idx=0, keep=True):
         """keep: hold on to the block inputs / outputs of this step for the verification (costs their memory until the next step)"""
@@ -299,10 +307,10 @@ class Pipeline:
         blk_n, src_off, src_len, dst_off, trailers, layout = [], [], [], [], [], {}
         pos = 0
         for b in mine:
-            u, l, own_rank = P["blocks"][int(b)]
+            u, l, own_rank, src = P["blocks"][int(b)]      # src: the occurrence each fragment is read from (this rank's own copy where it has one)
             o = pos + np.concatenate(([0], np.cumsum(l)[:-1]))
             own = own_rank == self.rank
-            src_off.append(u[own] - my_lo); src_len.append(l[own]); dst_off.append(o[own])
+            src_off.append(src[own] - my_lo); src_len.append(l[own]); dst_off.append(o[own])
             layout.update({int(g): int(d) for g, d in zip(u[~own].tolist(), o[~own].tolist())})
             size = int(l.sum())
             tr = np.concatenate((l.astype("<u4"), np.array([0, len(l)], dtype="<u4"))).tobytes()
@@ -502,30 +510,36 @@ def verify_add(pipe, layout, corpus, threads):
     return res
 
 
-def split_archive(arc):
-    """[(name, comment, start, end, payload bytes)] of the blocks of a journaling archive whose blocks have no context model
+def split_archive(arc, payloads=None):
+    """payloads: block types ("chi") whose stored bytes are wanted (default: all).  [(name, comment, start, end, payload bytes)] of the blocks of a journaling archive whose blocks have no context model
     (stored sub-blocks): tag, zPQ level type, header, 1 name 0 comment 0 0, {len[4] bytes}... 0[4], 253 sha1[20] | 254, 255."""
+    arc = memoryview(arc).cast("B")              # (bytes or the view of a multi-gigabyte archive: nothing below copies more than a block)
     out, p, n = [], 0, len(arc)
+
+    def nul(q):
+        return q + bytes(arc[q:q + 4096]).index(0)
     while p < n:
         s0 = p
-        assert arc[p + 13:p + 16] == b"zPQ", "no block at %d" % p
+        assert bytes(arc[p + 13:p + 16]) == b"zPQ", "no block at %d" % p
         hs = arc[p + 18] | arc[p + 19] << 8
         assert arc[p + 24] == 0, "block with a context model"
         p += 20 + hs
         assert arc[p] == 1
-        e = arc.index(b"\0", p + 1); name = arc[p + 1:e]
-        e2 = arc.index(b"\0", e + 1); comment = arc[e + 1:e2]
+        e = nul(p + 1); name = bytes(arc[p + 1:e])
+        e2 = nul(e + 1); comment = bytes(arc[e + 1:e2])
         p = e2 + 2
-        pay = bytearray()
+        pay = bytearray() if payloads is None or chr(name[17]) in payloads else None
         while True:
             k = int.from_bytes(arc[p:p + 4], "big"); p += 4
             if not k:
                 break
-            pay += arc[p:p + k]; p += k
+            if pay is not None:
+                pay += arc[p:p + k]
+            p += k
         p += 21 if arc[p] == 253 else 1
         assert arc[p] == 255
         p += 1
-        out.append((name, comment, s0, p, bytes(pay)))
+        out.append((name, comment, s0, p, bytes(pay) if pay is not None else None))
     return out
 
 
@@ -536,21 +550,22 @@ def verify_product(pipe, archive, threads):
     and i block (the d blocks are the bytes of (a))."""
     import orc
     res = {}
-    blocks = split_archive(archive)
+    blocks = split_archive(archive, payloads="chi")
     kinds = "".join(chr(b[0][17]) for b in blocks)
     nb = kinds.count("d")
     res["archive_blocks"] = {k: kinds.count(k) for k in "cdhi"}
     ok_layout = kinds == "c" + "d" * nb + "h" * nb + "i" * kinds.count("i") and kinds.count("i") >= 1
     want = pipe.framed_blocks()
-    got_d = [archive[b[2]:b[3]] for b in blocks if chr(b[0][17]) == "d"]
-    res["verified_product_d_blocks"] = bool(ok_layout and len(want) == len(got_d) and all(w[1] == g for w, g in zip(want, got_d)))
+    got_d = [archive[b[2]:b[3]] for b in blocks if chr(b[0][17]) == "d"]        # (views)
+    res["verified_product_d_blocks"] = bool(ok_layout and len(want) == len(got_d) and all(w[0] == b[0] and w[1] == g for w, g, b in
+                                                                                       zip(want, got_d, [b for b in blocks if chr(b[0][17]) == "d"])))
     # reference decoder over the index blocks
     ok_ref = True
     if orc.have_ref():
         for b in blocks:
             if chr(b[0][17]) == "d":
                 continue
-            r = orc.ref_decompress_block(archive[b[2]:b[3]], len(b[4]) * 8 + 65536)
+            r = orc.ref_decompress_block(bytes(archive[b[2]:b[3]]), len(b[4]) * 8 + 65536)
             ok_ref = ok_ref and r["sha1_ok"] == 1 and r["consumed"] == b[3] - b[2] and r["filename"] == b[0]
     res["verified_index_blocks_by_reference_decoder"] = bool(ok_ref and orc.have_ref())
     L = pipe.last
@@ -560,11 +575,11 @@ def verify_product(pipe, archive, threads):
     dig = pipe.digests[: nf * 20].cpu().numpy().reshape(nf, 20)
     # c block: the d blocks' bytes; h blocks: bsize + (sha1, usize) per fragment of its d block
     cb = [b for b in blocks if chr(b[0][17]) == "c"][0]
-    ok = ok_layout and int.from_bytes(orc.ref_decompress_block(archive[cb[2]:cb[3]], 65536)["data"] if orc.have_ref() else b"", "little") == sum(len(g) for g in got_d)
+    ok = ok_layout and int.from_bytes(orc.ref_decompress_block(bytes(archive[cb[2]:cb[3]]), 65536)["data"] if orc.have_ref() else b"", "little") == sum(len(g) for g in got_d)
     st = P["starts"]
     hb = [b for b in blocks if chr(b[0][17]) == "h"]
     for k, b in enumerate(hb):
-        body = orc.ref_decompress_block(archive[b[2]:b[3]], len(b[4]) * 2 + 65536)["data"] if orc.have_ref() else b""
+        body = orc.ref_decompress_block(bytes(archive[b[2]:b[3]]), len(b[4]) * 2 + 65536)["data"] if orc.have_ref() else b""
         u = uniq[st[k]:st[k + 1]]
         wantb = len(got_d[k]).to_bytes(4, "little") + b"".join(bytes(dig[i]) + int(lens[i]).to_bytes(4, "little") for i in u.tolist())
         ok = ok and body == wantb and int(b[0][18:]) == int(st[k]) + 1
@@ -577,7 +592,7 @@ def verify_product(pipe, archive, threads):
     for b in blocks:
         if chr(b[0][17]) != "i":
             continue
-        body = orc.ref_decompress_block(archive[b[2]:b[3]], 1 << 22)["data"] if orc.have_ref() else b""
+        body = orc.ref_decompress_block(bytes(archive[b[2]:b[3]]), 1 << 22)["data"] if orc.have_ref() else b""
         q = 0
         while q < len(body) and ok:
             e = body.index(b"\0", q + 8)
@@ -868,14 +883,19 @@ def main_text_m2(a, rank, world, local, dev):
         sec = dt / steps
         # algorithmic bytes per step (SURVEY 8d has no figure for the suffix sort; the floor of any construction is the
         # n input bytes read and the 4n bytes of suffix array written): candidates read SA/ISA/LCP once and write a decision
-        alg = {"sa_radix_sort_pairs": 5 * total, "lz77_sa_candidates_kernel": total * (1 + 4 + 4 + 2) + 16 * total,
-               "sa_lcp_kernel": total * (1 + 4 + 4) + 2 * total, "lz77_sa_walk_kernel": 16 * total, "sha1_chain_kernel": total}
+        # (the two candidate passes each read text + suffix array + LCP and write or update a 16-byte decision record per position)
+        alg = {"sa_radix_sort_pairs": 5 * total, "lz77_sa_cand0_kernel": total * (1 + 4 + 2) + 16 * total, "lz77_sa_cand1_kernel": total * (1 + 4 + 2) + 32 * total,
+               "sa_lcp_kernel": total * (1 + 4 + 4) + 2 * total, "sha1_chain_kernel": total}
         sa_ms = sum(m for k_, (c_, m) in kern.items() if k_.startswith("sa_")) / steps
 
         traffic = {}
         tf = os.path.join(ROOT, "profiles", "traffic_text_m2.json")      # PMC bytes per launch (tools/gpu_traffic.sh, profiles/summarize.py)
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("bytes_per_launch", {})
+            tj = json.load(open(tf))
+            traffic = dict(tj.get("bytes_per_launch", {}))
+            # the sort scope is several rocPRIM launches: its bytes per scope = all rocPRIM bytes of the profiled jobs / jobs / scopes per job
+            if tj.get("jobs_profiled") and tj.get("bytes_total", {}).get("rocprim") and "sa_radix_sort_pairs" in kern_alone:
+                traffic["sa_radix_sort_pairs"] = int(tj["bytes_total"]["rocprim"] / tj["jobs_profiled"] / (kern_alone["sa_radix_sort_pairs"][0] / n_alone))
 
         def roof(k, src=None, nsteps=None, how=None):
             src = kern if src is None else src
@@ -1619,6 +1639,7 @@ def main():
                 res.update(verify_add(pipe, layout, corpus, threads))
                 if product_archive is not None:
                     res.update(verify_product(pipe, product_archive, threads))
+        product_archive = None          # (a view of memory the next product step releases)
         if not extract:
             res["twin_fold"] = dict(enabled=bool(pipe.use_twins), **(pipe.twin_stats or {}),
                                     note="files whose bytes equal an earlier file's are found by comparing every byte on the device (HBM-bound) "
@@ -1686,6 +1707,8 @@ def main():
                 f.write(g)
     if dist.is_initialized():
         dist.destroy_process_group()
+    for p_ in pipes:
+        p_.drop_archive()
     for e_ in engines:
         e_.close()
 

@@ -49,7 +49,7 @@ def main(root, tag, work=""):
             out.append("%-34s %6d %16.1f %16.1f" % (short(name)[:34], calls, sm, av))
         out.append("")
     # bytes per launch for bench.py's roofline.traffic: FETCH_SIZE*2 (gfx950 correction) + WRITE_SIZE
-    per = {}
+    per, tot, launches = {}, {}, {}
     for sub, ctr, mul in (("prof_fetch" + sfx, "FETCH_SIZE", 2.0), ("prof_write" + sfx, "WRITE_SIZE", 1.0)):
         cur = q(os.path.join(root, sub))
         if not cur:
@@ -58,12 +58,20 @@ def main(root, tag, work=""):
             k = short(name)
             k = "fragment_resume_kernel" if k.startswith("fragment_spec_kernel<true") else k.split("<")[0]   # names bench.py uses
             k = {"lz77_spec3_kernel": "lz77_spec_kernel", "lz77_direct3_kernel": "lz77_direct_kernel", "lz77_direct4_kernel": "lz77_direct_kernel"}.get(k, k)
+            if k.startswith("rocprim::"):
+                k = "rocprim"                 # (sort and scan passes under the suffix array: bench.py's scope sa_radix_sort_pairs)
             per[k] = per.get(k, 0) + int(sm * 1024 * mul / max(1, calls))
+            tot[k] = tot.get(k, 0) + int(sm * 1024 * mul)
+            launches[k] = max(launches.get(k, 0), calls)
     if per:
         import json
-        json.dump({"source": "profiles/%s_rocprof_summary.txt: per launch, FETCH_SIZE*2 (gfx950 correction, calibrated on the copyBuffer "
-                             "dispatches of the same run) + WRITE_SIZE" % tag,
-                   "bytes_per_launch": dict(sorted(per.items(), key=lambda kv: -kv[1]))},
+        # whole jobs the counter passes ran (bench.py runs sizing and verification steps beside the timed one): a kernel launched once per job
+        marker = {"text_m2": "sha1_chain_kernel", "extract_m1": "unframe_walk_kernel"}.get(work, "dedup_insert_kernel")
+        json.dump({"source": "profiles/%s_rocprof_summary%s.txt: per launch, FETCH_SIZE*2 (gfx950 correction, calibrated on the copyBuffer "
+                             "dispatches of the same run) + WRITE_SIZE" % (tag, sfx),
+                   "jobs_profiled": launches.get(marker, 0), "jobs_marker_kernel": marker,
+                   "bytes_per_launch": dict(sorted(per.items(), key=lambda kv: -kv[1])),
+                   "bytes_total": dict(sorted(tot.items(), key=lambda kv: -kv[1])), "launches": launches},
                   open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic%s.json" % sfx), "w"), indent=1)
     txt = "\n".join(out)
     open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "%s_rocprof_summary%s.txt" % (tag, sfx)), "w").write(txt)

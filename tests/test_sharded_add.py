@@ -137,3 +137,47 @@ def test_a_failing_collective_fails_the_add():
         engine.jidac_add_sharded(eng, 0, 1, broken, None, part, 20260925120000, "14")
     arc, _ = engine.jidac_add_sharded(eng, 0, 1, lambda b: [b], None, part, 20260925120000, "14")     # world 1: the plain add
     assert arc == engine.jidac_add(eng, None, files, 20260925120000, "14")[0]
+
+
+def test_rccl_gather_library_exports_every_symbol_of_its_header():
+    """zpaqfranz_amd/shim/rccl_gather.h (the in-tree collective: rccl.h, no torch) vs libzpaq_rccl.so -- loads without a GPU."""
+    import ctypes
+    import re
+    from zpaqfranz_amd import build
+    build.build(verbose=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(build.RCCL_SO):
+        build.build_rccl()
+    hdr = open(os.path.join(root, "zpaqfranz_amd", "shim", "rccl_gather.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(zpqr_\w+)\s*\(", hdr))
+    assert {"zpqr_unique_id", "zpqr_create", "zpqr_allgatherv", "zpqr_last_error", "zpqr_destroy"} <= names
+    R = ctypes.CDLL(build.RCCL_SO)
+    for n in sorted(names):
+        assert hasattr(R, n), n
+    # its signature is the one zpqj_add_sharded takes
+    jh = open(os.path.join(root, "zpaqfranz_amd", "shim", "jidac_gpu.h")).read()
+    assert "typedef int (*zpqj_allgatherv_fn)(void* user, const void* send, size_t send_len, void** recv, size_t* recv_len);" in jh
+    assert "int zpqr_allgatherv(void* comm, const void* send, size_t send_len, void** recv, size_t* recv_len);" in hdr
+
+
+@pytest.mark.gpu
+def test_sharded_add_over_the_in_tree_rccl_collective_world_size_1():
+    """The C function zpqr_allgatherv (RCCL on the engine's stream) handed to zpqj_add_sharded as its collective: with one rank
+    the archive is the plain add's; the collective itself returns what was sent (strings of 0, 1 and 70 001 bytes)."""
+    if os.environ.get("ZPQ_TEST_EMU") == "1":
+        pytest.skip("RCCL needs the device")
+    from zpaqfranz_amd import engine
+    files = _corpus(nfiles=9)
+    part = [(n, b, len(b)) for n, b in files]
+    eng = engine.Engine(0)
+    g = engine.RcclGather(eng, 0, 1, engine.RcclGather.unique_id())
+    try:
+        for s in (b"", b"x", bytes(range(256)) * 273 + b"!"):
+            assert g(s) == [s]
+        arc, st = engine.jidac_add_sharded(eng, 0, 1, g, None, part, 20260925120000, "14", checksums=True)
+        want, wst = engine.jidac_add(eng, None, files, 20260925120000, "14", checksums=True)
+        assert arc == want and st == wst
+    finally:
+        g.close()
+        eng.close()

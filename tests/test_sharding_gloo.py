@@ -99,7 +99,7 @@ def test_balanced_ownership_deals_the_blocks_out_and_the_lists_match():
     first = sharding.first_occurrence(dig)
     plans = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20) for r in range(world)]
     assert len(plans[0]["mine"]) == plans[0]["nblocks"] and all(len(p["mine"]) == 0 for p in plans[1:])
-    bal = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20, balance=True) for r in range(world)]
+    bal = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20, balance=True, local_copies=False) for r in range(world)]
     nb = bal[0]["nblocks"]
     assert nb >= 2 * world
     owned = [p["mine"].tolist() for p in bal]
@@ -112,3 +112,46 @@ def test_balanced_ownership_deals_the_blocks_out_and_the_lists_match():
                 a = bal[src]["send"].get(dst, np.zeros(0, dtype=np.int64)); b = bal[dst]["recv"].get(src, np.zeros(0, dtype=np.int64))
                 assert a.tolist() == b.tolist()
     assert sum(len(v) for v in bal[0]["send"].values()) > 0 and not bal[1]["send"]       # rank 0 ships the blocks it does not keep
+
+
+def test_a_rank_reads_the_fragments_of_its_blocks_from_its_own_copy_where_it_has_one():
+    """local_copies (the default with balance=True): whole copies on every rank -> nothing is shipped, every fragment of a dealt
+    block is read at the rank's own occurrence; a rank that lacks some fragments (its copy is cut short) gets exactly those, and
+    sender and receiver agree on the lists.  The block contents (which unique fragments, in which order) never change."""
+    rng = np.random.default_rng(4)
+    n0 = 3000
+    dig0 = rng.integers(0, 256, size=(n0, 20), dtype=np.uint8)
+    lens0 = rng.integers(4096, 200000, size=n0).astype(np.int64)
+    world = 4
+    dig = np.concatenate([dig0] * world); lens = np.concatenate([lens0] * world)
+    first = sharding.first_occurrence(dig)
+    ref = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20, balance=True, local_copies=False) for r in range(world)]
+    loc = [sharding.plan(first, lens, [n0] * world, r, block_limit=4 << 20, balance=True) for r in range(world)]
+    for r in range(world):
+        assert not loc[r]["send"] and not loc[r]["recv"]
+        assert loc[r]["mine"].tolist() == ref[r]["mine"].tolist()
+        for b in loc[r]["mine"].tolist():
+            u, l, sr, si = loc[r]["blocks"][b]
+            assert u.tolist() == ref[r]["blocks"][b][0].tolist() and (sr == r).all()
+            assert (si >= r * n0).all() and (si < (r + 1) * n0).all() and np.array_equal(first[si], u) and np.array_equal(lens[si], l)
+    # rank 2 holds only the first 40 % of a copy, rank 3 a copy in another order
+    k = int(0.4 * n0)
+    perm = rng.permutation(n0)
+    dig2 = np.concatenate([dig0, dig0, dig0[:k], dig0[perm]]); lens2 = np.concatenate([lens0, lens0, lens0[:k], lens0[perm]])
+    counts = [n0, n0, k, n0]
+    first2 = sharding.first_occurrence(dig2)
+    pl = [sharding.plan(first2, lens2, counts, r, block_limit=4 << 20, balance=True) for r in range(world)]
+    lo = np.concatenate(([0], np.cumsum(counts)))
+    for src in range(world):
+        for dst in range(world):
+            if src != dst:
+                a = pl[src]["send"].get(dst, np.zeros(0, dtype=np.int64)); b = pl[dst]["recv"].get(src, np.zeros(0, dtype=np.int64))
+                assert a.tolist() == b.tolist()
+    assert not pl[1]["recv"] and not pl[3]["recv"] and set(pl[2]["recv"]) == {0}           # only the short copy needs anything
+    got = pl[2]["recv"][0]
+    assert (got >= k).all() and len(got) == sum(int((pl[2]["blocks"][b][2] != 2).sum()) for b in pl[2]["mine"].tolist())
+    for r in range(world):
+        for b in pl[r]["mine"].tolist():
+            u, l, sr, si = pl[r]["blocks"][b]
+            own = sr == r
+            assert (si[own] >= lo[r]).all() and (si[own] < lo[r + 1]).all() and np.array_equal(first2[si], u)

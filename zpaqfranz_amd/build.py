@@ -19,7 +19,8 @@ def needs_build():
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "zpq_internal.h"), os.path.join(CSRC, "cm_spec_src.inc"), os.path.join(CSRC, "lz77_waves.inc"), os.path.join(ROOT, "include", "zpaqhip.h"),
             os.path.join(HERE, "shim", "libzpaq_gpu.cpp"), os.path.join(HERE, "shim", "libzpaq_gpu.h"),
-            os.path.join(HERE, "shim", "jidac_gpu.cpp")]
+            os.path.join(HERE, "shim", "jidac_gpu.cpp"), os.path.join(HERE, "shim", "jidac_gpu.h"), os.path.join(HERE, "shim", "rccl_gather.cpp"),
+            os.path.join(HERE, "shim", "rccl_gather.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -60,7 +61,20 @@ def build_shim():
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(HERE, "shim")] + srcs + ["-L" + HERE, "-lzpaqhip", "-Wl,-rpath,$ORIGIN", "-o", so]
         subprocess.check_call(cmd)
+    build_rccl()
     return SHIM_SO
+
+
+RCCL_SO = os.path.join(HERE, "libzpaq_rccl.so")
+
+
+def build_rccl():
+    """The all-gather of byte strings over RCCL (shim/rccl_gather.cpp: plain rccl.h, no torch) that zpqj_add_sharded takes as
+    its one collective; a library of its own so that nothing else depends on librccl."""
+    cmd = ["hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "shim"),
+           os.path.join(HERE, "shim", "rccl_gather.cpp"), "-L" + HERE, "-lzpaqhip", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", RCCL_SO]
+    subprocess.check_call(cmd)
+    return RCCL_SO
 
 
 def build_shim_driver(out):

@@ -629,6 +629,60 @@ def dist_allgather_bytes(group=None):
     return f
 
 
+class RcclGather:
+    """The in-tree collective for jidac_add_sharded (shim/rccl_gather.cpp: rccl.h, no torch): an all-gather of byte strings over
+    RCCL on the engine's own stream.  `uid`: the 128 bytes RcclGather.unique_id() returned on rank 0, handed to every rank by
+    whatever the launcher offers (a file, the environment, a socket)."""
+
+    @staticmethod
+    def lib():
+        p = os.path.join(_HERE, "libzpaq_rccl.so")
+        if not os.path.exists(p):
+            raise ImportError("libzpaq_rccl.so is missing: run `python -m zpaqfranz_amd.build`")
+        load()
+        R = C.CDLL(p)
+        R.zpqr_unique_id.argtypes = [C.c_char_p]
+        R.zpqr_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        R.zpqr_allgatherv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        R.zpqr_last_error.argtypes = [C.c_void_p]
+        R.zpqr_last_error.restype = C.c_char_p
+        R.zpqr_destroy.argtypes = [C.c_void_p]
+        R.zpqr_destroy.restype = None
+        return R
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = RcclGather.lib().zpqr_unique_id(buf)
+        if rc != 0:
+            raise ZpqError(rc, "zpqr_unique_id")
+        return buf.raw
+
+    def __init__(self, eng, rank, world, uid):
+        self.R = RcclGather.lib()
+        self.comm = C.c_void_p()
+        self.rank, self.world = rank, world
+        rc = self.R.zpqr_create(eng.ctx, rank, world, uid, C.byref(self.comm))
+        if rc != 0:
+            raise ZpqError(rc, "zpqr_create (rank %d of %d)" % (rank, world))
+        self.fn = C.cast(self.R.zpqr_allgatherv, ALLGATHERV)      # the C function itself goes to zpqj_add_sharded: no Python in between
+
+    def __call__(self, b):
+        """the same collective from Python: bytes -> [bytes of every rank]"""
+        recv = (C.c_void_p * self.world)()
+        rlen = (C.c_size_t * self.world)()
+        buf = C.create_string_buffer(bytes(b), max(1, len(b)))
+        rc = self.R.zpqr_allgatherv(self.comm, buf, len(b), recv, rlen)
+        if rc != 0:
+            raise ZpqError(rc, "zpqr_allgatherv: " + self.R.zpqr_last_error(self.comm).decode())
+        return [C.string_at(recv[r], rlen[r]) if rlen[r] else b"" for r in range(self.world)]
+
+    def close(self):
+        if self.comm:
+            self.R.zpqr_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+
 def jidac_shard_files(names, sizes, world, rank):
     """Which files rank `rank` of `world` supplies to jidac_add_sharded: a list of bools in the order given."""
     S = load_shim()
@@ -670,7 +724,9 @@ def jidac_add_sharded(eng, rank, world, allgather, archive, files, version_date,
         except Exception as e:          # an exception cannot cross the C frames: report it after the call
             err.append(e)
             return 1
-    rc = S.zpqj_add_sharded(eng.ctx, rank, world, ALLGATHERV(cb), None, bytes(archive) if archive else None, len(archive) if archive else 0,
+    native = isinstance(allgather, RcclGather)          # the in-tree RCCL collective: zpqj_add_sharded calls the C function directly
+    rc = S.zpqj_add_sharded(eng.ctx, rank, world, allgather.fn if native else ALLGATHERV(cb), allgather.comm if native else None,
+                            bytes(archive) if archive else None, len(archive) if archive else 0,
                             names, datas, sizes, dts, n, version_date, method.encode(), (1 if checksums else 0) | (2 if hint else 0),
                             C.byref(out), C.byref(out_len), stats)
     if err:

@@ -27,7 +27,7 @@ def pack_blocks(uniq_len, block_limit=BLOCK_LIMIT):
     return blk, b
 
 
-def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT, balance=False):
+def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT, balance=False, local_copies=None):
     """Returns a dict describing what `rank` has to do:
       uniq_idx     global indices of new fragments (ascending)
       nblocks      number of d blocks in the archive
@@ -38,7 +38,13 @@ def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT, balance=False):
                    ascending ranks still own ascending blocks, so the per-rank streams concatenate to block order)
       blocks       {block id: (global fragment indices, lengths, owning rank of each fragment)}
       send         {dst rank: global indices of MY fragments that live in blocks owned by dst, in order}
-      recv         {src rank: global indices of fragments I need from src, in order}"""
+      recv         {src rank: global indices of fragments I need from src, in order}
+    local_copies (default: on with balance): a fragment of a block dealt to rank r that first occurred on another rank is taken
+    from r's OWN data when r holds a duplicate of it (the global table says which of r's fragments have that first
+    occurrence) -- every rank can tell that for every rank, so sender and receiver drop it from their lists alike.  With ONE
+    corpus of whole copies split by file range every rank holds every unique fragment: nothing is shipped at all, where
+    rank 0 would otherwise send every block it does not keep.  blocks[b] then carries a fourth array: the global index of
+    the occurrence to read each fragment from (its own index where the source is its first occurrence)."""
     first = np.asarray(first)
     lens = np.asarray(lens, dtype=np.int64)
     ntot = len(first)
@@ -52,18 +58,33 @@ def plan(first, lens, counts, rank, block_limit=BLOCK_LIMIT, balance=False):
     if balance and nblk:
         blk_owner = (np.arange(nblk, dtype=np.int64) * len(counts)) // nblk
     starts = np.concatenate((first_in_blk, [len(uniq_idx)])).astype(np.int64)
+    # where every fragment of a block is read from: the rank of its first occurrence, or -- local_copies -- the block's owner
+    # itself when it holds a duplicate
+    src_rank = owner.copy()
+    src_idx = uniq_idx.copy()
+    if (balance if local_copies is None else local_copies) and len(blk):
+        lo = bounds - np.asarray(counts, dtype=np.int64)
+        for r in range(len(counts)):
+            ks = np.nonzero((blk_owner[blk] == r) & (owner != r))[0]
+            if not len(ks) or bounds[r] == lo[r]:
+                continue
+            uq, at = np.unique(first[lo[r]:bounds[r]], return_index=True)      # first occurrences rank r holds a copy of, and where
+            pos = np.minimum(np.searchsorted(uq, uniq_idx[ks]), len(uq) - 1)
+            has = uq[pos] == uniq_idx[ks]
+            src_rank[ks[has]] = r
+            src_idx[ks[has]] = lo[r] + at[pos[has]]
     mine = np.nonzero(blk_owner == rank)[0]
     blocks = {}
     recv = {}
     for b in mine:
         sl = slice(starts[b], starts[b + 1])
-        blocks[int(b)] = (uniq_idx[sl], lens[uniq_idx[sl]], owner[sl])
-        for src in np.unique(owner[sl]):
+        blocks[int(b)] = (uniq_idx[sl], lens[uniq_idx[sl]], src_rank[sl], src_idx[sl])
+        for src in np.unique(src_rank[sl]):
             if src != rank:
-                recv.setdefault(int(src), []).append(uniq_idx[sl][owner[sl] == src])
+                recv.setdefault(int(src), []).append(uniq_idx[sl][src_rank[sl] == src])
     send = {}
     if len(blk):
-        theirs = np.nonzero((owner == rank) & (blk_owner[blk] != rank))[0]
+        theirs = np.nonzero((src_rank == rank) & (blk_owner[blk] != rank))[0]
         for dst in np.unique(blk_owner[blk[theirs]]):
             send[int(dst)] = uniq_idx[theirs[blk_owner[blk[theirs]] == dst]]
     recv = {k: np.concatenate(v) for k, v in recv.items()}

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <new>
 #include <stdexcept>
@@ -230,6 +231,19 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
   return ZPQ_OK;
 }
 
+// ZPQJ_TIMING=1: the phases of an add on stderr (milliseconds of host wall clock; debugging aid)
+struct PhaseClock {
+  bool on; std::chrono::steady_clock::time_point t0, last; std::string line;
+  PhaseClock() : on(getenv("ZPQJ_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), last(t0) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    char b[96]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - last).count());
+    line += b; last = now;
+  }
+  ~PhaseClock() { if (on) fprintf(stderr, "[zpqj add %.1f ms]%s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), line.c_str()); }
+};
+
 // ---- add ----------------------------------------------------------------------------------------------------------
 // One context per GPU.  Files (name order) are cut into contiguous ranges of about equal size, one per context;
 // every context fragments and hashes its range; the tables are concatenated in range order (what an RCCL all-gather
@@ -337,6 +351,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   bool hint = (flags & ZPQJ_METHOD_HINT) != 0;
   for (const char* q = method; hint && q && *q; ++q) if (*q < '0' || *q > '9') hint = false;     // only for "LB" methods
   zpq_ctx* ctx = ctxs[0];
+  PhaseClock clk;
   Index ix;
   if (archive && archive_len) { int rc = read_index(ctx, archive, archive_len, ix); if (rc) return rc; }
   std::unordered_map<Sha1Key, uint32_t, Sha1Hash> known;
@@ -368,6 +383,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
   }
+  clk.mark("fragment+sha1");
   if (X) {
     // exchange 1: every rank's fragment table (lengths, owning files, SHA-1s) and file checksums
     Bytes snd; std::vector<Bytes> got;
@@ -419,6 +435,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     zpq_dev_free_pooled(ctx, d_dig); zpq_dev_free_pooled(ctx, d_first);
     if (rc) return rc;
   }
+  clk.mark("tables+dedup");
   // fragment ids: known from earlier versions, else new (first occurrence in this batch)
   const uint32_t first_new_id = (uint32_t)ix.ht.size();
   std::vector<uint32_t> id(nf, 0), newfrags;
@@ -440,6 +457,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   std::vector<Bytes> dblock(blocks.size());
   std::vector<int> brc(nctx, ZPQ_OK);
+  clk.mark("ids+pack");
   // exchange 2 (process-sharded): the fragments a block takes from a rank other than its owner (the packing crosses a range
   // edge at most once per edge, so this is a few fragments per rank).  Every rank derives the same list from the global
   // table; a sender gathers its part on the device, and xoff[k] is where fragment newfrags[k] sits in its sender's string.
@@ -518,6 +536,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       }
       if (R.len && (rc = zpq_copy_peer(c, (uint8_t*)d_blk + R.dst_off, sh[R.src_shard].ctx, (const uint8_t*)sh[R.src_shard].d_data + R.src_off, R.len))) return rc;
     }
+    if (nctx == 1) clk.mark("gather");
     std::vector<zpq_block_job> jobs(mine.size());
     std::vector<std::string> nm(mine.size());
     uint64_t opos = 0; std::vector<uint64_t> ooff(mine.size());
@@ -565,7 +584,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       j.out = (uint8_t*)d_out + ooff[m]; j.out_cap = (uint32_t)zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01");
     }
     if ((rc = zpq_sync(c))) return rc;
+    if (nctx == 1) clk.mark("trailers");
     if ((rc = zpq_compress_blocks_dev(c, jobs.data(), jobs.size()))) return rc;
+    if (nctx == 1) clk.mark("compressBlock");
     for (size_t m = 0; m < mine.size(); ++m) {
       dblock[mine[m]].resize(jobs[m].out_len);
       if ((rc = zpq_d2h(c, dblock[mine[m]].data(), jobs[m].out, jobs[m].out_len))) return rc;
@@ -574,7 +595,8 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   };
   {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { brc[r] = compress_owned(r); });
+    if (nctx == 1) brc[0] = compress_owned(0);
+    else for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { brc[r] = compress_owned(r); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (brc[r]) return brc[r];
   }
@@ -597,6 +619,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     }
     for (size_t b = 0; b < blocks.size(); ++b) if (dblock[b].empty()) return ZPQ_ERR_FORMAT;
   }
+  clk.mark("d blocks");
   Bytes dpart;                                      // the d blocks, in block order whoever compressed them
   std::vector<uint32_t> dsize(blocks.size());
   for (size_t b = 0; b < blocks.size(); ++b) { dsize[b] = (uint32_t)dblock[b].size(); dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end()); }
@@ -643,8 +666,10 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       tmp = Bytes();
     }
   }
+  clk.mark("index built");
   std::vector<Bytes> hout;
   if ((rc = compress_host_many(ctx, hb, hout))) return rc;
+  clk.mark("index compressed");
   Bytes outb;
   size_t need = dpart.size();
   for (const Bytes& o : hout) need += o.size();
@@ -652,6 +677,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   outb.insert(outb.end(), hout[0].begin(), hout[0].end());
   outb.insert(outb.end(), dpart.begin(), dpart.end());
   for (size_t k = 1; k < hout.size(); ++k) outb.insert(outb.end(), hout[k].begin(), hout[k].end());
+  clk.mark("archive");
   *out = (uint8_t*)malloc(outb.size() ? outb.size() : 1);
   if (!*out) return ZPQ_ERR_NOMEM;
   memcpy(*out, outb.data(), outb.size());
