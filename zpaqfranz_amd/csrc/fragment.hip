@@ -35,7 +35,7 @@ namespace {
 // The speculation segment (independent of the fragment size limits) is chosen per call so that the
 // resident lanes get one segment each: a lane walks ~10-40 MB/s, so a second, partly filled round of
 // segments would cost as much again as the first.
-constexpr u64 kSegMin = 1ull << 18, kSegMax = 1ull << 20, kSegGrain = 1ull << 14;   // (64 KiB segments: 19 ms of per-file stitching on a 212 MB call, 4 ms with 256 KiB)
+constexpr u64 kSegMin = 1ull << 18, kSegMax = 1ull << 22, kSegGrain = 1ull << 14;   // (64 KiB segments: 19 ms of per-file stitching on a 212 MB call, 4 ms with 256 KiB)
 constexpr u64 kNone = ~0ull;
 
 struct FragP {
@@ -568,8 +568,11 @@ int fragment_run(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* file_off, 
   for (size_t f = 0; f < nfiles; ++f)
     if (!rep || rep[f] == f) total += file_off[f + 1] - file_off[f];
   const u64 readable = (all_bytes + 3) & ~3ull;  // callers pad allocations by >= 16 bytes (see header)
-  // every resident lane owns 256 B of LDS: 10 waves per CU fill the 160 KiB
-  int waves_per_cu = 10;
+  // Every resident lane owns 256 B of LDS: 10 waves per CU would fill the 160 KiB.  Six do better (round 5, profiles/
+  // r05c_sweep_fragment_waves_per_cu.txt: the kernel alone 43.7 ms against 55.8 for 54 GB, the step with twelve jobs in flight 109
+  // against 117 ms): fewer lanes means longer segments -- a smaller share of crossing walks and of steps a wave spends behind
+  // its slowest lane -- and 64 KiB of every unit's LDS stay free for the other jobs' kernels; with four the SIMDs run dry.
+  int waves_per_cu = 6;
   if (const char* e = getenv("ZPQ_FRAG_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 10) waves_per_cu = v; }
   u64 cap_waves = (u64)ctx->cu_count * (u64)waves_per_cu;
   {

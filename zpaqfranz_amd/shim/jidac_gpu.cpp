@@ -493,6 +493,12 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     if ((rc = xchg_all(*X, snd, xgot))) return rc;
     for (size_t r = 0; r < nctx; ++r) if (r != me && xgot[r].size() != cur[r]) return ZPQ_ERR_FORMAT;
   }
+  // One context and no exchange (zpqj_add, zpqj_add_dev): the compressed d blocks wait in HBM until the index blocks are
+  // compressed too and the archive's layout is known; then they are packed back to back by one gather and come over in ONE
+  // copy, straight to their place in the buffer that is returned (no per-block copies, no intermediate strings).
+  const bool one = nctx == 1 && !X;
+  struct Packed { zpq_ctx* c = nullptr; void* d_out = nullptr; std::vector<uint64_t> off; std::vector<uint32_t> len;
+                  ~Packed() { if (d_out) zpq_dev_free_pooled(c, d_out); } } packed;
   auto compress_owned = [&](size_t r) -> int {
     zpq_ctx* c = X ? ctxs[0] : ctxs[r];
     std::vector<size_t> mine;
@@ -550,7 +556,8 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       ooff[m] = opos; opos += (zpq_block_bound(bn[m], nm[m].c_str(), "jDC\x01") + 63) & ~(size_t)63;
     }
     void* d_out;
-    if ((rc = zpq_dev_alloc_pooled(c, opos + 64, &d_out))) return rc; dev.p.push_back(d_out);
+    if ((rc = zpq_dev_alloc_pooled(c, opos + 64, &d_out))) return rc;
+    if (one) { packed.c = c; packed.d_out = d_out; } else dev.p.push_back(d_out);
     // "method,R,t" per block (zpaq's add(); ZSFX/libzpaq.h:86-135): R from the order-1 hits of its fragments, t from the
     // text / exe votes -- one lane per fragment over the assembled blocks
     std::vector<std::string> mth(mine.size(), std::string(method));
@@ -587,6 +594,11 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     if (nctx == 1) clk.mark("trailers");
     if ((rc = zpq_compress_blocks_dev(c, jobs.data(), jobs.size()))) return rc;
     if (nctx == 1) clk.mark("compressBlock");
+    if (one) {          // (mine = every block, in order)
+      packed.off = ooff; packed.len.resize(mine.size());
+      for (size_t m = 0; m < mine.size(); ++m) { if (jobs[m].status) return jobs[m].status; packed.len[m] = jobs[m].out_len; }
+      return ZPQ_OK;
+    }
     for (size_t m = 0; m < mine.size(); ++m) {
       dblock[mine[m]].resize(jobs[m].out_len);
       if ((rc = zpq_d2h(c, dblock[mine[m]].data(), jobs[m].out, jobs[m].out_len))) return rc;
@@ -620,13 +632,18 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     for (size_t b = 0; b < blocks.size(); ++b) if (dblock[b].empty()) return ZPQ_ERR_FORMAT;
   }
   clk.mark("d blocks");
-  Bytes dpart;                                      // the d blocks, in block order whoever compressed them
+  Bytes dpart;                                      // the d blocks, in block order whoever compressed them (one context: they are still in HBM)
   std::vector<uint32_t> dsize(blocks.size());
-  for (size_t b = 0; b < blocks.size(); ++b) { dsize[b] = (uint32_t)dblock[b].size(); dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end()); }
+  uint64_t dtotal = 0;
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    dsize[b] = one ? packed.len[b] : (uint32_t)dblock[b].size();
+    dtotal += dsize[b];
+    if (!one) dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end());
+  }
   // 4. c block, d blocks, h blocks, i blocks: the index blocks are put together first and compressed by ONE call
   std::vector<HostBlock> hb;
   {
-    Bytes t8; put64(t8, dpart.size());
+    Bytes t8; put64(t8, dtotal);
     hb.push_back({t8, "0", block_name(version_date, 'c', first_new_id)});
   }
   for (size_t b = 0; b < blocks.size(); ++b) {
@@ -660,7 +677,12 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     size_t f1 = fi;
     while (f1 < nf && ffile[f1] == k) ++f1;
     put32(tmp, (uint32_t)(f1 - fi));
-    for (; fi < f1; ++fi) put32(tmp, id[fi]);
+    {                                                  // ni pointers, 4 bytes each, low byte first
+      const size_t at = tmp.size();
+      tmp.resize(at + 4 * (f1 - fi));
+      uint8_t* q = tmp.data() + at;
+      for (; fi < f1; ++fi, q += 4) { const uint32_t v = id[fi]; q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); q[3] = (uint8_t)(v >> 24); }
+    }
     if (tmp.size() > 16000 || k + 1 == nfiles) {       // zpaq flushes the index every ~16 KB
       hb.push_back({std::move(tmp), "1", block_name(version_date, 'i', inum++)});
       tmp = Bytes();
@@ -670,21 +692,39 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   std::vector<Bytes> hout;
   if ((rc = compress_host_many(ctx, hb, hout))) return rc;
   clk.mark("index compressed");
-  Bytes outb;
-  size_t need = dpart.size();
+  size_t need = (size_t)dtotal;
   for (const Bytes& o : hout) need += o.size();
-  outb.reserve(need);
-  outb.insert(outb.end(), hout[0].begin(), hout[0].end());
-  outb.insert(outb.end(), dpart.begin(), dpart.end());
-  for (size_t k = 1; k < hout.size(); ++k) outb.insert(outb.end(), hout[k].begin(), hout[k].end());
+  uint8_t* ob = (uint8_t*)malloc(need ? need : 1);
+  if (!ob) return ZPQ_ERR_NOMEM;
+  struct Guard { uint8_t* p; ~Guard() { free(p); } } guard{ob};          // (released to the caller at the end)
+  size_t at = 0;
+  memcpy(ob + at, hout[0].data(), hout[0].size()); at += hout[0].size();
+  if (one && dtotal) {
+    // pack on the device (the blocks sit at their capacity bounds), then one copy to where the d blocks belong
+    zpq_ctx* c = packed.c;
+    struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{c, {}};
+    std::vector<uint64_t> dso(blocks.size());
+    uint64_t q = 0;
+    for (size_t b = 0; b < blocks.size(); ++b) { dso[b] = q; q += dsize[b]; }
+    void *d_pack, *d_so, *d_sl, *d_dso;
+    if ((rc = zpq_dev_alloc_pooled(c, dtotal + 64, &d_pack))) return rc; dev.p.push_back(d_pack);
+    if ((rc = zpq_dev_alloc_pooled(c, blocks.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
+    if ((rc = zpq_dev_alloc_pooled(c, blocks.size() * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+    if ((rc = zpq_dev_alloc_pooled(c, blocks.size() * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+    if ((rc = zpq_h2d(c, d_so, packed.off.data(), blocks.size() * 8)) || (rc = zpq_h2d(c, d_sl, dsize.data(), blocks.size() * 4)) ||
+        (rc = zpq_h2d(c, d_dso, dso.data(), blocks.size() * 8))) return rc;
+    if ((rc = zpq_gather_dev(c, (const uint8_t*)packed.d_out, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, blocks.size(), (uint8_t*)d_pack))) return rc;
+    if ((rc = zpq_d2h(c, ob + at, d_pack, (size_t)dtotal))) return rc;
+  } else if (dtotal) memcpy(ob + at, dpart.data(), dpart.size());
+  at += (size_t)dtotal;
+  for (size_t k = 1; k < hout.size(); ++k) { memcpy(ob + at, hout[k].data(), hout[k].size()); at += hout[k].size(); }
   clk.mark("archive");
-  *out = (uint8_t*)malloc(outb.size() ? outb.size() : 1);
-  if (!*out) return ZPQ_ERR_NOMEM;
-  memcpy(*out, outb.data(), outb.size());
-  *out_len = outb.size();
+  guard.p = nullptr;
+  *out = ob;
+  *out_len = need;
   if (stats) {
     uint64_t ub = 0; for (uint32_t f : newfrags) ub += flen[f];
-    stats[0] = nf; stats[1] = newfrags.size(); stats[2] = blocks.size(); stats[3] = ub; stats[4] = dpart.size(); stats[5] = outb.size();
+    stats[0] = nf; stats[1] = newfrags.size(); stats[2] = blocks.size(); stats[3] = ub; stats[4] = dtotal; stats[5] = need;
   }
   return ZPQ_OK;
 }
