@@ -1113,7 +1113,7 @@ def compact_line(d, top=6):
     cb = d.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
-    for k in ("blake3_verify", "no_fold", "every_byte_hashed", "twin_fold_on", "single_job"):
+    for k in ("blake3_verify", "no_fold", "every_byte_hashed", "twin_fold_on", "single_job", "product_one_call", "archive_blocks"):
         if isinstance(d.get(k), dict):
             out[k] = {kk: vv for kk, vv in d[k].items() if kk != "note"}
     return out

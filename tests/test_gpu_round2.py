@@ -534,6 +534,39 @@ def test_sha1_extents_staged_and_direct_forms_agree_with_hashlib(staged):
         assert "digests ok: True" in r.stdout and ("staged=%s" % staged) in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("late", ["0", "1"])
+def test_sha1_extents_staged_form_both_store_orders(late):
+    """The wave-fetched fragment SHA-1 (> 4096 extents) with the staging rows parked after the first or after both blocks of a trip
+    (ZPQ_SHA1_LATE): 5000 extents of 0..700 bytes plus a few long ones, ragged starts, every digest against hashlib.  Plain C ABI,
+    no torch: runs on the emulated engine too.  (The order is read once per process, hence the subprocess.)"""
+    import subprocess, sys
+    code = r'''
+import ctypes as C, hashlib, os, sys
+sys.path.insert(0, os.environ["ZPQ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["ZPQ_ROOT"], "tests"))
+import numpy as np
+from zpaqfranz_amd import Engine
+rng = np.random.default_rng(9)
+lens = rng.integers(0, 700, size=5000).astype(np.uint32)
+lens[[7, 1234, 4999]] = [70001, 128, 4097]; lens[[11, 12, 13]] = [64, 63, 65]
+gaps = rng.integers(0, 9, size=5000)
+off = np.cumsum(np.concatenate(([3], (lens[:-1] + gaps[:-1]).astype(np.int64)))).astype(np.uint64)
+total = int(off[-1] + lens[-1])
+data = rng.integers(0, 256, size=total, dtype=np.uint8).tobytes()
+eng = Engine(0)
+d, do, dl, dg = eng.upload(data), eng.upload(off.tobytes()), eng.upload(lens.tobytes()), eng.alloc(5000 * 20 + 64)
+eng.sha1_extents_dev(d.ptr, do.ptr, dl.ptr, 5000, dg.ptr)
+eng.sync()
+got = dg.download(5000 * 20)
+bad = [i for i in range(5000) if got[20 * i:20 * i + 20] != hashlib.sha1(data[int(off[i]):int(off[i]) + int(lens[i])]).digest()]
+print("bad", bad[:5], len(bad))
+sys.exit(1 if bad else 0)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZPQ_SHA1_LATE=late, ZPQ_SHA1_STAGED="1", ZPQ_ROOT=root),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("level", [1, 2])
 def test_shim_compressor_startblock_level(tmp_path, level):
     """Compressor::startBlock(int level) (ZSFX/libzpaq.h:1346): the block carries libzpaq's built-in model `level`, the coded
