@@ -534,11 +534,11 @@ def test_sha1_extents_staged_and_direct_forms_agree_with_hashlib(staged):
         assert "digests ok: True" in r.stdout and ("staged=%s" % staged) in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("late", ["0", "1"])
-def test_sha1_extents_staged_form_both_store_orders(late):
-    """The wave-fetched fragment SHA-1 (> 4096 extents) with the staging rows parked after the first or after both blocks of a trip
-    (ZPQ_SHA1_LATE): 5000 extents of 0..700 bytes plus a few long ones, ragged starts, every digest against hashlib.  Plain C ABI,
-    no torch: runs on the emulated engine too.  (The order is read once per process, hence the subprocess.)"""
+@pytest.mark.parametrize("waves", ["1", "2"])
+def test_sha1_extents_staged_form_without_torch(waves):
+    """The wave-fetched fragment SHA-1 (> 4096 extents): 5000 extents of 0..700 bytes plus a few long ones, ragged starts, every
+    digest against hashlib, with four and with eight waves per compute unit (ZPQ_SHA_WAVES).  Plain C ABI, no torch: runs on the
+    emulated engine too.  (The grid is read per process, hence the subprocess.)"""
     import subprocess, sys
     code = r'''
 import ctypes as C, hashlib, os, sys
@@ -562,7 +562,7 @@ print("bad", bad[:5], len(bad))
 sys.exit(1 if bad else 0)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZPQ_SHA1_LATE=late, ZPQ_SHA1_STAGED="1", ZPQ_ROOT=root),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZPQ_SHA_WAVES=waves, ZPQ_SHA1_STAGED="1", ZPQ_ROOT=root),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
 

@@ -153,7 +153,7 @@ constexpr u32 kHalfDwords = 64 * kRowDwords;
 
 __global__ __launch_bounds__(64) void sha1_extents_staged_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                                   const u32* __restrict__ len, u32 n, u8* __restrict__ digests,
-                                                                  u32* __restrict__ counter, const u32* __restrict__ order, const u32 late) {
+                                                                  u32* __restrict__ counter, const u32* __restrict__ order) {
   __shared__ u32x4 stage_raw[2 * kHalfDwords / 4];
   u32* const stage = (u32*)stage_raw;
   const u32 lane = (u32)lane_id();
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void sha1_extents_staged_kernel(const u8* __res
     const u32* mine = stage + cur * kHalfDwords + lane * kRowDwords;
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
-      if (slot == 1 && !late) {
+      if (slot == 1) {
         // (D) the requested rows go to the other half (nobody reads it during this trip)
         u32* dst = stage + (cur ^ 1) * kHalfDwords + (lane >> 3) * kRowDwords + (lane & 7) * 4;
 #pragma unroll
@@ -233,13 +233,6 @@ __global__ __launch_bounds__(64) void sha1_extents_staged_kernel(const u8* __res
           have = false;
         }
       }
-    }
-    if (late) {
-      // (D), late form (round 5): the rows are parked after BOTH blocks of the trip -- a fetch then has two blocks' worth of rounds
-      // (~2 us) to arrive instead of one, at the price of 32 registers held across the second block (two waves per SIMD: 256 each)
-      u32* dst = stage + (cur ^ 1) * kHalfDwords + (lane >> 3) * kRowDwords + (lane & 7) * 4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) *(u32x4*)(dst + 8 * i * kRowDwords) = row[i];
     }
     fresh = false;
     cur ^= 1;
@@ -647,9 +640,13 @@ int zpq_sha1_extents_on(zpq_ctx* ctx, hipStream_t s, const u8* d_base, const u64
   static const int staged = [] { const char* e = getenv("ZPQ_SHA1_STAGED"); return e ? atoi(e) : 1; }();
   if (staged && n > 4096) {
     // many extents: the wave-fetched form (one wave per workgroup, 18 KiB of LDS each)
-    static const u32 late = [] { const char* e = getenv("ZPQ_SHA1_LATE"); return e ? (u32)atoi(e) : 0u; }();
-    ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_staged_kernel, dim3(grid * 4), dim3(64), d_base, d_off, d_len, (u32)n, d_digests, counter,
-               order, late);
+    // Four waves per compute unit (round 5, profiles/r05f_sweep_sha1_waves.txt): 24.1 ms for the 54 GB of config 2 against 27.1 ms with
+    // eight -- 64 lanes of a wave read 64 pages, and the address translation is what more waves in flight make worse -- and
+    // 72 KiB of every unit's LDS stay free for the other jobs.  (Parking the staging rows a block later, so that a fetch has two
+    // blocks' worth of rounds to arrive, was measured too: no difference, 27.05 against 27.12 ms.)
+    const int grid4 = persistent_grid(ctx, n, 1);
+    ZPQ_LAUNCH(ctx, prof_name, s, sha1_extents_staged_kernel, dim3(grid4 * 4), dim3(64), d_base, d_off, d_len, (u32)n, d_digests, counter,
+               order);
     ZPQ_HIP(ctx, hipGetLastError());
     return ZPQ_OK;
   }
