@@ -14,5 +14,6 @@ print("headline", d["value"], d["ms_per_step"], "single", (d.get("single_job") o
 print("roofline", d.get("roofline"))
 print("summary", d.get("workloads_summary"), d.get("failed_workloads"))
 PY
+bash tools/gpu_pmc_dup8.sh $T
 echo "[$(( $(date +%s) - S0 )) s] done"
 grep -v "^\[bench.py\]" gpurun_out/${T}_bench.err | tail -5
