@@ -247,6 +247,38 @@ def test_lz77_streams_bit_identical(eng, args):
 
 
 L2_HASH_ARGS = [(4, 2, 5, 0, 3, 22), (4, 2, 12, 0, 3, 24), (0, 2, 4, 0, 1, 18), (5, 2, 6, 0, 2, 20), (4, 2, 4, 0, 0, 16)]
+# (block bits, level, minMatch, minMatch2, log2 bucket, log2 table, lookahead): a second, higher-order context and lookahead
+SECOND_CONTEXT_ARGS = [(4, 1, 4, 8, 3, 24, 0), (4, 1, 4, 8, 3, 24, 1), (4, 1, 5, 12, 2, 22, 2), (0, 1, 4, 6, 0, 18, 0), (4, 2, 4, 8, 3, 22, 1),
+                       (4, 2, 6, 10, 1, 20, 3), (5, 1, 4, 9, 3, 25, 1), (4, 1, 4, 0, 3, 24, 2), (4, 1, 6, 3, 2, 20, 0)]
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref/libzpaqref.so not available")
+@pytest.mark.parametrize("args", SECOND_CONTEXT_ARGS)
+def test_lz77_second_context_and_lookahead_equal_the_real_lzbuffer(eng, args):
+    """args[3] = minMatch2 > 0 (and / or args[6] = lookahead > 0) with the hash-table finder: LZBuffer searches the bucket of a
+    second, higher-order hash first -- matches counted from `lookahead` bytes on and extended backwards, the bytes in front become
+    leading literals -- and both hashes share one table (ZSFX/libzpaq.cpp:6263-6290, 6373-6447).  The code stream of
+    lz77_generic_kernel must be the REAL LZBuffer's, bit for bit (level 1) / byte for byte (level 2), on text, binary, mixed and
+    constructed inputs, empty and tiny blocks, and the stream must decode back."""
+    rng = np.random.default_rng(33)
+    base = rng.integers(0, 256, size=50000, dtype=np.uint8).tobytes()
+    rep = bytearray()
+    for i in range(900):                       # repeats whose first bytes were changed: matches that start behind a lookahead
+        q = int(rng.integers(0, 49000))
+        piece = bytearray(base[q:q + int(rng.integers(6, 60))])
+        if i % 3 == 0 and len(piece) > 3:
+            piece[0] ^= 0x5a
+        if i % 5 == 0 and len(piece) > 4:
+            piece[1] ^= 0x33
+        rep += piece + bytes(rng.integers(0, 256, size=int(rng.integers(0, 4)), dtype=np.uint8))
+    blocks = [datagen.text_like(120000, 41), datagen.mixed(90000, 42), base + bytes(rep), datagen.binary_like(60000, 43), bytes(20000), b"", b"q",
+              b"abcabcabc" * 30, datagen.text_like(9000, 44) * 3]
+    out = eng.lz77_encode(blocks, [args] * len(blocks))
+    for b, o in zip(blocks, out):
+        assert o == orc.ref_lzbuffer(b, list(args)), (args, len(b))
+    if args[1] == 1:                           # and it is a stream the level-1 decoder restores
+        for b, o in zip(blocks, out):
+            assert orc.lz77_decode(o, len(b) + 64, rb=max(0, args[0] - 4)) == b
 
 
 @pytest.mark.parametrize("args", L2_HASH_ARGS)
@@ -413,12 +445,14 @@ def test_compress_block_cm_methods_equal_reference_coder(eng, method):
 
 
 def test_unsupported_methods_are_refused_not_approximated(eng):
-    # what is still outside the implemented family is refused, never approximated: a secondary LZ77 context (args[3] > 0:
-    # the second hash table of LZBuffer is not restated), BWT + E8E9 above 16 MiB blocks (its post-processor is not
-    # restated), pre-processor numbers that do not exist.  (Levels 2 / 3 / E8E9-only are served since round 3, level 2 from
-    # the hash-table finder since round 4: tests/test_gpu_m3.py.)
-    res = eng.compress_blocks([b"hello world" * 100] * 3, ["x4,1,4,8,3,24", "x5,7ci1", "x4,9ci1"], None, None, True)
+    # what is still outside the implemented family is refused, never approximated: BWT + E8E9 above 16 MiB blocks (its
+    # post-processor is not restated), pre-processor numbers that do not exist, a secondary context beyond 64 bytes.  (Levels
+    # 2 / 3 / E8E9-only are served since round 3, level 2 from the hash-table finder since round 4, a secondary LZ77 context
+    # and lookahead since round 5: test_lz77_second_context_and_lookahead_equal_the_real_lzbuffer.)
+    res = eng.compress_blocks([b"hello world" * 100] * 3, ["x4,1,4,80,3,24", "x5,7ci1", "x4,9ci1"], None, None, True)
     assert [st for st, _ in res] == [-5, -5, -5]
+    (st, blk), = eng.compress_blocks([b"hello world" * 100], ["x4,1,4,8,3,24,1"], None, None, True)       # second context of 8 bytes, lookahead 1
+    assert st == 0 and eng.decompress_blocks([blk], [2000])[0]["data"] == b"hello world" * 100
     (st, blk), = eng.compress_blocks([b"hello world" * 100], ["x4,6,4,0,3,24c0"], None, None, True)       # byte codes from the hash-table finder + E8E9
     assert st == 0 and eng.decompress_blocks([blk], [2000])[0]["data"] == b"hello world" * 100
     (st, blk), = eng.compress_blocks([b"hello world" * 100], ["14,100,2"], None, None, True)

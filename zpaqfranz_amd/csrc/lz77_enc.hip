@@ -836,6 +836,197 @@ __global__ __launch_bounds__(1024) void lz77_pack_tokens_kernel(const LzJobDev* 
   }
 }
 
+
+// ---- the hash-table finder with a SECOND, higher-order context and lookahead (args[3] = minMatch2 > 0, args[6]) -----------------
+// LZBuffer::fill's hash branch in full (ZSFX/libzpaq.cpp:6373-6447): the bucket of the order-(minMatch2 + lookahead) hash h2 is
+// searched first -- a match is counted from `lookahead` bytes behind the position, then extended backwards, the bytes in front of
+// it become leading literals -- and the order-minMatch bucket only if that found nothing of minMatch2 bytes; both hashes index
+// the SAME table and every position is inserted under both.  No built-in level asks for it ("x" methods only), so it gets the
+// plain formulation: ONE WAVE PER BLOCK walks the positions the parse visits, lanes = the 2 x (bucket + 1) candidates of a
+// position (table word, match length by 8-byte compares, backward extension), the reference's in-order selection on
+// `v_readlane`d results, the code stream written as the parse goes (LZBuffer::write_literal / write_match / putb / put,
+// :6166-6184, :6452-6547 -- bits or, level 2, bytes), the skipped positions inserted 64 at a time (hashes computed from the
+// bytes, "latest position wins" by atomic maximum).  Two or three dependent memory round trips per visited position: a
+// fallback's speed (about a megabyte per second and block), many blocks side by side.
+struct GenericJob {
+  const u8* in; u32 n;
+  u32 minMatch, minMatch2, lookahead, bucket, htbits, checkbits, shift1, shift2, rb, level, minMatchBoth;
+  u32* ht;             // 2^htbits words, zeroed
+  u8* out; u32 out_cap;
+  u32* result;         // [0] matches, [1] bytes written, [2] overflow
+};
+
+struct ByteSink {      // wave-uniform state; lane 0 stores
+  __attribute__((address_space(1))) u8* out; u32 cap, pos, overflow;
+  u64 acc; u32 nbits;
+  __device__ __forceinline__ void byte(u32 b, u32 lane) {
+    if (pos < cap) { if (lane == 0) out[pos] = (u8)b; } else overflow = 1;
+    ++pos;
+  }
+  __device__ __forceinline__ void putb(u32 x, u32 k, u32 lane) {      // k <= 24 bits, LSB first (:6171-6179)
+    acc |= (u64)(x & ((1u << k) - 1u)) << nbits;
+    nbits += k;
+    while (nbits >= 8) { byte((u32)(acc & 255u), lane); acc >>= 8; nbits -= 8; }
+  }
+  __device__ __forceinline__ void flush(u32 lane) { if (nbits) { byte((u32)(acc & 255u), lane); acc = 0; nbits = 0; } }
+};
+
+// h1 / h2 as LZBuffer holds them when it reaches position q (the rolling updates of :6438-6444 folded from the bytes; `la` = 0 and
+// the order-minMatch constants for h1, `lookahead` and the order-minMatch2 constants for h2); updates stop at upd_limit
+__device__ __forceinline__ u32 generic_hash(g_cu8* in, u32 q, u32 upd_limit, u32 order, u32 la, u32 mulc, u32 shift, u32 addc, u32 htmask) {
+  const u32 U = q < upd_limit ? q : upd_limit;
+  const u32 F = mulc << shift;
+  u32 h = 0;
+  for (u32 t = U > order ? U - order : 0; t < U; ++t) h = h * F + ((u32)in[t + order + la] + 1u) * addc;
+  return h & htmask;
+}
+
+__device__ __forceinline__ u32 generic_match_from(g_cu8* in, u32 p, u32 i, u32 from, u32 limit) {   // first l >= from with in[p+l] != in[i+l], capped at limit
+  u32 l = from;
+  while (l + 8 <= limit) {
+    const u64 x = load8(in + p + l) ^ load8(in + i + l);
+    if (x) return l + (u32)(__builtin_ctzll(x) >> 3);
+    l += 8;
+  }
+  while (l < limit && in[p + l] == in[i + l]) ++l;
+  return l;
+}
+
+__global__ __launch_bounds__(64) void lz77_generic_kernel(const GenericJob* __restrict__ jobs) {
+  const GenericJob J = jobs[blockIdx.x];
+  const u32 lane = (u32)lane_id();
+  g_cu8* in = (g_cu8*)J.in;
+  g_u32* ht = (g_u32*)J.ht;
+  const u32 n = J.n, mm = J.minMatch, mm2 = J.minMatch2, la = J.lookahead, NB = J.bucket + 1u;
+  const u32 htmask = (1u << J.htbits) - 1u, mask = (1u << J.checkbits) - 1u;
+  const u32 upd_limit = n > J.minMatchBoth ? n - J.minMatchBoth : 0u;          // positions i with i + minMatchBoth < n are inserted
+  ByteSink bs{(__attribute__((address_space(1))) u8*)J.out, J.out_cap, 0u, 0u, 0ull, 0u};
+  auto at = [&](u32 x) -> u32 { return x < n ? (u32)in[x] : 0u; };             // (bytes behind the block read as 0)
+  auto write_literal = [&](u32 i, u32& lit) {                                  // :6452-6485
+    if (J.level == 1) {
+      if (lit < 1) return;
+      int ll = lg32(lit);
+      bs.putb(0, 2, lane);
+      --ll;
+      while (--ll >= 0) { bs.putb(1, 1, lane); bs.putb((lit >> ll) & 1u, 1, lane); }
+      bs.putb(0, 1, lane);
+      while (lit) { bs.putb((u32)in[i - lit], 8, lane); --lit; }
+    } else {
+      while (lit > 0) {
+        const u32 lit1 = lit > 64 ? 64u : lit;
+        bs.byte(lit1 - 1, lane);
+        for (u32 j = i - lit; j < i - lit + lit1; ++j) bs.byte((u32)in[j], lane);
+        lit -= lit1;
+      }
+    }
+  };
+  auto write_match = [&](u32 len, u32 off) {                                   // :6488-6547
+    if (J.level == 1) {
+      int ll = lg32(len) - 1;
+      off += (1u << J.rb) - 1u;
+      const int lo = lg32(off) - 1 - (int)J.rb;
+      bs.putb((u32)(lo + 8) >> 3, 2, lane);
+      bs.putb((u32)lo & 7u, 3, lane);
+      while (--ll >= 2) { bs.putb(1, 1, lane); bs.putb((len >> ll) & 1u, 1, lane); }
+      bs.putb(0, 1, lane);
+      bs.putb(len & 3u, 2, lane);
+      bs.putb(off, J.rb, lane);
+      if (lo > 0) bs.putb(off >> J.rb, (u32)lo, lane);
+    } else {
+      --off;
+      while (len > 0) {
+        const u32 len1 = len > mm * 2 + 63 ? mm + 63 : len > mm + 63 ? len - mm : len;
+        if (off < (1u << 16)) { bs.byte(64 + len1 - mm, lane); bs.byte(off >> 8, lane); bs.byte(off, lane); }
+        else if (off < (1u << 24)) { bs.byte(128 + len1 - mm, lane); bs.byte(off >> 16, lane); bs.byte(off >> 8, lane); bs.byte(off, lane); }
+        else { bs.byte(192 + len1 - mm, lane); bs.byte(off >> 24, lane); bs.byte(off >> 16, lane); bs.byte(off >> 8, lane); bs.byte(off, lane); }
+        len -= len1;
+      }
+    }
+  };
+  u32 i = 0, lit = 0, nmatch = 0;
+  while (i < n) {
+    // ---- the candidates of position i: lanes [0, NB) the h2 bucket, [NB, 2 NB) the h1 bucket, in probe order
+    const u32 h1 = generic_hash(in, i, upd_limit, mm, 0, 5u, J.shift1, 123456791u, htmask);
+    const u32 h2 = mm2 ? generic_hash(in, i, upd_limit, mm2, la, 9u, J.shift2, 23456789u, htmask) : 0u;
+    const bool grp2 = lane < NB, grp1 = lane >= NB && lane < 2 * NB;
+    u32 p = 0; bool valid = false;
+    u32 lo = 0, hi = 0;                     // in[p + x] == in[i + x] for x in [lo, hi); a mismatch (or a limit) at hi and at lo - 1
+    if ((grp2 && mm2) || grp1) {
+      const u32 e = __builtin_nontemporal_load(ht + ((grp2 ? h2 : h1) ^ (grp2 ? lane : lane - NB)));
+      const bool chk = grp2 ? true : i + 3 < n;                                   // (:6376 / :6398: only the lower order tests i + 3 < n)
+      if (e && chk && (e & mask) == (at(i + 3) & mask)) { p = e >> J.checkbits; valid = p < i; }
+    }
+    if (valid) {
+      const u32 limit = n - i < kMaxMatch ? n - i : kMaxMatch;                   // i + l < n && l < maxMatch
+      const u32 from = grp2 ? la : 0u;
+      hi = from <= limit ? generic_match_from(in, p, i, from, limit) : from;
+      lo = from;
+      while (lo > 0 && in[p + lo - 1] == in[i + lo - 1]) --lo;                  // (h2 only: back from the lookahead)
+    }
+    // ---- the reference's selection, candidate after candidate (:6373-6409)
+    u32 blen = mm - 1, bp = 0, blit = 0; int bscore = 0;
+    for (u32 k = 0; k < 2 * NB; ++k) {
+      if (k < NB && !mm2) continue;
+      if (k == NB && mm2 && blen >= mm2) break;                                   // "if (!minMatch2 || blen<minMatch2)"
+      const bool v = __shfl((int)valid, (int)k) != 0;
+      if (v) {
+        const u32 pk = (u32)__shfl((int)p, (int)k), lok = (u32)__shfl((int)lo, (int)k), hik = (u32)__shfl((int)hi, (int)k);
+        bool ok = i + blen <= n;
+        if (ok) {                                                                 // in[p+blen-1] == in[i+blen-1]
+          const u32 idx = blen - 1;
+          if (idx >= lok && idx < hik) ok = true;
+          else ok = in[pk + idx] == in[i + idx];                                    // (both inside the block: i + blen <= n, p < i)
+        }
+        if (ok) {
+          if (k < NB) {
+            const u32 l = hik;                                                    // counted from the lookahead
+            if (l >= mm2 + la) {
+              const u32 l1 = lok;
+              const int score = (int)(l - l1) * 8 - lg32(i - pk) - 8 * (int)(lit == 0 && l1 > 0) - 11;
+              if (score > bscore) { blen = l; bp = pk; blit = l1; bscore = score; }
+            }
+          } else {
+            const u32 l = hik;
+            const int score = (int)l * 8 - lg32(i - pk) - 2 * (int)(lit > 0) - 11;
+            if (score > bscore) { blen = l; bp = pk; blit = 0; bscore = score; }
+          }
+        }
+      }
+      if (blen >= 128) break;
+    }
+    // ---- take the match or count a literal (:6411-6426)
+    const u32 off = i - bp;
+    const u32 need = mm + (J.level == 2 ? (u32)(off >= (1u << 16)) + (u32)(off >= (1u << 24)) : 0u);
+    if (off > 0 && bscore > 0 && blen - blit >= need) {
+      lit += blit;
+      write_literal(i + blit, lit);
+      write_match(blen - blit, off);
+      ++nmatch;
+    } else {
+      blen = 1;
+      ++lit;
+    }
+    // ---- insert the blen positions from i on, under both hashes (:6430-6447); "latest position wins" = the maximum
+    for (u32 q0 = i; q0 < i + blen; q0 += 64) {
+      const u32 q = q0 + lane;
+      if (q < i + blen && q < upd_limit) {
+        const u32 ih = ((q * 1234547u) >> 19) & J.bucket;
+        const u32 val = (q << J.checkbits) | (at(q + 3) & mask);
+        if (val) {
+          if (mm2) atomicMax((u32*)J.ht + (generic_hash(in, q, upd_limit, mm2, la, 9u, J.shift2, 23456789u, htmask) ^ ih), val);
+          atomicMax((u32*)J.ht + (generic_hash(in, q, upd_limit, mm, 0, 5u, J.shift1, 123456791u, htmask) ^ ih), val);
+        }
+      }
+    }
+    ZPQ_WAIT_VMCNT0;
+    i += blen;
+    if (lit >= kMaxLiteral) write_literal(i, lit);
+  }
+  write_literal(n, lit);
+  bs.flush(lane);
+  if (lane == 0) { J.result[0] = nmatch; J.result[1] = bs.pos; J.result[2] = bs.overflow; }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -863,6 +1054,7 @@ int zpq_lz77_pack_launch(zpq_ctx* ctx, const zpq_lzjob_dev* d_jobs, size_t nj, u
 }
 
 static bool uses_suffix_array(const int32_t a[9]) { return a[5] - a[0] >= 21; }
+static bool uses_second_context(const int32_t a[9]) { return !uses_suffix_array(a) && (a[3] != 0 || a[6] != 0); }
 
 static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
   const int lvl = a[1] & 3;
@@ -876,7 +1068,8 @@ static int check_args(zpq_ctx* ctx, const int32_t a[9], u32 n) {
     if ((u64)n > (1ull << (20 + a[0]))) return zpq_fail(ctx, ZPQ_ERR_ARG, "block of %u bytes exceeds 2^%d", n, 20 + a[0]);
     return ZPQ_OK;
   }
-  if (a[3] != 0 || a[6] != 0) return zpq_fail(ctx, ZPQ_ERR_METHOD, "secondary context not implemented");
+  // a second, higher-order context and lookahead (lz77_generic_kernel): both up to 64 bytes
+  if (a[3] < 0 || a[3] > 64 || a[6] < 0 || a[6] > 64) return zpq_fail(ctx, ZPQ_ERR_METHOD, "secondary context %d / lookahead %d out of range", a[3], a[6]);
   if (a[2] < 4 || a[2] > 31) return zpq_fail(ctx, ZPQ_ERR_METHOD, "min match %d out of range", a[2]);
   if (a[4] < 0 || a[4] > 3) return zpq_fail(ctx, ZPQ_ERR_METHOD, "bucket 2^%d not implemented", a[4]);
   if (a[0] < 0 || a[0] > 6 || a[5] - a[0] >= 21 || a[5] < 4 || a[5] > 26 || a[5] <= a[4])
@@ -1137,6 +1330,59 @@ static int encode_batch(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t lo, size_t hi, 
 // what compressBlock asks before it queues a block for the encoder: a refusal belongs to that block, not to the whole call
 int zpq_lz77_check_args(zpq_ctx* ctx, const int32_t args[9], u32 n) { return check_args(ctx, args, n); }
 
+// Jobs whose hash-table finder has a second context / lookahead: one wave per block (lz77_generic_kernel), a table each, in
+// batches that fit the table arena.
+static int encode_second_context(zpq_ctx* ctx, zpq_lz77_job* jobs, const size_t* which, size_t nj_all) {
+  hipStream_t st = ctx->stream;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t have_b = free_b + ctx->scratch_cap[0], budget = std::max<size_t>((size_t)1 << 30, have_b / 2);
+  for (size_t lo = 0; lo < nj_all;) {
+    size_t hi = lo, words = 0;
+    while (hi < nj_all) {
+      const size_t w = (size_t)1 << jobs[which[hi]].args[5];
+      if (hi > lo && (words + w) * 4 > budget) break;
+      words += w; ++hi;
+    }
+    const size_t nj = hi - lo;
+    u32* d_tab = (u32*)zpq_scratch(ctx, 0, words * 4 + 256);
+    u8* d_meta = (u8*)zpq_scratch(ctx, 2, nj * (sizeof(GenericJob) + 16) + 512);
+    if (!d_tab || !d_meta) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "lz77 scratch (%zu MiB of tables)", words >> 18);
+    GenericJob* d_jobs = (GenericJob*)d_meta;
+    u32* d_res = (u32*)(d_meta + ((nj * sizeof(GenericJob) + 255) & ~(size_t)255));
+    std::vector<GenericJob> hj(nj);
+    size_t at = 0;
+    for (size_t k = 0; k < nj; ++k) {
+      const zpq_lz77_job& z = jobs[which[lo + k]];
+      const int32_t* a = z.args;
+      GenericJob& G = hj[k];
+      G.in = z.d_in; G.n = z.n;
+      G.minMatch = (u32)a[2]; G.minMatch2 = (u32)a[3]; G.lookahead = (u32)a[6]; G.bucket = (1u << a[4]) - 1u; G.htbits = (u32)a[5];
+      G.checkbits = (u32)(12 - a[0]); G.shift1 = (u32)((a[5] - 1) / a[2] + 1); G.shift2 = a[3] > 0 ? (u32)((a[5] - 1) / a[3] + 1) : 0u;
+      G.rb = a[0] > 4 ? (u32)(a[0] - 4) : 0u; G.level = (u32)(a[1] & 3);
+      G.minMatchBoth = (u32)std::max(a[2], a[3] + a[6]) + 4u;                   // :6283
+      G.ht = d_tab + at; at += (size_t)1 << a[5];
+      G.out = z.d_out; G.out_cap = z.out_cap; G.result = d_res + 4 * k;
+    }
+    ZPQ_HIP(ctx, hipMemsetAsync(d_tab, 0, words * 4, st));
+    ZPQ_HIP(ctx, hipMemsetAsync(d_res, 0, nj * 16, st));
+    ZPQ_HIP(ctx, hipMemcpyAsync(d_jobs, hj.data(), nj * sizeof(GenericJob), hipMemcpyHostToDevice, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    ZPQ_LAUNCH(ctx, "lz77_generic_kernel", st, lz77_generic_kernel, dim3((unsigned)nj), dim3(64), d_jobs);
+    ZPQ_HIP(ctx, hipGetLastError());
+    std::vector<u32> res(nj * 4);
+    ZPQ_HIP(ctx, hipMemcpyAsync(res.data(), d_res, nj * 16, hipMemcpyDeviceToHost, st));
+    ZPQ_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t k = 0; k < nj; ++k) {
+      jobs[which[lo + k]].n_matches = res[4 * k];
+      jobs[which[lo + k]].out_len = res[4 * k + 1];
+      if (res[4 * k + 2]) return zpq_fail(ctx, ZPQ_ERR_CAPACITY, "job %zu: output capacity exceeded", which[lo + k]);
+    }
+    lo = hi;
+  }
+  return ZPQ_OK;
+}
+
 extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njobs) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (njobs == 0) return ZPQ_OK;
@@ -1156,6 +1402,21 @@ extern "C" int zpq_lz77_encode_dev(zpq_ctx* ctx, zpq_lz77_job* jobs, size_t njob
       std::vector<zpq_lz77_job> rest;
       std::vector<size_t> at;
       for (size_t i = 0; i < njobs; ++i) if (!uses_suffix_array(jobs[i].args)) { rest.push_back(jobs[i]); at.push_back(i); }
+      rc = zpq_lz77_encode_dev(ctx, rest.data(), rest.size());
+      for (size_t k = 0; k < rest.size(); ++k) jobs[at[k]] = rest[k];
+      return rc;
+    }
+  }
+  {   // ... and so do the hash-table jobs with a second context or lookahead (one wave per block, lz77_generic_kernel)
+    std::vector<size_t> g_jobs;
+    for (size_t i = 0; i < njobs; ++i) if (uses_second_context(jobs[i].args)) g_jobs.push_back(i);
+    if (!g_jobs.empty()) {
+      int rc = encode_second_context(ctx, jobs, g_jobs.data(), g_jobs.size());
+      if (rc) return rc;
+      if (g_jobs.size() == njobs) return ZPQ_OK;
+      std::vector<zpq_lz77_job> rest;
+      std::vector<size_t> at;
+      for (size_t i = 0; i < njobs; ++i) if (!uses_second_context(jobs[i].args)) { rest.push_back(jobs[i]); at.push_back(i); }
       rc = zpq_lz77_encode_dev(ctx, rest.data(), rest.size());
       for (size_t k = 0; k < rest.size(); ++k) jobs[at[k]] = rest[k];
       return rc;
