@@ -225,13 +225,15 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
                                 U32* trace, long trace_cap, long* ntrace) {
   const U32 n = (U32)n_;
   const int level = args[1] & 3;
-  if (args[3] != 0 || args[6] != 0 || (level != 1 && level != 2) || args[5] - args[0] >= 21 || args[2] < 4) return -10;
+  if (args[3] < 0 || args[6] < 0 || (level != 1 && level != 2) || args[5] - args[0] >= 21 || args[2] < 4) return -10;
   const int checkbits = 12 - args[0];                 // :6253
   const U32 htsize = 1u << args[5];                   // :6250
   const U32 minMatch = args[2], maxMatch = (1u << 14) * 3, maxLiteral = (1u << 14) / 4;  // :6258-6262
   const U32 bucket = (1u << args[4]) - 1;             // :6265
   const int shift1 = (args[5] - 1) / minMatch + 1;    // :6266
-  const U32 minMatchBoth = minMatch + 4;              // :6268 with minMatch2=lookahead=0
+  const U32 minMatch2 = args[3], lookahead = args[6]; // :6257, :6263: the second (higher-order) context and how far in front of it a match may start
+  const int shift2 = minMatch2 > 0 ? (args[5] - 1) / minMatch2 + 1 : 0;   // :6267
+  const U32 minMatchBoth = (minMatch > minMatch2 + lookahead ? minMatch : minMatch2 + lookahead) + 4;   // :6268
   const int rb = args[0] > 4 ? args[0] - 4 : 0;       // :6269
   const U32 mask = (1u << checkbits) - 1;
   std::vector<U32> ht(htsize, 0);
@@ -257,9 +259,30 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
       len -= len1;
     }
   };
-  U32 i = 0, h1 = 0, lit = 0; long nt = 0;
+  U32 i = 0, h1 = 0, h2 = 0, lit = 0; long nt = 0;
+  auto byte_at = [&](U32 x) -> U32 { return x < n ? in[x] : 0u; };   // (the reference reads in[i+3] behind the block in the last 3 positions of the h2 search: taken as 0)
   while (i < n) {                                     // fill(), :6329-6453
-    U32 blen = minMatch - 1, bp = 0; int bscore = 0;
+    U32 blen = minMatch - 1, bp = 0, blit = 0; int bscore = 0;
+    if (minMatch2 > 0) {                              // :6373-6393: the higher order first
+      for (U32 k = 0; k <= bucket; ++k) {
+        U32 p = ht[h2 ^ k];
+        if (p && (p & mask) == (byte_at(i + 3) & mask)) {
+          p >>= checkbits;
+          if (p < i && i + blen <= n && in[p + blen - 1] == in[i + blen - 1]) {
+            U32 l = lookahead;                        // counted from the lookahead on ...
+            while (i + l < n && l < maxMatch && in[p + l] == in[i + l]) ++l;
+            if (l >= minMatch2 + lookahead) {
+              int l1 = (int)lookahead;                // ... then back: what is left in front are leading literals
+              while (l1 > 0 && in[p + l1 - 1] == in[i + l1 - 1]) --l1;
+              int score = (int)(l - l1) * 8 - lg(i - p) - 8 * (lit == 0 && l1 > 0) - 11;
+              if (score > bscore) blen = l, bp = p, blit = (U32)l1, bscore = score;
+            }
+          }
+        }
+        if (blen >= 128) break;
+      }
+    }
+    if (!minMatch2 || blen < minMatch2)
     for (U32 k = 0; k <= bucket; ++k) {               // :6396-6408
       U32 p = ht[h1 ^ k];
       if (p && i + 3 < n && (p & mask) == (in[i + 3] & mask)) {
@@ -268,22 +291,28 @@ extern "C" long orc_lz77_encode(const U8* in, long n_, const int args[9], U8* ou
           U32 l = 0;
           while (i + l < n && l < maxMatch && in[p + l] == in[i + l]) ++l;
           int score = (int)(l * 8) - lg(i - p) - 2 * (lit > 0) - 11;
-          if (score > bscore) blen = l, bp = p, bscore = score;
+          if (score > bscore) blen = l, bp = p, blit = 0, bscore = score;
         }
       }
       if (blen >= 128) break;
     }
     const U32 off = i - bp;                           // :6413-6421
-    if (off > 0 && bscore > 0 && blen >= minMatch + (level == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)))) {
-      write_literal(i, lit); lit = 0;
-      write_match(blen, off);
-      if (trace && nt < trace_cap) { trace[3 * nt] = i; trace[3 * nt + 1] = blen; trace[3 * nt + 2] = off; }
+    if (off > 0 && bscore > 0 && blen - blit >= minMatch + (level == 2) * ((off >= (1u << 16)) + (off >= (1u << 24)))) {
+      lit += blit;
+      write_literal(i + blit, lit); lit = 0;
+      write_match(blen - blit, off);
+      if (trace && nt < trace_cap) { trace[3 * nt] = i + blit; trace[3 * nt + 1] = blen - blit; trace[3 * nt + 2] = off; }
       ++nt;
     } else { blen = 1; ++lit; }
     while (blen--) {                                  // :6432-6447
       if (i + minMatchBoth < n) {
         U32 ih = ((i * 1234547u) >> 19) & bucket;
-        ht[h1 ^ ih] = (i << checkbits) | (in[i + 3] & mask);
+        const U32 pv = (i << checkbits) | (in[i + 3] & mask);
+        if (minMatch2) {
+          ht[h2 ^ ih] = pv;
+          h2 = (((h2 * 9) << shift2) + (in[i + minMatch2 + lookahead] + 1) * 23456789u) & (htsize - 1);
+        }
+        ht[h1 ^ ih] = pv;
         h1 = (((h1 * 5) << shift1) + (in[i + minMatch] + 1) * 123456791u) & (htsize - 1);
       }
       ++i;

@@ -83,6 +83,31 @@ def test_lz77_level2_hash_finder_stream_identical_to_lzbuffer(args):
         assert orc.lz77_encode(b, args) == orc.ref_lzbuffer(b, args), (args, len(b))
 
 
+# (block bits, level, minMatch, minMatch2, log2 bucket, log2 table, lookahead)
+SECOND_CONTEXT_ARGS = [(4, 1, 4, 8, 3, 24, 0), (4, 1, 4, 8, 3, 24, 1), (4, 1, 5, 12, 2, 22, 2), (0, 1, 4, 6, 0, 18, 0), (4, 2, 4, 8, 3, 22, 1),
+                       (4, 2, 6, 10, 1, 20, 3), (5, 1, 4, 9, 3, 25, 1), (4, 1, 4, 0, 3, 24, 2), (4, 1, 6, 3, 2, 20, 0)]
+
+
+@pytest.mark.parametrize("args", SECOND_CONTEXT_ARGS, ids=lambda a: ",".join(map(str, a)))
+def test_lz77_second_context_and_lookahead_identical_to_lzbuffer(args):
+    """The restatement of LZBuffer's second, higher-order context and lookahead (round 5; ZSFX/libzpaq.cpp:6263-6290, 6373-6393,
+    6411-6447) against the real LZBuffer: matches counted from the lookahead on and extended backwards, leading literals, both
+    hashes in one table, levels 1 and 2 -- incl. repeats whose first bytes were changed (matches that start behind a lookahead)."""
+    rng = np.random.default_rng(33)
+    base = rng.integers(0, 256, size=50000, dtype=np.uint8).tobytes()
+    rep = bytearray()
+    for i in range(900):
+        q = int(rng.integers(0, 49000))
+        piece = bytearray(base[q:q + int(rng.integers(6, 60))])
+        if i % 3 == 0 and len(piece) > 3:
+            piece[0] ^= 0x5a
+        if i % 5 == 0 and len(piece) > 4:
+            piece[1] ^= 0x33
+        rep += piece + bytes(rng.integers(0, 256, size=int(rng.integers(0, 4)), dtype=np.uint8))
+    for b in list(INPUTS.values()) + [base + bytes(rep), bytes(20000), b"abcabcabc" * 30]:
+        assert orc.lz77_encode(b, list(args)) == orc.ref_lzbuffer(b, list(args)), (args, len(b))
+
+
 def test_e8e9_forward_and_inverse():
     rng = np.random.default_rng(11)
     b = bytearray(rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes())
