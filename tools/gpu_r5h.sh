@@ -1,7 +1,7 @@
 # Round 5, final GPU call: the whole -m gpu suite, smoke(), and the default bench.py run on the final tree.
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
-T=${1:-r05h}
+T=${1:-r05k}
 S0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 -p no:cacheprovider -x > gpurun_out/${T}_tests_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${T}_tests_gpu.log; tail -4 gpurun_out/${T}_tests_gpu.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
