@@ -48,3 +48,14 @@ def test_nested_lines_are_compact_and_summarised():
     assert bench.summary_row({"error": "boom", "rc": 1}) == [None, None, False, None, None]
     bad = dict(full, verified_dedup=False)
     assert bench.summary_row(bad)[2] is False
+    # round 5: what a reader of the one line needs of a nested workload survives the cut -- the lone-job figure, the three rooflines
+    # with their PMC traffic, the product call of config 4
+    r = {"bound": "hbm", "kernel": "k", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": 123, "traffic_over_algorithmic": 1.2,
+         "avg_launch_ms": 1.0, "launches_per_step": 1.0, "ms_per_step": 1.0, "measured": "one job alone", "note": "z" * 200, "integer_issue_ceiling_GBps": 1.0}
+    more = dict(full, roofline=r, roofline_in_flight=r, roofline_longest_chain=dict(r, waves=13), single_job={"ms": 391.0, "value": 172.0, "note": "n" * 300},
+                product_one_call={"ms": 4710.6, "archive_bytes": 5728947211, "note": "n" * 200}, archive_blocks={"c": 1, "d": 13, "h": 13, "i": 175})
+    c = bench.compact_line(more)
+    assert c["single_job"] == {"ms": 391.0, "value": 172.0} and c["product_one_call"]["ms"] == 4710.6 and c["archive_blocks"]["i"] == 175
+    for k in ("roofline", "roofline_in_flight", "roofline_longest_chain"):
+        assert c[k]["traffic"] == 123 and c[k]["measured"] == "one job alone" and "note" not in c[k]
+    assert c["roofline_longest_chain"]["waves"] == 13 and len(json.dumps(c)) < 2600
