@@ -205,7 +205,7 @@ int main(int argc, char** argv) {
     // an unsupported method must surface through libzpaq::error, not be approximated
     try {
       libzpaq::StringBuffer sb, o; sb.write("hello", 5);
-      libzpaq::compressBlock(&sb, &o, "x4,1,4,8,3,24", 0, 0, true);   // LZ77 with a secondary context (the second hash table of LZBuffer): not implemented
+      libzpaq::compressBlock(&sb, &o, "x4,1,4,80,3,24", 0, 0, true);   // LZ77 with a secondary context of 80 bytes: beyond what the engine serves (64)
       printf("unsupported: NOT refused\n");
     } catch (std::exception& e) { printf("unsupported: refused (%s)\n", e.what()); }
   } catch (std::exception& e) {
