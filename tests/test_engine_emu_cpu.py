@@ -59,7 +59,6 @@ SLOW = [
     "test_gpu_parity.py::test_lz77_full_16mib_block",
     "test_gpu_parity.py::test_compress_block_level5_prefix_of_second_fixture",
     "test_gpu_parity.py::test_sha_more_extents_than_lanes_longest_first",
-    "test_gpu_parity.py::test_libzpaq_shim_multithreaded_cpp_caller",
     "test_gpu_parity.py::test_cm_encode_decode_equal_reference[alltypes]",
     "test_gpu_parity.py::test_cm_encode_decode_equal_reference[mid]",
     "test_gpu_parity.py::test_lz77_streams_bit_identical[4,1,4,0,2,24]",
