@@ -230,39 +230,3 @@ def test_builtin_models_of_startblock_level_equal_reference(eng, level):
     assert st == 0 and got == orc.ref_cm_encode(h, x)
     (st, back), = eng.cm_code([h], [got], [len(x) + 16], encode=False)
     assert st == 0 and back == x
-
-
-LOOPY_CFG = """comp 1 0 0 0 1
-  0 icm 8
-hcomp
-  c=a a=0
-  do
-    a++ a== 250
-  until
-  a=c a<<= 9 *d=a
-  halt
-post
-  0
-end
-"""
-
-
-def test_a_block_the_generated_hcomp_gives_up_on_is_coded_by_the_interpreter_kernel(eng, monkeypatch):
-    """The generated HCOMP code stops a call after ZGUARD backward jumps (2^24; ZPQ_JIT_HCOMP_GUARD=100 here) and reports the block
-    as malformed; run_cm then codes it with the interpreter-driven kernel (limit 2^30) -- a VALID program that loops 250 times per
-    byte must come out exactly as the reference Predictor + ZPAQL interpreter code it, in both directions."""
-    h = orc.ref_compile(LOOPY_CFG, [0] * 9)[0]
-    data = [b"\0" + datagen.text_like(1500, 71), b"\0" + datagen.binary_like(900, 72)]
-    want = [orc.ref_cm_encode(h, d) for d in data]
-    caps = [len(d) * 2 + 64 for d in data]
-    got = eng.cm_code([h] * 2, data, caps, encode=True)                     # 250 < 2^24: the specialised kernel itself
-    assert got == [(0, w) for w in want]
-    monkeypatch.setenv("ZPQ_JIT_HCOMP_GUARD", "100")
-    monkeypatch.setenv("ZPQ_JIT_NOCACHE", "1")
-    # (another header, so that this process compiles a kernel with the small limit: the size of H differs)
-    h2 = orc.ref_compile(LOOPY_CFG.replace("comp 1 0 0 0 1", "comp 2 0 0 0 1"), [0] * 9)[0]
-    want2 = [orc.ref_cm_encode(h2, d) for d in data]
-    got2 = eng.cm_code([h2] * 2, data, caps, encode=True)
-    assert got2 == [(0, w) for w in want2]                                   # given up at 100 jumps, coded by the second pass
-    back = eng.cm_code([h2] * 2, want2, [len(d) + 16 for d in data], encode=False)
-    assert back == [(0, d) for d in data]

@@ -995,10 +995,8 @@ size_t meta_bytes(const ParsedHeader& P) {
 }
 
 // One batch: blocks idx[0..nb) of jobs[], all resident at once.
-// force_generic: the interpreter-driven kernels whatever the header (the second pass of run_cm); was_spec (may be null): [job index] = 1
-// for the jobs a specialised kernel coded
 int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>& ph, const size_t* idx, size_t nb, int encode,
-                 const Tables* dT, bool force_generic = false, std::vector<char>* was_spec = nullptr) {
+                 const Tables* dT) {
   hipStream_t st = ctx->stream;
   const bool trace = getenv("ZPQ_CM_TRACE") != nullptr;
   auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
@@ -1148,7 +1146,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
   std::vector<int> group(nb, -1);
   std::vector<zpq_cm_spec*> gk;
   std::vector<std::vector<size_t>> members;
-  const bool want_spec = !force_generic && getenv("ZPQ_CM_GENERIC") == nullptr;
+  const bool want_spec = getenv("ZPQ_CM_GENERIC") == nullptr;
   {
     std::map<std::string, int> by_header;
     for (size_t k = 0; k < nb; ++k) {
@@ -1167,7 +1165,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
         it = by_header.insert({key, g}).first;
       }
       group[k] = it->second;
-      if (group[k] >= 0) { members[group[k]].push_back(k); if (was_spec) (*was_spec)[i] = 1; }
+      if (group[k] >= 0) members[group[k]].push_back(k);
     }
   }
   // the specialised kernels take their blocks from a queue: order each group's records contiguously
@@ -1280,27 +1278,13 @@ int run_cm(zpq_ctx* ctx, zpq_cm_job* jobs, size_t njobs, int encode) {
   if (const char* e = getenv("ZPQ_CM_BUDGET_MB")) budget = (size_t)atoll(e) << 20;
   std::vector<size_t> order(njobs);
   for (size_t i = 0; i < njobs; ++i) order[i] = i;
-  std::vector<char> was_spec(njobs, 0);
   size_t at = 0;
   while (at < njobs) {
     size_t sum = 0, nb = 0;
     while (at + nb < njobs && nb < 16384 && (nb == 0 || sum + need[order[at + nb]] <= budget)) sum += need[order[at + nb++]];
-    int rc = run_cm_batch(ctx, jobs, ph, order.data() + at, nb, encode, dT, false, &was_spec);
+    int rc = run_cm_batch(ctx, jobs, ph, order.data() + at, nb, encode, dT);
     if (rc) return rc;
     at += nb;
-  }
-  // A block a SPECIALISED kernel gave up on as malformed gets a second pass through the interpreter-driven kernel: the generated
-  // code stops an HCOMP call after 2^24 backward jumps, the interpreter after 2^30, and a valid program may lie in between
-  // (one that initialises H or M in a loop on its first byte).  The reference has no limit at all
-  // (ZPAQL::run0, ZSFX/libzpaq.cpp:1033-1254); a block that fails both ways is malformed for this engine.
-  std::vector<size_t> redo;
-  for (size_t i = 0; i < njobs; ++i) if (was_spec[i] && jobs[i].status == ZPQ_ERR_FORMAT) redo.push_back(i);
-  for (size_t a2 = 0; a2 < redo.size();) {
-    size_t sum = 0, nb = 0;
-    while (a2 + nb < redo.size() && nb < 16384 && (nb == 0 || sum + need[redo[a2 + nb]] <= budget)) sum += need[redo[a2 + nb++]];
-    int rc = run_cm_batch(ctx, jobs, ph, redo.data() + a2, nb, encode, dT, true, nullptr);
-    if (rc) return rc;
-    a2 += nb;
   }
   int first = ZPQ_OK;
   for (size_t i = 0; i < njobs; ++i) if (jobs[i].status && !first) first = jobs[i].status;

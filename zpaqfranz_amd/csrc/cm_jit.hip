@@ -302,13 +302,7 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   std::string s;
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
   s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
-  {
-    // backward jumps HCOMP may take per byte before the generated code gives the block up (run_cm then codes it with the
-    // interpreter-driven kernel, whose limit is 2^30).  ZPQ_JIT_HCOMP_GUARD: tests force that second pass with a small limit.
-    unsigned guard = 1u << 24;
-    if (const char* e = getenv("ZPQ_JIT_HCOMP_GUARD")) { const long v = atol(e); if (v >= 1 && v <= (1l << 30)) guard = (unsigned)v; }
-    s += "#define ZGUARD " + itos(guard) + "u\n";
-  }
+  s += "#define ZGUARD (1u << 24)\n";        // backward jumps HCOMP may take per byte (a program that initialises H or M in a loop on its first byte must pass)
 
   if (getenv("ZPQ_CM_PROGRESS")) s += "#define ZPROGRESS 1\n";
   static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
