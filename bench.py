@@ -136,6 +136,37 @@ class _NoOrder:          # single-threaded use (sizing steps, one rank)
 # ---------------------------------------------------------------------------------------------------------------------
 # corpora (synthetic stand-ins, resident in HBM)
 # ---------------------------------------------------------------------------------------------------------------------
+def steady_window(run_steps, barrier, depth, warm, steps, before=lambda: None):
+    """The timed region.  With ONE step in flight: barrier, K steps, barrier (the contract, literally).  With `depth` steps in flight
+    (software pipeline over `depth` contexts) a barrier on both sides of K steps also times filling and draining the pipeline, which
+    makes the figure a function of K (162 ms at --steps 20, 100 ms at 48, same tree, same chip).  So the
+    pipeline is kept primed: ONE continuous run of  depth (prime) + W (warm-up) + K (timed) + depth (tail, keeps the chip as full at
+    the end of the window as at its start)  jobs between two barriers; the clock starts when the (depth + W)-th job has COMPLETED
+    (a job's completion is a host-side fact: the product call has returned with the archive in host memory) and stops when K further
+    jobs have completed.  Exactly K jobs complete inside the window; nothing is skipped, every job is the full step.
+    Returns (seconds for the K steps, jobs run between the barriers, result of the last job, completion-time list)."""
+    if depth <= 1:
+        run_steps(warm)
+        before()
+        barrier(); t0 = time.perf_counter()
+        out, _ = run_steps(steps)
+        barrier()
+        return time.perf_counter() - t0, steps, out, None
+    n = depth + warm + steps + depth
+    before()
+    barrier(); t0 = time.perf_counter()
+    out, done = run_steps(n)
+    barrier()
+    ct = sorted(done)
+    k0 = depth + warm
+    return ct[k0 + steps - 1] - ct[k0 - 1], n, out, [round(t - t0, 4) for t in ct]
+
+
+STEADY_NOTE = ("steady state: one continuous run of depth + warmup + steps + depth jobs between two barriers; the clock runs from the completion of "
+               "job depth+warmup to the completion of job depth+warmup+steps (exactly `steps` whole jobs complete inside it, the pipeline full at both "
+               "ends); ms_per_step_cold = barrier, `steps` jobs from an idle chip, barrier (includes filling and draining the pipeline)")
+
+
 def silesia_layout(dev, corpus, copies):
     """x`copies` replication of the 12-member corpus: files in copy order, one flat device buffer."""
     base = b"".join(b for _, b in corpus)
@@ -811,11 +842,12 @@ def main_text_m2(a, rank, world, local, dev):
 
     def run_steps(n):
         import threading
+        done = [0.0] * n
         if depth == 1:
             r = 0
-            for _ in range(n):
-                r = step(0)
-            return r
+            for i in range(n):
+                r = step(0); done[i] = time.perf_counter()
+            return r, done
         nxt, lock, res, errs = [0], threading.Lock(), [0], []
 
         def worker(c, delay):
@@ -827,7 +859,7 @@ def main_text_m2(a, rank, world, local, dev):
                         i = nxt[0]; nxt[0] += 1
                     if i >= n:
                         return
-                    res[0] = step(c)
+                    res[0] = step(c); done[i] = time.perf_counter()
             except Exception as ex:
                 errs.append(ex)
         th = [threading.Thread(target=worker, args=(c, c * stagger / depth)) for c in range(depth)]
@@ -835,7 +867,7 @@ def main_text_m2(a, rank, world, local, dev):
         for t in th: t.join()
         if errs:
             raise errs[0]
-        return res[0]
+        return res[0], done
 
     def barrier():
         if dist.is_initialized():
@@ -861,19 +893,20 @@ def main_text_m2(a, rank, world, local, dev):
         engines.append(Engine(local))
         add_ctx(engines[-1])
         step(c)
-    run_steps(warm)
-    for e_ in engines:
-        e_.profile(not a.no_kernel_timing)
-    barrier()
-    t0 = time.perf_counter()
-    out_bytes = run_steps(steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    def prof_on():
+        for e_ in engines:
+            e_.profile(not a.no_kernel_timing)
+    dt, prof_steps, out_bytes, completions = steady_window(run_steps, barrier, depth, warm, steps, prof_on)
     kern = {}
     for e_ in engines:
         for k_, (c_, m_) in e_.profile_report().items():
             kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
         e_.profile(False)
+    cold = None
+    if completions is not None:
+        barrier(); t0 = time.perf_counter()
+        out_bytes, _ = run_steps(steps)
+        barrier(); cold = (time.perf_counter() - t0) / steps
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
         tsum = torch.tensor([float(out_bytes)], dtype=torch.float64, device="cpu" if _CPU_COLLECTIVES else dev)
@@ -886,7 +919,14 @@ def main_text_m2(a, rank, world, local, dev):
         # (the two candidate passes each read text + suffix array + LCP and write or update a 16-byte decision record per position)
         alg = {"sa_radix_sort_pairs": 5 * total, "lz77_sa_cand0_kernel": total * (1 + 4 + 2) + 16 * total, "lz77_sa_cand1_kernel": total * (1 + 4 + 2) + 32 * total,
                "sa_lcp_kernel": total * (1 + 4 + 4) + 2 * total, "sha1_chain_kernel": total}
-        sa_ms = sum(m for k_, (c_, m) in kern.items() if k_.startswith("sa_")) / steps
+        sa_ms = sum(m for k_, (c_, m) in kern.items() if k_.startswith("sa_")) / prof_steps
+        # the algorithmic bytes of this path are 1 byte read + r bytes written per input byte, whatever a pass of the
+        # implementation moves; `alg` above (suffix array, LCP, decision records) is the implementation's own traffic model and is
+        # reported as `traffic_model`, never as `achieved`
+        model = alg
+        per_rank_out = out_bytes // max(1, world)
+        alg = {k: total + per_rank_out for k in model}
+        alg["sha1_chain_kernel"] = total
 
         traffic = {}
         tf = os.path.join(ROOT, "profiles", "traffic_text_m2.json")      # PMC bytes per launch (tools/gpu_traffic.sh, profiles/summarize.py)
@@ -899,12 +939,15 @@ def main_text_m2(a, rank, world, local, dev):
 
         def roof(k, src=None, nsteps=None, how=None):
             src = kern if src is None else src
-            nsteps = steps if nsteps is None else nsteps
+            nsteps = prof_steps if nsteps is None else nsteps
             cnt, ms = src[k]
             ach = alg[k] / 1e9 / (ms / nsteps / 1e3)
             r = {"bound": "hbm", "kernel": k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                  "traffic": traffic.get(k), "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": round(cnt / nsteps, 2),
-                 "algorithmic_bytes_per_step": int(alg[k]), "ms_per_step": round(ms / nsteps, 3)}
+                 "algorithmic_bytes_per_step": int(alg[k]), "ms_per_step": round(ms / nsteps, 3),
+                 "algorithmic": "SURVEY 8(d): 1 B read + r B written per input byte",
+                 "traffic_model": {"bytes_per_step": int(model[k]), "GBps": round(model[k] / 1e9 / (ms / nsteps / 1e3), 2),
+                                   "note": "what this pass of the implementation must move (text, suffix array, LCP, decision records)"}}
             if traffic.get(k):
                 r["traffic_over_algorithmic"] = round(traffic[k] * (cnt / nsteps) / alg[k], 3)
             if how:
@@ -923,7 +966,8 @@ def main_text_m2(a, rank, world, local, dev):
                "input_GBps": round(total * world / 1e9 / sec, 3), "steps_in_flight": depth, "ms_per_step_serial": round(stagger * 1e3, 3),
                "single_job": single,
                "suffix_array_ms_per_step": round(sa_ms, 2),
-               "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               "kernels_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               **({"ms_per_step_cold": round(cold * 1e3, 3), "timing": STEADY_NOTE, "jobs_between_barriers": prof_steps} if cold else {}),
                "kernels_ms_per_job_alone": {k: round(v[1] / n_alone, 3) for k, v in sorted(kern_alone.items(), key=lambda kv: -kv[1][1])},
                "roofline": roof(dom, kern_alone, n_alone, how) if dom else None,
                "roofline_in_flight": roof(dom) if dom and dom in kern else None,
@@ -1096,7 +1140,7 @@ def compact_line(d, top=6):
     """A nested workload's JSON line cut down to what a reader of the ONE line needs (the driver's record keeps only the
     tail of a long line): the contract keys, the verification flags, the dominant kernel's roofline and the CPU baseline.
     The full line goes to stderr."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_serial", "steps_in_flight", "scaling", "dtype",
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_cold", "ms_per_step_serial", "steps_in_flight", "scaling", "dtype",
             "data", "input_GBps", "output_GBps", "input_MBps", "sha256_mismatches", "error", "rc", "skipped", "wall_s")
     out = {k: d[k] for k in keep if k in d}
     out.update({k: v for k, v in d.items() if k.startswith("verified") or k.endswith("_failures") or k == "method_expansion_checked"})
@@ -1227,6 +1271,7 @@ def main():
                     help="add workloads, one rank: time the call-by-call orchestration in Python (fragment -> dedup -> plan -> gather -> "
                          "compressBlock, d blocks only) instead of the product's one-call zpqj_add_dev (the default: whole archive incl. c/h/i)")
     ap.add_argument("--product", action="store_true", help="dup8_m1: time zpqj_add_dev (archive to host memory) instead of the call-by-call path")
+    ap.add_argument("--strict", action="store_true", help="exit with status 4 when a nested workload failed or was skipped (the line is printed first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block-sha1", action="store_true", help="experiment only: skip the per-block SHA-1 (invalid as a result)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with hipEvents (roofline block is then empty)")
@@ -1301,6 +1346,8 @@ def main():
         print(json.dumps(res))
         if failed:           # reported in the line (failed_workloads, workloads_summary); the headline itself is complete
             sys.stderr.write("bench.py: nested workload(s) failed or were skipped: " + ", ".join(failed) + "\n")
+            if a.strict or os.environ.get("ZPQ_BENCH_STRICT"):
+                raise SystemExit(4)          # (CI: a failed nested workload fails the run; the driver's run keeps rc 0 and reads failed_workloads)
         return
     if a.same_device:
         local = 0
@@ -1407,7 +1454,7 @@ def main():
         latency-bound tail (LZ77 parse, block checksums: a few hundred waves) the next one already
         fragments and hashes on the rest of the chip.  Every step is complete when this returns."""
         import threading
-        nxt, lock, outs, errs = [0], threading.Lock(), [0] * n, []
+        nxt, lock, outs, errs, done = [0], threading.Lock(), [0] * n, [], [0.0] * n
 
         order = CollectiveOrder(n, depth) if (world > 1 or a.force_collectives) else _NoOrder()
 
@@ -1421,6 +1468,7 @@ def main():
                     if i >= n:
                         return
                     outs[i] = p_.step(order, i, i == n - 1) if isinstance(p_, Pipeline) else p_.step(order, i)
+                    done[i] = time.perf_counter()
                     if i == n - 1:
                         last_pipe[0] = p_
             except Exception as ex:       # surface worker failures in the main thread
@@ -1440,7 +1488,7 @@ def main():
             for t in th: t.join()
         if errs:
             raise errs[0]
-        return outs[-1] if n else 0
+        return (outs[-1] if n else 0), done
 
     stagger = [0.0]
     last_pipe = [runners[0]]     # the context that ran the last step (its results are the ones dumped / verified)
@@ -1466,20 +1514,22 @@ def main():
         more_contexts()
         for p_ in runners[1:]:         # one untimed serial step per further context sizes its scratch
             p_.step()
-    run_steps(warm)
-    for e_ in engines:
-        e_.profile(not a.no_kernel_timing)
-    barrier()
-    t0 = time.perf_counter()
-    out_bytes = run_steps(steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    pipe = last_pipe[0]
+    def prof_on():
+        for e_ in engines:
+            e_.profile(not a.no_kernel_timing)
+    dt, prof_steps, out_bytes, completions = steady_window(run_steps, barrier, depth if len(runners) > 1 else 1, warm, steps, prof_on)
     kern = {}
     for e_ in engines:
         for k_, (c_, m_) in e_.profile_report().items():
             kern[k_] = (kern.get(k_, (0, 0.0))[0] + c_, kern.get(k_, (0, 0.0))[1] + m_)
         e_.profile(False)
+    cold = None
+    if completions is not None:
+        # the same K steps from an idle chip to an idle chip (what rounds 1-5 reported as ms_per_step): fill and drain included
+        barrier(); t0 = time.perf_counter()
+        out_bytes, _ = run_steps(steps)
+        barrier(); cold = (time.perf_counter() - t0) / steps
+    pipe = last_pipe[0]
     product_stats, product_archive, product_once = None, None, None
     if (not product and a.workload == "dup8_m1" and world == 1 and not a.force_collectives and not a.python_pipeline and not a.no_verify
             and isinstance(pipe, Pipeline)):
@@ -1562,7 +1612,7 @@ def main():
 
         def roof(k, src=None, nsteps=None, how=None):
             src = kern if src is None else src
-            nsteps = steps if nsteps is None else nsteps
+            nsteps = prof_steps if nsteps is None else nsteps
             cnt, ms = src[k]
             per = ms / cnt
             ab = alg.get(k)          # algorithmic bytes of the kernel per STEP (a step may launch it more than once)
@@ -1591,7 +1641,7 @@ def main():
         # it); `roofline_longest_chain` = the few-wave kernel with the most time alone (block checksum chains: what bounds ONE
         # job's latency, not the chip's throughput).  With one step in flight (dup8) the timed region IS the job alone.
         simds = 1024
-        base, nbase = (kern_alone, n_alone) if kern_alone else (kern, steps)
+        base, nbase = (kern_alone, n_alone) if kern_alone else (kern, prof_steps)
         how = ("one job alone, %d runs (single_job)" % n_alone) if kern_alone else "the timed region (one step in flight)"
         fill = [k for k in base if alg.get(k) and waves.get(k, simds) >= simds]
         chains = [k for k in base if alg.get(k) and waves.get(k, simds) < simds]
@@ -1614,7 +1664,10 @@ def main():
                            "whole-archive identity is not provable here (block cut rule, R,t hint and file order of the missing zpaqfranz.cpp are unpinned)",
                ("output_GBps" if extract else "input_GBps"): round(in_bytes / 1e9 / sec, 3), "steps_in_flight": depth,
                "ms_per_step_serial": round(stagger[0] * 1e3, 3) if depth > 1 else round(sec * 1e3, 3),      # = single_job.ms
-               "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+               **({"ms_per_step_cold": round(cold * 1e3, 3), "value_cold": round(out_bytes / 1e6 / cold, 3), "timing": STEADY_NOTE,
+                   "jobs_between_barriers": prof_steps,
+                   "completions_s": completions if len(completions) <= 64 else completions[:: max(1, len(completions) // 64)]} if cold else {}),
+               "kernels_ms_per_step": {k: round(v[1] / prof_steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                **({"product_one_call": product_once} if product_once else {}),
                "roofline": roof_dom, "roofline_in_flight": roof_fill, "roofline_longest_chain": roof_chain, "single_job": single,
                **({"kernels_ms_per_job_alone": {k: round(v[1] / n_alone, 3) for k, v in sorted(kern_alone.items(), key=lambda kv: -kv[1][1])}} if kern_alone else {}),
@@ -1633,11 +1686,9 @@ def main():
                 want12 = [orc.blake3(b) for _, b in corpus]
                 for r_ in runners:
                     r_.verify_hash = "blake3"; r_.blake3_want = want12 * a.copies
-                run_steps(len(runners))                      # warm
-                barrier(); tb = time.perf_counter()
                 nb3 = 2 * len(runners)
-                run_steps(nb3)
-                barrier(); secb = (time.perf_counter() - tb) / nb3
+                dtb, _, _, _ = steady_window(run_steps, barrier, depth if len(runners) > 1 else 1, 0, nb3)
+                secb = dtb / nb3
                 res["blake3_verify"] = {"ms_per_step": round(secb * 1e3, 3), "value": round(pipe.arc_bytes / 1e6 / secb, 3), "unit": "MB/s",
                                         "output_GBps": round(pipe.total / 1e9 / secb, 3),
                                         "mismatches": int(sum(getattr(r_, "blake3_mismatches", 0) for r_ in runners)),
@@ -1674,11 +1725,9 @@ def main():
             for p_ in pipes:
                 p_.use_twins = not main_fold
             try:
-                run_steps(len(pipes))
-                barrier(); tb = time.perf_counter()
-                n2 = max(3 * len(pipes), min(steps, 36))      # (three rounds of every context: a steady state, not one job's latency or the staggered start)
-                ob2 = run_steps(n2)
-                barrier(); sec2 = (time.perf_counter() - tb) / n2
+                n2 = max(len(pipes), min(steps, 36))
+                dt2, _, ob2, _ = steady_window(run_steps, barrier, depth if len(pipes) > 1 else 1, 0, n2)
+                sec2 = dt2 / n2
                 var = {"ms_per_step": round(sec2 * 1e3, 3), "value": round(ob2 / 1e6 / sec2, 3), "unit": "MB/s", "steps": n2,
                        "input_GBps": round(in_bytes / 1e9 / sec2, 3)}
                 if main_fold:

@@ -59,3 +59,27 @@ def test_nested_lines_are_compact_and_summarised():
     for k in ("roofline", "roofline_in_flight", "roofline_longest_chain"):
         assert c[k]["traffic"] == 123 and c[k]["measured"] == "one job alone" and "note" not in c[k]
     assert c["roofline_longest_chain"]["waves"] == 13 and len(json.dumps(c)) < 2600
+
+
+def test_steady_window_counts_exactly_k_completions_with_the_pipeline_full():
+    """bench.steady_window: depth + warm + steps + depth jobs between the barriers, the clock from the completion of job
+    depth+warm to the completion of job depth+warm+steps -- independent of how long the pipeline takes to fill or drain."""
+    import bench
+    calls = []
+
+    def fake_run(n):                       # a pipeline that fills slowly (first `depth` completions late), then one job per 10 ms
+        calls.append(n)
+        t, done = 100.0, []
+        for i in range(n):
+            t += 0.5 if i < 4 else 0.010
+            done.append(t)
+        done[-1] += 3.0                    # ... and drains slowly
+        return 7, done[::-1]               # (completion order is not job order)
+    bars = []
+    dt, n, out, ct = bench.steady_window(fake_run, lambda: bars.append(1), 4, 5, 20)
+    assert calls == [4 + 5 + 20 + 4] and n == 33 and out == 7 and len(bars) == 2
+    assert abs(dt - 20 * 0.010) < 1e-9
+    # one step in flight: the contract's literal bracket
+    calls.clear(); bars.clear()
+    dt, n, out, ct = bench.steady_window(lambda k: (calls.append(k), (3, [0.0] * k))[1], lambda: bars.append(1), 1, 2, 6)
+    assert calls == [2, 6] and n == 6 and out == 3 and ct is None and len(bars) == 2
