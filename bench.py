@@ -729,9 +729,33 @@ class ExtractPipeline:
         torch.cuda.synchronize()
         return c
 
+    def use_product(self, archive):
+        """The timed step becomes ONE C-ABI call, zpqj_extract_dev: the whole journaling archive (c, d, h, i blocks as zpqj_add_dev
+        returned them) resident in HBM in; restored files + their SHA-256 left in HBM.  The index is read by the call itself."""
+        self.full = torch.zeros(len(archive) + 64, dtype=torch.uint8, device=self.dev)
+        self.full[: len(archive)] = torch.frombuffer(bytearray(archive), dtype=torch.uint8).to(self.dev)
+        self.full_len = len(archive)
+        names, off, st = self.E.jidac_extract_dev(self.eng, self.full.data_ptr(), self.full_len)       # plan call: sizes only
+        if off != list(self.file_off):
+            raise RuntimeError("extract: the archive's index does not describe the files that were added")
+        self.product = True
+
+    def step_product(self):
+        E = self.E
+        _, _, st = E.jidac_extract_dev(self.eng, self.full.data_ptr(), self.full_len, self.out.data_ptr(), self.total + 64,
+                                       self.d_sha_got.data_ptr(), self.nfiles, twins=getattr(self, "use_twins", False))
+        if st["files"] != self.nfiles or st["bytes"] != self.total or st["d_blocks"] != self.nb:
+            raise RuntimeError("extract: %r" % st)
+        self.twin_stats = dict(twins=st["twins"], twin_bytes=st["twin_bytes"], compared=0, compared_bytes=st["compared_bytes"])
+        mism, _ = self.eng.digest_compare_dev(self.d_sha_got.data_ptr(), self.d_sha_want.data_ptr(), self.nfiles, 32)
+        self.sha256_mismatches = int(mism)
+        return self.full_len
+
     def step(self, order=None, idx=0):
         eng = self.eng
         self.out.zero_() if getattr(self, "scrub", False) else None
+        if getattr(self, "product", False) and getattr(self, "verify_hash", "sha256") == "sha256":
+            return self.step_product()
         rc = eng.decompress_blocks_dev(self.jobs, self.nb, True)
         bad = [k for k in range(self.nb) if self.jobs[k].status != 0 or self.jobs[k].out_len != self.usize[k]]
         if rc != 0 or bad:
@@ -1423,7 +1447,13 @@ def main():
         pipes[0].step()                                     # the archive to extract (untimed)
         sha = [hashlib.sha256(b).digest() for _, b in corpus]
         ex_pipe = ExtractPipeline(eng, dev, pipes[0], layout, sha * a.copies)
-        ex_pipe.use_twins = not a.no_twins          # (extract keeps its fold of equal restored files unless --no-twins)
+        # since round 6 the timed region hashes EVERY restored byte (fold off, as the add headline since round 5); the fold's figure
+        # is reported beside it (`twin_fold_on`); --twins times the fold
+        ex_pipe.use_twins = a.twins
+        if not a.python_pipeline:
+            pipes[0].step_product(True)                     # the same job through zpqj_add_dev: the whole archive (c, d, h, i blocks)
+            ex_pipe.use_product(bytes(pipes[0].archive))
+            pipes[0].drop_archive()
         layout["data"] = None; del pipes[0].verify_blocks  # the originals are not needed any more
         for p_ in pipes:
             p_.data = None
@@ -1573,11 +1603,16 @@ def main():
             tw = tw or dict(twins=0, twin_bytes=0, compared=0, compared_bytes=0)
             hashed = pipe.total - tw["twin_bytes"]      # bytes SHA-256 actually sees (the representatives)
             chain_bytes = min(chain_bytes, hashed)
-            alg = {"sha256_chain_kernel": chain_bytes, "sha256_extents_kernel": hashed - chain_bytes, "gather_kernel": pipe.total + ub,
+            long_bytes = sum(n_ for n_ in (pipe.file_off[i + 1] - pipe.file_off[i] for i in range(pipe.nfiles)) if n_ >= (1 << 20))
+            grouped = "sha256_group_kernel" in kern or "sha256_group_kernel" in kern_alone       # (several chains per wave: every file of 1 MiB and more)
+            if grouped:
+                chain_bytes = min(long_bytes, hashed)
+            alg = {"sha256_chain_kernel": chain_bytes, "sha256_group_kernel": chain_bytes, "sha256_extents_kernel": hashed - chain_bytes, "gather_kernel": pipe.total + ub,
                    "twin_compare_kernel": tw["compared_bytes"] + (hashed if tw["compared_bytes"] else 0),
                    "lz77_decode_kernel": ub + pipe.arc_bytes, "sha1_extents_kernel": ub, "sha1_chain_kernel": ub}
             nhashed = pipe.nfiles - tw["twins"]       # files SHA-256 actually sees: one wave (chain) or one lane each
             waves = {"lz77_decode_kernel": pipe.nb, "sha1_chain_kernel": pipe.nb, "sha256_chain_kernel": nhashed, "sha256_extents_kernel": -(-nhashed // 64),
+                     "sha256_group_kernel": -(-nhashed // 4),
                      "lz77_copy_kernel": pipe.nb, "sha1_extents_kernel": -(-pipe.nu // 64)}
             alg_step = pipe.arc_bytes + 2 * pipe.total  # r bytes read + 1 byte written per restored byte + 1 byte read back for SHA-256
             metric = "MB/s compressed archive input extracted + verified (SHA-1 per fragment, SHA-256 per file), Silesia x%d -m1" % a.copies
@@ -1658,7 +1693,9 @@ def main():
                           **({"corpus": "one Silesia x%d split by file range over %d ranks" % (a.copies, world)} if shared else {}),
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
-               "timed_step": ("one C-ABI call: zpqj_add_dev (files resident in HBM in, whole journaling archive -- c, d, h, i blocks -- out to host memory)"
+               "timed_step": ("one C-ABI call: zpqj_extract_dev (whole journaling archive resident in HBM in -- the call reads the index itself --, restored "
+                              "files and their SHA-256 left in HBM) + the digest compare" if (extract and getattr(pipe, "product", False)) else
+                              "one C-ABI call: zpqj_add_dev (files resident in HBM in, whole journaling archive -- c, d, h, i blocks -- out to host memory)"
                               if product else "call-by-call orchestration in bench.py (d blocks only)"),
                "identity": "per d block and per table: every block, fragment boundary, SHA-1 and the dedup map equal the reference-derived oracle; "
                            "whole-archive identity is not provable here (block cut rule, R,t hint and file order of the missing zpaqfranz.cpp are unpinned)",
@@ -1677,6 +1714,27 @@ def main():
                                        "note": "whole step: SURVEY 8(d) algorithmic bytes (input once + unique + output; extract: r + 1 + 1) / ms_per_step; the passes are integer-issue bound, not HBM bound: see integer_issue_ceiling_GBps per kernel"}}
         if extract:
             res["sha256_mismatches"] = pipe.sha256_mismatches
+            res["archive_bytes"] = {"whole_archive": int(out_bytes), "d_blocks": int(pipe.arc_bytes)}
+            res["value_d_blocks_only"] = round(pipe.arc_bytes / 1e6 / sec, 3)      # (what rounds 2-5 quoted: the d blocks' bytes per second)
+            if world == 1 and not a.no_verify and not os.environ.get("ZPQ_BENCH_NO_VARIANT"):
+                # the same job with the fold the other way round (default: fold ON beside the fold-off headline)
+                main_fold = bool(getattr(pipe, "use_twins", False))
+                for r_ in runners:
+                    r_.use_twins = not main_fold
+                try:
+                    n2 = max(len(runners), min(steps, 8))
+                    dt2, _, ob2, _ = steady_window(run_steps, barrier, depth if len(runners) > 1 else 1, 0, n2)
+                    sec2 = dt2 / n2
+                    tws = runners[0].twin_stats or {}
+                    res["every_byte_hashed" if main_fold else "twin_fold_on"] = dict(
+                        ms_per_step=round(sec2 * 1e3, 3), value=round(ob2 / 1e6 / sec2, 3), unit="MB/s", steps=n2, output_GBps=round(pipe.total / 1e9 / sec2, 3),
+                        sha256_mismatches=int(sum(r_.sha256_mismatches for r_ in runners)), **{k: tws[k] for k in ("twins", "twin_bytes") if k in tws})
+                finally:
+                    for r_ in runners:
+                        r_.use_twins = main_fold
+                    pipe.step()          # (what the verification below reads -- digests, restored bytes -- is the headline mode's again)
+                    if not main_fold:
+                        pipe.twin_stats = None
             res["twin_fold"] = dict(enabled=bool(getattr(pipe, "use_twins", True)), **tw,
                                     note="restored files whose bytes equal an earlier restored file's (every byte compared on the device) take that "
                                          "file's SHA-256; the representatives are hashed (zpq_sha256_files_dev)")

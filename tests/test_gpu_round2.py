@@ -343,6 +343,23 @@ def test_sha256_long_and_short_extents_together(eng, monkeypatch):
     monkeypatch.delenv("ZPQ_SHA256_CHAIN_MIN")
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32])
+def test_sha256_several_chains_per_wave(eng, monkeypatch, lanes):
+    """sha256_group_kernel: 64 / lanes chains per wave (what an extract's thousands of restored files go through): more
+    chains than groups (the queue), unequal lengths inside a wave, every tail length, batches that end inside a group's
+    `lanes` blocks, plus short extents on the lane-wise kernel beside them."""
+    monkeypatch.setenv("ZPQ_SHA256_GROUP", str(lanes))
+    monkeypatch.setenv("ZPQ_SHA256_CHAIN_MIN", "4096")
+    sizes = [4096 + 64 * k + (k * 37) % 64 for k in range(0, 70)] + [64 * lanes * 5, 64 * lanes * 5 + 1, 64 * lanes * 5 - 1, 200000, 4096, 77777,
+                                                                     (1 << 18) + 13, 5, 0, 4095, 100, 64, 63, 4160]
+    files = [datagen.random_bytes(n, 900 + i) for i, n in enumerate(sizes)]
+    assert eng.sha256_many(files) == [hashlib.sha256(f).digest() for f in files]
+    # one long chain alone in its wave, and exactly one group's worth of chains
+    files = [datagen.random_bytes(300000 + 7 * i, 990 + i) for i in range(64 // lanes)]
+    assert eng.sha256_many(files[:1]) == [hashlib.sha256(files[0]).digest()]
+    assert eng.sha256_many(files) == [hashlib.sha256(f).digest() for f in files]
+
+
 def test_gather_long_extents_and_many_extents(eng):
     rng = np.random.default_rng(8)
     src = datagen.random_bytes(12 << 20, 55)

@@ -95,3 +95,38 @@ def test_verify_reports_a_damaged_block(eng):
     bad[first_d + 2000] ^= 0x10
     rc, _ = E.jidac_verify(eng, bytes(bad))
     assert rc != 0
+
+
+@pytest.mark.parametrize("twins", [False, True])
+def test_extract_with_archive_and_files_resident_in_hbm(eng, twins):
+    """zpqj_extract_dev (Jidac::extract, ZSFX/zsfx.cpp:2018-2281, as ONE call with the archive in HBM and the files left there):
+    the plan call returns the index, the real call the same index, the files byte for byte and every file's SHA-256 -- for an
+    archive of two versions (the second one's d blocks lie behind the first one's index: the c-block jump, :1432-1461)."""
+    import hashlib
+    from zpaqfranz_amd import engine as E
+    fs = files()
+    arc1, _ = E.jidac_add(eng, b"", fs, 20240101120000)
+    more = [("v/a", datagen.text_like(300000, 95)), ("v/e", fs[2][1] + b"tail"), ("w/twin1", fs[4][1]), ("w/twin2", fs[4][1])]
+    arc2, _ = E.jidac_add(eng, arc1, more, 20240102120000)
+    arc = arc1 + arc2
+    want = dict(fs); want.update(dict(more))
+    d_arc = eng.upload(arc)
+    names, off, st = E.jidac_extract_dev(eng, d_arc.ptr, len(arc))
+    assert names == sorted(want) and off[0] == 0 and [off[i + 1] - off[i] for i in range(len(names))] == [len(want[n]) for n in names]
+    assert st["files"] == len(want) and st["bytes"] == off[-1]
+    d_out = eng.alloc(off[-1]); d_sha = eng.alloc(32 * len(names))
+    names2, off2, st2 = E.jidac_extract_dev(eng, d_arc.ptr, len(arc), d_out.ptr, off[-1] + 64, d_sha.ptr, len(names), twins=twins)
+    assert (names2, off2) == (names, off) and st2["fragments"] >= st2["d_blocks"] >= 2
+    blob = d_out.download(off[-1])
+    assert all(blob[off[i]:off[i + 1]] == want[n] for i, n in enumerate(names))
+    sha = d_sha.download(32 * len(names))
+    assert [sha[32 * i:32 * i + 32] for i in range(len(names))] == [hashlib.sha256(want[n]).digest() for n in names]
+    # a buffer that is too small is refused, and so is a damaged fragment
+    with pytest.raises(E.ZpqError):
+        E.jidac_extract_dev(eng, d_arc.ptr, len(arc), d_out.ptr, off[-1], d_sha.ptr, len(names))
+    bad = bytearray(arc); at = arc.index(TAG, 50) + 400; bad[at] ^= 1
+    d_bad = eng.upload(bytes(bad))
+    with pytest.raises(E.ZpqError):
+        E.jidac_extract_dev(eng, d_bad.ptr, len(arc), d_out.ptr, off[-1] + 64, d_sha.ptr, len(names))
+    for d in (d_arc, d_out, d_sha, d_bad):
+        d.free()

@@ -61,18 +61,36 @@ def build_shim():
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(HERE, "shim")] + srcs + ["-L" + HERE, "-lzpaqhip", "-Wl,-rpath,$ORIGIN", "-o", so]
         subprocess.check_call(cmd)
-    build_rccl()
+    try:
+        build_rccl()
+    except (subprocess.CalledProcessError, OSError) as ex:
+        # only the process-sharded add (zpqj_add_sharded over zpqr_allgatherv) needs it: a host without librccl still gets the
+        # engine, the shim and the journaling library; RcclGather.lib() says what is missing when it is first asked for
+        sys.stderr.write("zpaqfranz_amd.build: libzpaq_rccl.so not built (%s); the in-tree RCCL all-gather is unavailable\n" % ex)
     return SHIM_SO
 
 
 RCCL_SO = os.path.join(HERE, "libzpaq_rccl.so")
 
 
+def rocm_path():
+    """ROCM_PATH, else what hipconfig says, else /opt/rocm"""
+    p = os.environ.get("ROCM_PATH")
+    if p:
+        return p
+    try:
+        p = subprocess.run(["hipconfig", "--rocmpath"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        p = ""
+    return p or "/opt/rocm"
+
+
 def build_rccl():
     """The all-gather of byte strings over RCCL (shim/rccl_gather.cpp: plain rccl.h, no torch) that zpqj_add_sharded takes as
     its one collective; a library of its own so that nothing else depends on librccl."""
     cmd = ["hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "shim"),
-           os.path.join(HERE, "shim", "rccl_gather.cpp"), "-L" + HERE, "-lzpaqhip", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", RCCL_SO]
+           os.path.join(HERE, "shim", "rccl_gather.cpp"), "-L" + HERE, "-lzpaqhip", "-L" + os.path.join(rocm_path(), "lib"), "-lrccl",
+           "-Wl,-rpath,$ORIGIN", "-o", RCCL_SO]
     subprocess.check_call(cmd)
     return RCCL_SO
 

@@ -500,6 +500,107 @@ __global__ __launch_bounds__(256) void sha256_chain_kernel(const u8* __restrict_
   }
 }
 
+// ---- several long chains per wave ---------------------------------------------------------------------------------
+// sha256_chain_kernel spends a whole wave on one chain: 64 lanes run the same 64 rounds and one of them is right.  That is
+// the fastest a single chain goes (~915 instructions per 64-byte block on the chain, 36 MB/s), but a SIMD issues one wave64
+// integer instruction per four cycles whoever it comes from, so 3072 restored files of 2-51 MB cost the chip 3072 x that.
+// Here a wave carries G = 64 / S chains, S lanes each: group g loads and expands the schedules of the next S blocks of ITS
+// chain (lane j: block b0 + j), then all groups run the rounds of their blocks 0 .. S-1 one after the other, every lane on
+// its own schedule from its group's state (VGPRs now, uniform within the group); lane g S + b holds the true successor
+// state and ds_bpermute hands it to the group.  The chain is ~(915 + 544 / S + 30) instructions per block -- 4-15 % slower
+// than the wave-wide form for S = 16 .. 4 -- and the wave's instructions serve G chains: the SHA-256 of Jidac's extract
+// (every restored file, ZSFX/libzpaq.cpp:171-304 byte for byte) drops from ~1.5 s of the whole chip to ~1.5 s of a
+// quarter (S = 16) or a sixteenth (S = 4) of it, which is what several extract jobs in flight need.
+// Groups are persistent: a group whose chain ends takes the next entry of the (longest-first) list off the queue.
+template <int S>
+__global__ __launch_bounds__(256) void sha256_group_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
+                                                           const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
+                                                           const u32* __restrict__ list, u32* __restrict__ queue) {
+  const int lane = lane_id();
+  const int g0 = lane & ~(S - 1), j = lane & (S - 1);          // first lane of my group, my block slot
+  bool have = false, done = false;
+  u32 idx = 0;
+  const u8* p = nullptr;
+  u64 total = 0, nfull = 0, b0 = 0;
+  u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (;;) {
+    if (__any(!have && !done)) {
+      u32 k = 0xffffffffu;
+      if (!have && !done && j == 0) k = atomicAdd(queue, 1u);
+      k = (u32)__builtin_amdgcn_ds_bpermute(g0 << 2, (int)k);
+      if (!have && !done) {
+        if (k < n) {
+          idx = list ? list[k] : k;
+          total = len[idx]; nfull = total >> 6; b0 = 0;
+          p = base + off[idx];
+          s[0] = 0x6a09e667u; s[1] = 0xbb67ae85u; s[2] = 0x3c6ef372u; s[3] = 0xa54ff53au;
+          s[4] = 0x510e527fu; s[5] = 0x9b05688cu; s[6] = 0x1f83d9abu; s[7] = 0x5be0cd19u;
+          have = true;
+        } else done = true;
+      }
+    }
+    if (!__any(have)) return;
+    const u64 left = have ? nfull - b0 : 0;
+    const u32 cnt = left < (u64)S ? (u32)left : (u32)S;
+    if (__any(cnt != 0)) {
+      u32 w[64];
+      if ((u32)j < cnt) {
+        const u32x4_u* q = (const u32x4_u*)(p + (b0 + (u64)j) * 64);
+        const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        w[0] = bswap32(v0.x); w[1] = bswap32(v0.y); w[2] = bswap32(v0.z); w[3] = bswap32(v0.w);
+        w[4] = bswap32(v1.x); w[5] = bswap32(v1.y); w[6] = bswap32(v1.z); w[7] = bswap32(v1.w);
+        w[8] = bswap32(v2.x); w[9] = bswap32(v2.y); w[10] = bswap32(v2.z); w[11] = bswap32(v2.w);
+        w[12] = bswap32(v3.x); w[13] = bswap32(v3.y); w[14] = bswap32(v3.z); w[15] = bswap32(v3.w);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = 0;
+      }
+#pragma unroll
+      for (int t = 16; t < 64; ++t) {
+        const u32 w15 = w[t - 15], w2 = w[t - 2];
+        w[t] = add3(w[t - 16], xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3), w[t - 7]) + xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+      }
+#pragma unroll
+      for (int t = 0; t < 64; ++t) w[t] += K256[t];
+      for (u32 b = 0; b < (u32)S; ++b) {
+        if (!__any(b < cnt)) break;
+        u32 a = s[0], bb = s[1], c = s[2], d = s[3], e = s[4], f = s[5], gg = s[6], h = s[7];
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+          const u32 t1 = add3(h, xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)), bfi(e, f, gg)) + w[t];
+          const u32 na = add3(t1, xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)), maj3(a, bb, c));
+          h = gg; gg = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = na;
+        }
+        const int src = (g0 + (int)b) << 2;
+        const u32 r0 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)a), r1 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)bb);
+        const u32 r2 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)c), r3 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)d);
+        const u32 r4 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)e), r5 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)f);
+        const u32 r6 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)gg), r7 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)h);
+        if (b < cnt) { s[0] += r0; s[1] += r1; s[2] += r2; s[3] += r3; s[4] += r4; s[5] += r5; s[6] += r6; s[7] += r7; }
+      }
+      b0 += cnt;
+    }
+    if (have && b0 >= nfull) {
+      // closing block(s): every lane of the group computes the same thing, its first lane stores
+      const u8* q = p + nfull * 64;
+      u32 rem = (u32)(total & 63);
+      bool marker = false, last = false;
+      while (!last) {
+        u32 w16[16];
+        last = tail_block(w16, q, rem, marker, total);
+        q += rem; rem = 0;
+        sha256_rounds(w16, s);
+      }
+      if (j == 0) {
+        u32* o = (u32*)(digests + (size_t)idx * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = bswap32(s[i]);
+      }
+      have = false;
+    }
+  }
+}
+
 // ---- longest-first work order ------------------------------------------------------------------------
 // A lane hashes ~13-25 MB/s, so one 508 KiB fragment is tens of milliseconds of serial work: handed
 // out in input order, the last long extents would finish long after everything else (measured: the
@@ -713,7 +814,33 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
     if (!d_ord) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "scratch");
     ZPQ_HIP(ctx, hipMemcpyAsync(d_ord, ord.data(), n * 4, hipMemcpyHostToDevice, st));
     ZPQ_HIP(ctx, hipStreamSynchronize(st));              // ord is a local
-    if (kc) {
+    // More long extents than SIMDs (an extract's restored files: thousands of megabytes-long chains): several chains per
+    // wave, S lanes each (sha256_group_kernel) -- every long extent at (nearly) chain speed from the start, on a fraction
+    // of the chip.  S from how many there are: one wave per SIMD at most where that is possible.  ZPQ_SHA256_GROUP=S forces
+    // it (0 = never: the wave-wide / lane-wise split of before).
+    size_t nl = 0;
+    while (nl < n && hl[ord[nl]] >= chain_min) ++nl;
+    int S = 0;
+    {
+      const size_t simds = (size_t)ctx->cu_count * 4;
+      if (nl > simds) S = nl <= simds * 4 ? 16 : nl <= simds * 8 ? 8 : 4;
+      if (const char* e = getenv("ZPQ_SHA256_GROUP")) { const int v = atoi(e); S = (v == 4 || v == 8 || v == 16 || v == 32) && nl ? v : 0; }
+    }
+    if (S) {
+      kc = nl;
+      ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
+      ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
+      const size_t groups = 64 / (size_t)S, waves = (nl + groups - 1) / groups;
+      const dim3 grid((unsigned)std::min<size_t>((waves + 3) / 4, (size_t)ctx->cu_count * 2));
+      switch (S) {
+        case 4: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<4>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
+        case 8: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<8>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
+        case 16: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<16>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
+        default: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<32>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
+      }
+      ZPQ_HIP(ctx, hipGetLastError());
+      ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
+    } else if (kc) {
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev2, st));
       ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
       const size_t cw = std::min(kc, max_chains);         // persistent waves, one per SIMD at most

@@ -591,6 +591,8 @@ def load_shim():
         S.zpqj_extract.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         S.zpqj_verify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p]
+        S.zpqj_extract_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32,
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_add_opts.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_add_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLGATHERV, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -814,6 +816,28 @@ def jidac_verify(eng, archive):
     rc = S.zpqj_verify(eng.ctx, bytes(archive), len(archive), st)
     keys = ("files", "fragments", "bytes", "files_with_checksums", "xxh64_mismatches", "crc32_mismatches", "d_blocks")
     return rc, dict(zip(keys, [int(x) for x in st]))
+
+
+def jidac_extract_dev(eng, d_archive, archive_len, d_out=0, out_cap=0, d_sha256=0, sha256_cap=0, sha256=True, twins=False):
+    """zpqj_extract_dev: archive resident in HBM in, restored files left in HBM (d_out) + their SHA-256 (d_sha256); returns
+    (names, file_off, stats).  d_out = 0: plan only (the index: names and offsets)."""
+    S = load_shim()
+    fo, names, n = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    st = (C.c_uint64 * 7)()
+    flags = (1 if sha256 and d_sha256 else 0) | (2 if twins else 0)
+    rc = S.zpqj_extract_dev(eng.ctx, C.c_void_p(d_archive), archive_len, C.c_void_p(d_out) if d_out else None, out_cap,
+                            C.c_void_p(d_sha256) if d_sha256 else None, sha256_cap, flags, C.byref(fo), C.byref(names), C.byref(n), st)
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    off = list((C.c_uint64 * (n.value + 1)).from_address(fo.value))
+    nm, p = [], names.value
+    for _ in range(n.value):
+        s_ = C.string_at(p)
+        p += len(s_) + 1
+        nm.append(s_.decode())
+    S.zpqj_free(fo); S.zpqj_free(names)
+    keys = ("files", "fragments", "bytes", "twins", "twin_bytes", "compared_bytes", "d_blocks")
+    return nm, off, {k: int(v) for k, v in zip(keys, st)}
 
 
 def jidac_extract(eng, archive):

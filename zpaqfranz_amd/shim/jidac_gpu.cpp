@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <new>
 #include <stdexcept>
@@ -163,11 +164,16 @@ int decompress_host(zpq_ctx* ctx, const uint8_t* blk, size_t n, size_t usize, By
   return ZPQ_OK;
 }
 
-// read_archive (ZSFX/zsfx.cpp:1283-1627), journaling blocks only
-int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
+// read_archive (ZSFX/zsfx.cpp:1283-1627), journaling blocks only.
+// fetch != nullptr: `arc` is a host SHADOW of an archive that lies in HBM -- fetch(lo, hi) makes [lo, hi) of it valid -- and the
+// d blocks are never looked at: after a c block the walk jumps over them by the size the c block holds, as the reference's
+// own read_archive does (ZSFX/zsfx.cpp:1432-1461).
+int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix, const std::function<int(size_t, size_t)>* fetch = nullptr) {
   size_t pos = 0, data_offset = 0;
+  bool rest_fetched = false;
   while (pos < n) {
     RawBlock rb;
+    if (fetch && !rest_fetched) { const int rc = (*fetch)(pos, std::min(n, pos + 4096)); if (rc) return rc; }
     if (!parse_block(arc + pos, n - pos, rb)) return ZPQ_ERR_FORMAT;
     if (rb.name.size() != 28 || rb.name.compare(0, 3, "jDC") != 0 || rb.comment.size() < 4 ||
         rb.comment.compare(rb.comment.size() - 4, 4, "jDC\x01") != 0)
@@ -191,6 +197,14 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix) {
         if (jmp < 0) break;                       // incomplete transaction: roll back (ZSFX/zsfx.cpp:1436-1443)
         ++ix.versions;
         data_offset = pos + rb.size;
+        if (fetch) {
+          if ((uint64_t)jmp > n - pos - rb.size) return ZPQ_ERR_FORMAT;
+          pos += (size_t)jmp;                      // (+ rb.size below): the first h block of this version
+          if (!rest_fetched) {                     // everything behind the first version's d blocks: index blocks (and later versions)
+            const int rc = (*fetch)(pos + rb.size, n); if (rc) return rc;
+            rest_fetched = true;
+          }
+        }
       } else if (type == 'h') {
         if (os.size() % 24 != 4) return ZPQ_ERR_FORMAT;
         const uint32_t nf = (uint32_t)((os.size() - 4) / 24), bsize = get32(os.data());
@@ -757,10 +771,27 @@ bool stored_checksums(const std::string& attr, uint64_t* xxh, uint32_t* crc) {
 // verify != nullptr: nothing is returned to the host; the files are assembled in HBM and their stored XXHASH64 / CRC-32
 // (when the attributes carry them) recomputed there.  verify[0..6] = files, fragments checked, bytes restored, files
 // with stored checksums, XXHASH64 mismatches, CRC-32 mismatches, d blocks.
+// dv != nullptr (zpqj_extract_dev): `archive` is a DEVICE pointer, the files stay in HBM (dv->d_out) and, if asked for, their
+// SHA-256 is computed there; what comes back to the host is the index: names and file offsets.
+struct DevExtract { uint8_t* d_out; size_t out_cap; uint8_t* d_sha256; size_t sha_cap; uint32_t flags; uint64_t** file_off; uint64_t* stats; };
 int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes, char** names,
-                 size_t* nfiles, uint64_t* verify = nullptr) {
+                 size_t* nfiles, uint64_t* verify = nullptr, const DevExtract* dv = nullptr) {
   Index ix;
-  int rc = read_index(ctx, archive, archive_len, ix);
+  int rc;
+  struct Shadow { uint8_t* p; ~Shadow() { free(p); } } shadow{nullptr};
+  const uint8_t* d_archive = nullptr;
+  if (dv) {
+    // the host reads the index blocks only: a zero-filled shadow of the archive (calloc: pages that are never written are never
+    // backed), filled where read_index asks -- the c block in front, then everything behind the first version's d blocks
+    d_archive = archive;
+    shadow.p = (uint8_t*)calloc(archive_len + 64, 1);
+    if (!shadow.p) return ZPQ_ERR_NOMEM;
+    const std::function<int(size_t, size_t)> fetch = [&](size_t lo, size_t hi) { return hi > lo ? zpq_d2h(ctx, shadow.p + lo, d_archive + lo, hi - lo) : (int)ZPQ_OK; };
+    rc = read_index(ctx, shadow.p, archive_len, ix, &fetch);
+    archive = shadow.p;
+  } else {
+    rc = read_index(ctx, archive, archive_len, ix);
+  }
   if (rc) return rc;
   struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{ctx, {}};
   const size_t nb = ix.blocks.size();
@@ -773,19 +804,29 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     aoff[b] = apos; apos += ((uint64_t)B.csize + 64 + 63) & ~(uint64_t)63;
     poff[b] = ppos; ppos += (B.usize + 64 + 63) & ~(uint64_t)63;
   }
+  // (plan only -- zpqj_extract_dev without an output buffer: the index is all that is wanted)
+  const bool plan_only = dv && !dv->d_out;
   void *d_arc = nullptr, *d_plain = nullptr;
-  if ((rc = zpq_dev_alloc_pooled(ctx, apos + 64, &d_arc))) return rc; dev.p.push_back(d_arc);
-  if ((rc = zpq_dev_alloc_pooled(ctx, ppos + 64, &d_plain))) return rc; dev.p.push_back(d_plain);
-  if ((rc = zpq_dev_memset(ctx, d_arc, 0, apos + 64))) return rc;
+  if (!dv) {
+    if ((rc = zpq_dev_alloc_pooled(ctx, apos + 64, &d_arc))) return rc; dev.p.push_back(d_arc);
+    if ((rc = zpq_dev_memset(ctx, d_arc, 0, apos + 64))) return rc;
+  }
+  if (!plan_only) { if ((rc = zpq_dev_alloc_pooled(ctx, ppos + 64, &d_plain))) return rc; dev.p.push_back(d_plain); }
   std::vector<zpq_unblock_job> jobs(nb);
-  for (size_t b = 0; b < nb; ++b) {
+  for (size_t b = 0; b < nb && !plan_only; ++b) {
     const DBlock& B = ix.blocks[b];
-    if ((rc = zpq_h2d(ctx, (uint8_t*)d_arc + aoff[b], archive + B.offset, B.csize))) return rc;
     memset(&jobs[b], 0, sizeof jobs[b]);
-    jobs[b].in = (uint8_t*)d_arc + aoff[b]; jobs[b].n = B.csize;
+    if (dv) {
+      // the d blocks are decoded where they lie (the caller guarantees 64 readable bytes behind the archive)
+      jobs[b].in = d_archive + B.offset;
+    } else {
+      if ((rc = zpq_h2d(ctx, (uint8_t*)d_arc + aoff[b], archive + B.offset, B.csize))) return rc;
+      jobs[b].in = (uint8_t*)d_arc + aoff[b];
+    }
+    jobs[b].n = B.csize;
     jobs[b].out = (uint8_t*)d_plain + poff[b]; jobs[b].out_cap = (uint32_t)B.usize + 64;
   }
-  if (nb) {
+  if (nb && !plan_only) {
     rc = zpq_decompress_blocks_dev(ctx, jobs.data(), nb, 1);
     for (size_t b = 0; b < nb; ++b) {
       if (jobs[b].status) return jobs[b].status;
@@ -807,7 +848,7 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
       o += ix.ht[f].usize;
     }
   }
-  if (!voff.empty()) {
+  if (!voff.empty() && !plan_only) {
     void *d_voff, *d_vlen, *d_want, *d_got;
     const size_t nv = voff.size();
     if ((rc = zpq_dev_alloc_pooled(ctx, nv * 8, &d_voff))) return rc; dev.p.push_back(d_voff);
@@ -837,7 +878,20 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     blob_len += len;
     sz.push_back(len); nm += kv.first; nm.push_back('\0');
   }
-  if (verify) {
+  if (dv) {
+    // the index goes back: names and offsets; the files stay where the gather below puts them
+    uint64_t* st = dv->stats;
+    if (st) { st[0] = sz.size(); st[1] = voff.size(); st[2] = blob_len; st[3] = st[4] = st[5] = 0; st[6] = nb; }
+    *dv->file_off = (uint64_t*)malloc((sz.size() + 1) * 8);
+    *names = (char*)malloc(nm.size() ? nm.size() : 1);
+    if (!*dv->file_off || !*names) return ZPQ_ERR_NOMEM;
+    (*dv->file_off)[0] = 0;
+    for (size_t i = 0; i < sz.size(); ++i) (*dv->file_off)[i + 1] = (*dv->file_off)[i] + sz[i];
+    memcpy(*names, nm.data(), nm.size());
+    *nfiles = sz.size();
+    if (plan_only) return ZPQ_OK;
+    if (blob_len + 64 > dv->out_cap || (dv->d_sha256 && sz.size() > dv->sha_cap)) return ZPQ_ERR_ARG;
+  } else if (verify) {
     verify[0] = sz.size(); verify[1] = voff.size(); verify[2] = blob_len; verify[3] = verify[4] = verify[5] = 0; verify[6] = nb;
   } else {
     *data = (uint8_t*)malloc(blob_len ? blob_len : 1);
@@ -846,7 +900,8 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     if (!*data || !*sizes || !*names) return ZPQ_ERR_NOMEM;
   }
   void* d_blob = nullptr;
-  if ((rc = zpq_dev_alloc_pooled(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob);
+  if (dv) d_blob = dv->d_out;
+  else { if ((rc = zpq_dev_alloc_pooled(ctx, blob_len + 64, &d_blob))) return rc; dev.p.push_back(d_blob); }
   if (!so.empty()) {
     void *d_so, *d_sl, *d_dso;
     if ((rc = zpq_dev_alloc_pooled(ctx, so.size() * 8, &d_so))) return rc; dev.p.push_back(d_so);
@@ -855,7 +910,24 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     if ((rc = zpq_h2d(ctx, d_so, so.data(), so.size() * 8)) || (rc = zpq_h2d(ctx, d_sl, sl.data(), sl.size() * 4)) ||
         (rc = zpq_h2d(ctx, d_dso, dso.data(), dso.size() * 8))) return rc;
     if ((rc = zpq_gather_dev(ctx, (const uint8_t*)d_plain, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, so.size(), (uint8_t*)d_blob))) return rc;
-    if (!verify && blob_len && (rc = zpq_d2h(ctx, *data, d_blob, blob_len))) return rc;
+    if (!verify && !dv && blob_len && (rc = zpq_d2h(ctx, *data, d_blob, blob_len))) return rc;
+  }
+  if (dv) {
+    if (dv->d_sha256 && !sz.empty()) {
+      // every restored file's SHA-256 (what `x` / `t` verify against the originals' -- zpaqfranz's -sha256 file hash), in HBM
+      if (dv->flags & ZPQJ_X_TWINS) {
+        uint64_t ts[4] = {0, 0, 0, 0};       // twins, twin bytes, files compared, bytes compared
+        if ((rc = zpq_sha256_files_dev(ctx, (const uint8_t*)d_blob, *dv->file_off, sz.size(), dv->d_sha256, 0, ts))) return rc;
+        if (dv->stats) { dv->stats[3] = ts[0]; dv->stats[4] = ts[1]; dv->stats[5] = ts[3]; }
+      } else {
+        void *d_fo, *d_fl;
+        if ((rc = zpq_dev_alloc_pooled(ctx, sz.size() * 8, &d_fo))) return rc; dev.p.push_back(d_fo);
+        if ((rc = zpq_dev_alloc_pooled(ctx, sz.size() * 8, &d_fl))) return rc; dev.p.push_back(d_fl);
+        if ((rc = zpq_h2d(ctx, d_fo, *dv->file_off, sz.size() * 8)) || (rc = zpq_h2d(ctx, d_fl, sz.data(), sz.size() * 8))) return rc;
+        if ((rc = zpq_sha256_extents_dev(ctx, (const uint8_t*)d_blob, (const uint64_t*)d_fo, (const uint64_t*)d_fl, sz.size(), dv->d_sha256))) return rc;
+      }
+    }
+    return zpq_sync(ctx);
   }
   if (verify && !sz.empty()) {
     // the `t` command: per-file XXHASH64 + CRC-32 of the assembled bytes against what the i blocks store
@@ -964,6 +1036,27 @@ int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
   *data = nullptr; *sizes = nullptr; *names = nullptr; *nfiles = 0;
   const int rc = guarded([&] { return extract_impl(ctx, archive, archive_len, data, sizes, names, nfiles); });
   if (rc) { free(*data); free(*sizes); free(*names); *data = nullptr; *sizes = nullptr; *names = nullptr; *nfiles = 0; }
+  return rc;
+}
+
+// Jidac::extract (ZSFX/zsfx.cpp:2018-2281, decompressThread :1731-1994) with the archive ALREADY IN HBM and the restored files LEFT
+// in HBM: the host reads the index (c / h / i blocks: a few megabytes cross PCIe, the d blocks are jumped over as the reference's
+// read_archive does, :1432-1461), the d blocks are decoded where they lie (stored SHA-1s checked), every fragment's SHA-1 is
+// compared with the h table, the files are assembled back to back in name order in d_out, and with ZPQJ_X_SHA256 every file's
+// SHA-256 is left in d_sha256 (32 bytes per file).  *file_off (nfiles + 1 offsets into d_out) and *names (NUL separated) are
+// malloc'd: zpqj_free.  d_out == NULL: plan only -- the index is read, *file_off / *names / *nfiles / stats come back and
+// nothing is decoded (the caller sizes d_out = file_off[nfiles] + 64 and d_sha256 from it).  d_archive must be readable for 64
+// bytes behind archive_len.  stats[0..6] = files, fragments checked, bytes restored, twin files, twin bytes, bytes compared
+// (ZPQJ_X_TWINS, else 0), d blocks.
+int zpqj_extract_dev(zpq_ctx* ctx, const uint8_t* d_archive, size_t archive_len, uint8_t* d_out, size_t out_cap, uint8_t* d_sha256,
+                     size_t sha256_cap_files, uint32_t flags, uint64_t** file_off, char** names, size_t* nfiles, uint64_t stats[7]) {
+  if (!file_off || !names || !nfiles) return ZPQ_ERR_ARG;
+  *file_off = nullptr; *names = nullptr; *nfiles = 0;
+  if (!ctx || !d_archive) return ZPQ_ERR_ARG;
+  if (!(flags & ZPQJ_X_SHA256)) d_sha256 = nullptr;
+  const DevExtract dv{d_out, out_cap, d_sha256, sha256_cap_files, flags, file_off, stats};
+  const int rc = guarded([&] { return extract_impl(ctx, d_archive, archive_len, nullptr, nullptr, names, nfiles, nullptr, &dv); });
+  if (rc) { free(*file_off); free(*names); *file_off = nullptr; *names = nullptr; *nfiles = 0; }
   return rc;
 }
 

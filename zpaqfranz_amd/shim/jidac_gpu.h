@@ -50,6 +50,17 @@ int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allga
 int zpqj_shard_files(const char* const* names, const uint64_t* sizes, size_t nfiles, int world, int rank, uint8_t* mine);
 int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes,
                  char** names, size_t* nfiles);
+/* Jidac::extract (ZSFX/zsfx.cpp:2018-2281; decompressThread :1731-1994; read_archive's jump over the d blocks :1432-1461) with the
+ * archive ALREADY IN HBM (d_archive, readable for 64 bytes behind archive_len) and the restored files LEFT IN HBM: back to back
+ * in name order in d_out (out_cap >= file_off[nfiles] + 64).  *file_off (nfiles + 1 entries) and *names (NUL separated) come back
+ * malloc'd (zpqj_free).  ZPQJ_X_SHA256: every restored file's SHA-256 into d_sha256 (32 bytes per file, room for
+ * sha256_cap_files); with ZPQJ_X_TWINS a file whose bytes equal an earlier restored file's (every byte compared on the device)
+ * takes that file's digest.  d_out == NULL: plan only (index read, sizes returned, nothing decoded).
+ * stats[0..6] = files, fragments checked, bytes restored, twin files, twin bytes, bytes compared (ZPQJ_X_TWINS), d blocks. */
+#define ZPQJ_X_SHA256 1u
+#define ZPQJ_X_TWINS 2u
+int zpqj_extract_dev(zpq_ctx* ctx, const uint8_t* d_archive, size_t archive_len, uint8_t* d_out, size_t out_cap, uint8_t* d_sha256,
+                     size_t sha256_cap_files, uint32_t flags, uint64_t** file_off, char** names, size_t* nfiles, uint64_t stats[7]);
 /* zpaqfranz t: decode + verify everything on the device (block SHA-1s, fragment SHA-1s against the h table, and the
  * per-file XXHASH64 / CRC-32 the i blocks carry, where they do); nothing but stats[0..6] comes back: files, fragments
  * checked, bytes restored, files with stored checksums, XXHASH64 mismatches, CRC-32 mismatches, d blocks. */
