@@ -78,6 +78,10 @@ int zpq_dev_free(zpq_ctx* ctx, void* dptr);
  * (ZSFX/libzpaq.h:1377-1494).  One job at a time per context, like every call on a context. */
 int zpq_dev_alloc_pooled(zpq_ctx* ctx, size_t bytes, void** dptr);
 int zpq_dev_free_pooled(zpq_ctx* ctx, void* dptr);
+/* Gives the context's idle pooled blocks back to the driver (*freed, optional: their bytes).  Every device allocation of the
+ * engine that fails does this by itself -- for the calling context, then for every other live context of the device -- and
+ * tries again before it reports ZPQ_ERR_NOMEM; a host about to allocate on its own calls it. */
+int zpq_pool_trim(zpq_ctx* ctx, size_t* freed);
 int zpq_h2d(zpq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int zpq_d2h(zpq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int zpq_dev_memset(zpq_ctx* ctx, void* dst_dev, int value, size_t bytes);

@@ -502,6 +502,10 @@ def test_jidac_add_dev_equals_the_host_pointer_add(eng):
         bad = E.DevFiles(["b", "a"], [0, 10, 20], version_date=1)
         with pytest.raises(E.ZpqError):
             E.jidac_add_dev(eng, b"", buf.ptr, bad, 20240101120000)
+        # ... the same name twice, offsets that go backwards, a base the 16-byte reads cannot use: refused, each of them
+        for names_, off_, base_ in ((["a", "a"], [0, 10, 20], buf.ptr), (["a", "b"], [0, 20, 10], buf.ptr), (["a", "b"], [0, 10, 20], buf.ptr + 4)):
+            with pytest.raises(E.ZpqError):
+                E.jidac_add_dev(eng, b"", base_, E.DevFiles(names_, off_, version_date=1), 20240101120000)
         if orc.have_ref():
             total = sum(len(d) for _, d in files)
             blocks, off = [], 0

@@ -130,3 +130,33 @@ def test_extract_with_archive_and_files_resident_in_hbm(eng, twins):
         E.jidac_extract_dev(eng, d_bad.ptr, len(arc), d_out.ptr, off[-1] + 64, d_sha.ptr, len(names))
     for d in (d_arc, d_out, d_sha, d_bad):
         d.free()
+
+
+def test_pool_trim_gives_idle_blocks_back(eng):
+    """zpq_dev_alloc_pooled keeps freed blocks in the context; zpq_pool_trim (what a failed allocation of ANY context of the device
+    now does before it reports ZPQ_ERR_NOMEM: ADVICE round 5) hands the idle ones back to the driver and leaves blocks in use alone."""
+    import ctypes as C
+    from zpaqfranz_amd import Engine
+    L = eng.L
+    L.zpq_pool_trim.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.zpq_dev_alloc_pooled.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.zpq_dev_free_pooled.argtypes = [C.c_void_p, C.c_void_p]
+    other = Engine(0)
+    try:
+        freed = C.c_size_t(0)
+        assert L.zpq_pool_trim(eng.ctx, C.byref(freed)) == 0           # whatever earlier tests left idle
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert L.zpq_dev_alloc_pooled(eng.ctx, 3 << 20, C.byref(a)) == 0 and L.zpq_dev_alloc_pooled(eng.ctx, 5 << 20, C.byref(b)) == 0
+        assert L.zpq_dev_alloc_pooled(other.ctx, 7 << 20, C.byref(c)) == 0
+        assert L.zpq_dev_free_pooled(eng.ctx, a) == 0
+        assert L.zpq_pool_trim(eng.ctx, C.byref(freed)) == 0 and (3 << 20) <= freed.value < (5 << 20)      # a went back, b is in use
+        assert L.zpq_pool_trim(eng.ctx, C.byref(freed)) == 0 and freed.value == 0
+        assert L.zpq_pool_trim(other.ctx, C.byref(freed)) == 0 and freed.value == 0                       # c is in use
+        assert L.zpq_dev_free_pooled(other.ctx, c) == 0
+        assert L.zpq_pool_trim(other.ctx, C.byref(freed)) == 0 and freed.value >= (7 << 20)
+        # b is still usable, and a fresh request is served after the trim
+        assert L.zpq_dev_memset(eng.ctx, b, 1, 5 << 20) == 0 and L.zpq_sync(eng.ctx) == 0
+        assert L.zpq_dev_alloc_pooled(eng.ctx, 3 << 20, C.byref(a)) == 0
+        assert L.zpq_dev_free_pooled(eng.ctx, a) == 0 and L.zpq_dev_free_pooled(eng.ctx, b) == 0
+    finally:
+        other.close()

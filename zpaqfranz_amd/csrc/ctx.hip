@@ -17,13 +17,53 @@ int zpq_fail(zpq_ctx* ctx, int status, const char* fmt, ...) {
   return status;
 }
 
+// ---- making room: every context keeps up to 6 GiB of idle pooled blocks, twelve contexts run beside each other in
+// the bench, and until round 6 only the pool's own allocator ever gave them back.  Now any device allocation of the engine that
+// fails first releases the idle blocks of its own context, then those of every other live context on the device, and tries again.
+static std::mutex g_ctx_mu;
+static std::vector<zpq_ctx*> g_ctxs;
+
+static size_t pool_trim(zpq_ctx* c) {
+  std::lock_guard<std::mutex> g(c->pool_mu);
+  size_t freed = 0;
+  for (size_t i = c->pool.size(); i-- > 0;)
+    if (!c->pool[i].in_use) {
+      // (an idle block's last user has finished or is ordered before this on the device: hipFree waits for the device)
+      freed += c->pool[i].cap;
+      (void)hipFree(c->pool[i].p);
+      c->pool.erase(c->pool.begin() + (long)i);
+    }
+  return freed;
+}
+
+hipError_t zpq_device_malloc(zpq_ctx* ctx, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();                       // (a failed hipMalloc must not surface as the "last error" of the next launch)
+  if (pool_trim(ctx)) {
+    if ((e = hipMalloc(p, bytes)) == hipSuccess) return e;
+    (void)hipGetLastError();
+  }
+  size_t freed = 0;
+  {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (zpq_ctx* c : g_ctxs)
+      if (c != ctx && c->device == ctx->device) freed += pool_trim(c);
+  }
+  if (freed) {
+    if ((e = hipMalloc(p, bytes)) == hipSuccess) return e;
+    (void)hipGetLastError();
+  }
+  return e;
+}
+
 void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (bytes <= ctx->scratch_cap[slot] && ctx->scratch[slot]) return ctx->scratch[slot];
   if (ctx->scratch[slot]) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipFree(ctx->scratch[slot]); }
   size_t cap = bytes + bytes / 4 + 4096;
   void* p = nullptr;
-  if (hipMalloc(&p, cap) != hipSuccess) { ctx->scratch[slot] = nullptr; ctx->scratch_cap[slot] = 0; return nullptr; }
+  if (zpq_device_malloc(ctx, &p, cap) != hipSuccess) { ctx->scratch[slot] = nullptr; ctx->scratch_cap[slot] = 0; return nullptr; }
   ctx->scratch[slot] = p;
   ctx->scratch_cap[slot] = cap;
   return p;
@@ -42,7 +82,6 @@ void* zpq_pinned(zpq_ctx* ctx, size_t bytes) {
 }
 
 // ---- cooperative wave placement (zpq_internal.h) -----------------------------------------------------------------
-#include <mutex>
 u32* zpq_simd_table(zpq_ctx* ctx) {
   static std::mutex mu;
   static u32* tab[64] = {nullptr};
@@ -131,6 +170,7 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
   }
   if (getenv("ZPQ_PLACE_DEBUG")) place_probe(c);
   g_live_contexts.fetch_add(1, std::memory_order_relaxed);
+  { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctxs.push_back(c); }
   *out = c;
   return ZPQ_OK;
 }
@@ -138,6 +178,7 @@ int zpq_create(int device_ordinal, zpq_ctx** out) {
 void zpq_destroy(zpq_ctx* ctx) {
   if (!ctx) return;
   g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
+  { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end()); }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
@@ -219,7 +260,16 @@ int zpq_profile_report(zpq_ctx* ctx, char* buf, size_t cap) {
 
 int zpq_dev_alloc(zpq_ctx* ctx, size_t bytes, void** dptr) {
   ZPQ_HIP(ctx, hipSetDevice(ctx->device));
-  if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", bytes);
+  if (zpq_device_malloc(ctx, dptr, bytes ? bytes : 1) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", bytes);
+  return ZPQ_OK;
+}
+// The idle blocks of the context's pool go back to the driver (*freed: their bytes).  Allocations of the engine that fail do this
+// themselves, for every context of the device; a host that is about to allocate on its own (torch, another library) calls it.
+int zpq_pool_trim(zpq_ctx* ctx, size_t* freed) {
+  if (!ctx) return ZPQ_ERR_ARG;
+  ZPQ_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = pool_trim(ctx);
+  if (freed) *freed = n;
   return ZPQ_OK;
 }
 int zpq_dev_free(zpq_ctx* ctx, void* dptr) {
@@ -235,21 +285,19 @@ int zpq_dev_alloc_pooled(zpq_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return ZPQ_ERR_ARG;
   ZPQ_HIP(ctx, hipSetDevice(ctx->device));
   if (!bytes) bytes = 1;
-  size_t best = ctx->pool.size();
-  for (size_t i = 0; i < ctx->pool.size(); ++i) {
-    const zpq_ctx::PoolBlock& b = ctx->pool[i];
-    if (!b.in_use && b.cap >= bytes && b.cap / 2 <= bytes + (1u << 20) && (best == ctx->pool.size() || b.cap < ctx->pool[best].cap)) best = i;
+  {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    size_t best = ctx->pool.size();
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+      const zpq_ctx::PoolBlock& b = ctx->pool[i];
+      if (!b.in_use && b.cap >= bytes && b.cap / 2 <= bytes + (1u << 20) && (best == ctx->pool.size() || b.cap < ctx->pool[best].cap)) best = i;
+    }
+    if (best != ctx->pool.size()) { ctx->pool[best].in_use = true; *dptr = ctx->pool[best].p; return ZPQ_OK; }
   }
-  if (best != ctx->pool.size()) { ctx->pool[best].in_use = true; *dptr = ctx->pool[best].p; return ZPQ_OK; }
   const size_t cap = bytes <= ((size_t)1 << 30) ? ((bytes + bytes / 8 + 65535) & ~(size_t)65535) : bytes;
-  if (hipMalloc(dptr, cap) != hipSuccess) {
-    // make room: give the idle blocks back to the driver and try once more
-    ZPQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = ctx->pool.size(); i-- > 0;)
-      if (!ctx->pool[i].in_use) { (void)hipFree(ctx->pool[i].p); ctx->pool.erase(ctx->pool.begin() + (long)i); }
-    if (hipMalloc(dptr, cap) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", cap);
-  }
-  if (bytes <= ((size_t)1 << 30)) ctx->pool.push_back({*dptr, cap, true});
+  // (makes room -- this context's idle blocks first, then the other contexts' -- before it gives up)
+  if (zpq_device_malloc(ctx, dptr, cap) != hipSuccess) return zpq_fail(ctx, ZPQ_ERR_NOMEM, "hipMalloc(%zu)", cap);
+  if (bytes <= ((size_t)1 << 30)) { std::lock_guard<std::mutex> g(ctx->pool_mu); ctx->pool.push_back({*dptr, cap, true}); }
   return ZPQ_OK;
 }
 int zpq_dev_free_pooled(zpq_ctx* ctx, void* dptr) {
@@ -257,11 +305,12 @@ int zpq_dev_free_pooled(zpq_ctx* ctx, void* dptr) {
   if (!dptr) return ZPQ_OK;
   size_t idle = 0;
   bool mine = false;
+  std::unique_lock<std::mutex> g(ctx->pool_mu);
   for (zpq_ctx::PoolBlock& b : ctx->pool) {
     if (b.p == dptr) { b.in_use = false; mine = true; }
     if (!b.in_use) idle += b.cap;
   }
-  if (!mine) return zpq_dev_free(ctx, dptr);          // larger than the pool keeps
+  if (!mine) { g.unlock(); return zpq_dev_free(ctx, dptr); }          // larger than the pool keeps
   while (idle > ((size_t)6 << 30)) {                    // over the limit: the largest idle block goes back to the driver
     size_t big = ctx->pool.size();
     for (size_t i = 0; i < ctx->pool.size(); ++i)

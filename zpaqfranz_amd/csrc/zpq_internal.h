@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct zpq_ctx {
   // device blocks handed back by zpq_dev_free_pooled, kept for the next zpq_dev_alloc_pooled (ctx.hip)
   struct PoolBlock { void* p; size_t cap; bool in_use; };
   std::vector<PoolBlock> pool;
+  std::mutex pool_mu;       // the owner's alloc / free against another context's zpq_device_malloc making room (ctx.hip)
   // optional per-kernel event timing
   bool profiling;
   struct ProfRec { const char* name; hipEvent_t a, b; };
@@ -55,6 +57,9 @@ struct ZpqProfScope {
     hipLaunchKernelGGL(kernel, grid, block, 0, (st), __VA_ARGS__);                 \
   } while (0)
 
+// hipMalloc that makes room before it gives up: on failure the idle pool blocks of THIS context, then of every other live
+// context of the device, go back to the driver and the allocation is tried again (ctx.hip).  hipSuccess or the last error.
+hipError_t zpq_device_malloc(zpq_ctx* ctx, void** p, size_t bytes);
 // Returns a device scratch buffer of at least `bytes` in slot `slot` (grow-only).
 void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes);
 void* zpq_pinned(zpq_ctx* ctx, size_t bytes);

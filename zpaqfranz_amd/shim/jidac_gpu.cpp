@@ -373,14 +373,21 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   // files in name order (the fixture's i blocks are name ordered)
   std::vector<size_t> order(nfiles);
   for (size_t i = 0; i < nfiles; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
   std::vector<uint64_t> ext_sizes;
   if (ext_base) {
-    // device-resident files lie back to back in the order they are processed in: name order
-    for (size_t i = 0; i < nfiles; ++i) if (order[i] != i || ext_off[i + 1] < ext_off[i]) return ZPQ_ERR_ARG;
+    // device-resident files lie back to back in the order they are processed in: STRICTLY ascending names (checked name by
+    // name -- a sort is not stable, equal names would pass or fail by accident: ADVICE round 5), offsets that ascend from 0,
+    // a base the kernels' 16-byte reads can use (ZPQ_ERR_ARG otherwise)
+    if (((uintptr_t)ext_base & 15) != 0) return ZPQ_ERR_ARG;
+    for (size_t i = 0; i < nfiles; ++i) {
+      if (!names[i] || ext_off[i + 1] < ext_off[i]) return ZPQ_ERR_ARG;
+      if (i && strcmp(names[i - 1], names[i]) >= 0) return ZPQ_ERR_ARG;
+    }
     ext_sizes.resize(nfiles);
     for (size_t i = 0; i < nfiles; ++i) ext_sizes[i] = ext_off[i + 1] - ext_off[i];
     sizes = ext_sizes.data();
+  } else {
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
   }
   // 1. contiguous file ranges of about equal bytes, one per context; fragment + hash per range (one host thread each)
   std::vector<Shard> sh(nctx);
