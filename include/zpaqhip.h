@@ -44,7 +44,10 @@ typedef enum zpq_status {
   ZPQ_ERR_METHOD = -5,      /* method string outside the family this engine implements */
   ZPQ_ERR_FORMAT = -6,      /* malformed ZPAQ block on the decode side */
   ZPQ_ERR_CHECKSUM = -7,    /* stored SHA-1 does not match the decoded data */
-  ZPQ_ERR_NOMEM = -8        /* device or host allocation failed */
+  ZPQ_ERR_NOMEM = -8,       /* device or host allocation failed */
+  ZPQ_ERR_LIMIT = -9        /* a ZPAQL program of the block (HCOMP / PCOMP) used up the engine's loop budget: a hard refusal of a
+                             * block that may be valid -- the reference's interpreter has no limit (ZSFX/libzpaq.cpp:1033-1254);
+                             * 2^24 backward jumps per byte + 2^28 once per block (HCOMP), 2^22 + 64 per byte (PCOMP) */
 } zpq_status;
 
 typedef struct zpq_ctx zpq_ctx;

@@ -125,11 +125,60 @@ def test_hcomp_jump_into_an_instruction_and_loops(eng):
 
 
 def test_hcomp_endless_loop_is_stopped(eng):
-    """jmp to itself: the reference would spin forever; the generated code counts backward jumps and reports a
-    format error instead of hanging the GPU."""
+    """jmp to itself: the reference would spin forever; the generated code counts backward jumps (2^24 free per byte + the
+    block's one credit of 2^28) and refuses the block with ZPQ_ERR_LIMIT -- within seconds -- instead of hanging the GPU."""
+    import time
     h = _raw_header(2, 4, [(2, 16, 255)], [63, 254])
+    t0 = time.time()
     (st, _), = eng.cm_code([h], [b"\0abcdef"], [256], encode=True)
-    assert st == -6
+    assert st == -9 and (time.time() - t0 < 10 or os.environ.get("ZPQ_TEST_EMU"))
+    # ... and the interpreter-driven kernel refuses it too (2^30 interpreted instructions; it used to end the call as if halted)
+    if not os.environ.get("ZPQ_TEST_EMU"):
+        os.environ["ZPQ_CM_GENERIC"] = "1"
+        try:
+            (st, _), = eng.cm_code([h], [b"\0a"], [256], encode=True)
+        finally:
+            del os.environ["ZPQ_CM_GENERIC"]
+        assert st == -9
+
+
+INIT_LOOP_CFG = """comp 1 0 0 0 1
+  0 icm 8
+hcomp
+  c=a a=r 0 a== 0 if
+    b=0 do
+      a=0 do a++ a== 250 until
+      b++ a=b a== 20
+    until
+    a= 1 r=a 0
+  endif
+  a=c a<<= 9 *d=a
+  halt
+post
+  0
+end
+"""
+
+
+def test_a_long_initialisation_loop_draws_on_the_blocks_credit(eng, monkeypatch):
+    """VERDICT round 5, item 5 / ADVICE: a VALID HCOMP program may loop longer in one call than the per-byte limit of the generated
+    code (one that initialises H or M on its first byte).  Such a call draws on a credit the block has once; with small limits
+    (100 free backward jumps per byte, a credit of 6000) the 5020 jumps of this program's first call are coded exactly as the
+    reference Predictor + ZPAQL interpreter code them, both directions; with a credit of 1000 the block is refused as
+    ZPQ_ERR_LIMIT, not as malformed."""
+    data = [b"\0" + datagen.text_like(1500, 71), b"\0" + datagen.binary_like(900, 72)]
+    caps = [len(d) * 2 + 64 for d in data]
+    h = orc.ref_compile(INIT_LOOP_CFG, [0] * 9)[0]
+    want = [orc.ref_cm_encode(h, d) for d in data]
+    assert eng.cm_code([h] * 2, data, caps, encode=True) == [(0, w) for w in want]          # (5020 < 2^24: no credit needed)
+    monkeypatch.setenv("ZPQ_JIT_NOCACHE", "1")
+    monkeypatch.setenv("ZPQ_JIT_HCOMP_GUARD", "100")
+    monkeypatch.setenv("ZPQ_JIT_HCOMP_CREDIT", "6000")
+    got = eng.cm_code([h] * 2, data, caps, encode=True)
+    assert got == [(0, w) for w in want]
+    assert eng.cm_code([h] * 2, want, [len(d) + 16 for d in data], encode=False) == [(0, d) for d in data]
+    monkeypatch.setenv("ZPQ_JIT_HCOMP_CREDIT", "1000")
+    assert [st for st, _ in eng.cm_code([h] * 2, data, caps, encode=True)] == [-9, -9]
 
 
 def _fixture_dblock():

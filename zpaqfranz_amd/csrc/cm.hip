@@ -143,7 +143,10 @@ __device__ void vm_body(Vm& z, u32 input, ProgPtr P, HPtr H) {
   u32 out_len = z.out_len; const u32 out_cap = z.out_cap; u8* const outp = z.out;
   int err = 0;
   u32 pc = 0, a = input, b = z.b, c = z.c, d = z.d, f = z.f;
-  for (int guard = 0; guard < (1 << 30); ++guard) {
+  // (2^30 interpreted instructions per call: a program that is still running then is refused -- err = 2, ZPQ_ERR_LIMIT -- where
+  //  the reference would go on, ZSFX/libzpaq.cpp:1033-1254 has no limit; until round 6 the call simply ended as if it had halted)
+  for (int guard = 0;; ++guard) {
+    if (guard >= (1 << 30)) { err = 2; break; }
     // The machine runs on one lane (or on lanes in identical states): telling the compiler that the
     // opcode, the program counter and the flag are wave-uniform turns the dispatch below into scalar
     // branches instead of a tree of exec-mask splits.
@@ -204,7 +207,7 @@ __device__ void vm_body(Vm& z, u32 input, ProgPtr P, HPtr H) {
     if (err) break;
   }
   z.a = a; z.b = b; z.c = c; z.d = d; z.f = f; z.out_len = out_len;
-  if (err) z.err = 1;
+  if (err) z.err = err;
 }
 
 // The wave coder keeps the HCOMP program and a small H[] in LDS: give those the ds_* path (a flat access
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void cm_code_kernel(CmJobDev* jobs, int encode)
     }
     if (bad) status = ZPQ_ERR_FORMAT;
   }
-  if (J.vm.err) status = ZPQ_ERR_FORMAT;
+  if (J.vm.err) status = J.vm.err == 2 ? ZPQ_ERR_LIMIT : ZPQ_ERR_FORMAT;
   J.result[0] = op;
   J.result[1] = (u32)status;
 }
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(64) void cm_wave_kernel(CmJobDev* jobs, int encode)
     }
     if (bad) status = ZPQ_ERR_FORMAT;
   }
-  if (pr.vmerr) status = ZPQ_ERR_FORMAT;
+  if (pr.vmerr) status = pr.vmerr == 2 ? ZPQ_ERR_LIMIT : ZPQ_ERR_FORMAT;
   if (lane == 0) {
     J.result[0] = op; J.result[1] = (u32)status;
 #ifdef ZPQ_CM_PROFILE
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(64) void pcomp_run_kernel(Vm* vms, const u8* in, u3
     if (seg) seg[nseg + s] = z.out_len;
   }
   result[0] = z.out_len;
-  result[1] = z.err ? (u32)ZPQ_ERR_FORMAT : (z.out_len > z.out_cap ? (u32)ZPQ_ERR_CAPACITY : 0u);
+  result[1] = z.err == 2 ? (u32)ZPQ_ERR_LIMIT : z.err ? (u32)ZPQ_ERR_FORMAT : (z.out_len > z.out_cap ? (u32)ZPQ_ERR_CAPACITY : 0u);
 }
 
 typedef zpq_cm_header ParsedHeader;

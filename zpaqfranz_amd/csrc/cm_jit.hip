@@ -44,7 +44,7 @@ std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pc
     if (target >= n) return "goto Lerr;";
     work.push_back(target);
     // a loop needs a jump to a lower (or the same) address: those are counted, so that no program spins forever
-    if (target <= from) return "{ if (++guard > ZGUARD) goto Lerr; goto L" + itos(target) + "; }";
+    if (target <= from) return "{ if (++guard > zlim) goto Llim; goto L" + itos(target) + "; }";
     return "goto L" + itos(target) + ";";
   };
   while (!work.empty()) {
@@ -125,11 +125,19 @@ std::string gen_zpaql(const std::vector<u8>& code, const char* fname, bool is_pc
   }
   std::string out = std::string("ZDEV void ") + fname + "(const u32 input, ZVm& z, g_u8* const M, g_u32* const R, const zh_ptr H" +
                     (is_pcomp ? ", g_u8* const zout, const u32 zcap, u32& zop" : "") + ") {\n";
-  // backward jumps are counted: HCOMP per call (one byte), a post-processor over the whole segment (z.g, limit z.lim)
+  // Backward jumps are counted so that no program spins forever (the reference's ZPAQL::run0 has no limit at all,
+  // ZSFX/libzpaq.cpp:1033-1254): a post-processor over the whole segment (z.g, limit z.lim); HCOMP per call (one byte) with
+  // ZGUARD jumps free per call and, beyond those, a CREDIT for the whole block (z.credit, ZCREDIT at the start) -- a valid
+  // program that initialises H or M in a long loop on its first byte draws on the credit once and is coded; a program that
+  // never ends has used both up after ZGUARD + ZCREDIT jumps (about two seconds of one lane) and the block is refused with
+  // err = 2 (ZPQ_ERR_LIMIT), not mistaken for a malformed one (err = 1, ZPQ_ERR_FORMAT).
   out += std::string("  u32 a = input, b = z.b, c = z.c, d = z.d, f = z.f, t = 0, guard = ") + (is_pcomp ? "z.g" : "0") + "; (void)t; (void)guard;\n";
+  out += is_pcomp ? "  const u32 zlim = ZGUARD; (void)zlim;\n" : "  const u32 zlim = (u32)(ZGUARD) + z.credit; (void)zlim;\n";
   out += n ? "  goto L0;\n" : "  goto Lerr;\n";
   for (auto& kv : stmt) out += "L" + itos(kv.first) + ": " + kv.second + "\n";
-  out += std::string("Lerr: z.err = 1;\nLend: z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;") + (is_pcomp ? " z.g = guard;" : "") + "\n}\n";
+  out += "Llim: z.err = 2; goto Lend;\nLerr: z.err = 1;\n";
+  out += std::string("Lend: z.a = a; z.b = b; z.c = c; z.d = d; z.f = f;") +
+         (is_pcomp ? " z.g = guard;" : " if (guard > (u32)(ZGUARD)) { const u32 used_ = guard - (u32)(ZGUARD); z.credit = used_ > z.credit ? 0u : z.credit - used_; }") + "\n}\n";
   return out;
 }
 
@@ -302,7 +310,15 @@ int zpq_cm_spec_source(const zpq_cm_header& P, std::string* src, std::string* wh
   std::string s;
   s += "#define ZN " + itos(P.n) + "\n#define ZW " + itos(waves) + "\n";
   s += "#define ZH_LDS " + itos(h_lds ? 1 : 0) + "\n#define ZHMASK " + itos((1u << P.hh) - 1) + "u\n#define ZMMASK " + itos((1u << P.hm) - 1) + "u\n";
-  s += "#define ZGUARD (1u << 24)\n";        // backward jumps HCOMP may take per byte (a program that initialises H or M in a loop on its first byte must pass)
+  {
+    // backward jumps HCOMP may take per byte for free, and the block's one credit beyond them (gen_zpaql).  The environment
+    // variables are for the tests (small limits reach both ends in milliseconds); they are part of the source text, hence of the
+    // cache key.
+    unsigned guard = 1u << 24, credit = 1u << 28;
+    if (const char* e = getenv("ZPQ_JIT_HCOMP_GUARD")) { const long v = atol(e); if (v >= 1 && v <= (1l << 28)) guard = (unsigned)v; }
+    if (const char* e = getenv("ZPQ_JIT_HCOMP_CREDIT")) { const long v = atol(e); if (v >= 0 && v <= (1l << 30)) credit = (unsigned)v; }
+    s += "#define ZGUARD " + itos(guard) + "u\n#define ZCREDIT " + itos(credit) + "u\n";
+  }
 
   if (getenv("ZPQ_CM_PROGRESS")) s += "#define ZPROGRESS 1\n";
   static const char* names[10] = {"", "CONS", "CM", "ICM", "MATCH", "AVG", "MIX2", "MIX", "ISSE", "SSE"};
@@ -445,7 +461,7 @@ typedef unsigned char u8; typedef unsigned short u16; typedef unsigned int u32; 
 typedef ZGA u32 g_u32; typedef ZGA u8 g_u8;
 typedef g_u32* zh_ptr;
 #define ZDEV __device__ inline __attribute__((always_inline))
-struct ZVm { u32 a, b, c, d, f, err, g, lim; };
+struct ZVm { u32 a, b, c, d, f, err, g, lim; };      // err: 1 = malformed program, 2 = loop budget used up
 //@@PCOMP@@
 // seg (null: one segment of n bytes): u32[nseg] input bytes per segment of the block, then u32[nseg] (result) the output end
 // of each -- the machine keeps its state from segment to segment and sees 2^32-1 at the end of each (PostProcessor::write)
@@ -466,7 +482,7 @@ extern "C" __global__ __launch_bounds__(64) void pcomp_spec(const u8* in, u32 n,
     if (seg) seg[nseg + s] = op;
   }
   result[0] = op;
-  result[1] = z.err ? (u32)-6 : (op > cap ? (u32)-4 : 0u);
+  result[1] = z.err == 2 ? (u32)-9 : z.err ? (u32)-6 : (op > cap ? (u32)-4 : 0u);
 }
 )ZPQSRC";
 

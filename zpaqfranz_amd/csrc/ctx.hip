@@ -204,6 +204,7 @@ const char* zpq_strerror(int status) {
     case ZPQ_ERR_FORMAT: return "malformed ZPAQ block";
     case ZPQ_ERR_CHECKSUM: return "SHA-1 mismatch";
     case ZPQ_ERR_NOMEM: return "out of memory";
+    case ZPQ_ERR_LIMIT: return "a ZPAQL program of the block used up the engine's loop budget";
     default: return "unknown status";
   }
 }
