@@ -96,11 +96,13 @@ class CollectiveOrder:
     hence identical on every rank, and one that lets step k exchange its tables before step k-1 has finished
     compressing.  A section holds the turn until its transfers have completed."""
 
-    def __init__(self, steps, depth):
+    def __init__(self, steps, depth, sections=3):
         import threading
         self.seq = []
+        # (sections > 3: the product's zpqj_add_sharded_dev has two late sections -- the sizes of the compressed blocks as a host
+        #  string, then the blocks themselves through the device form of the collective)
         for k in range(steps + depth):
-            for st, sec in ((k, 0), (k, 1), (k - (depth - 1), 2)):
+            for st, sec in [(k, 0), (k, 1)] + [(k - (depth - 1), q) for q in range(2, sections)]:
                 if 0 <= st < steps:
                     self.seq.append((st, sec))
         self.head = 0
@@ -268,13 +270,44 @@ class Pipeline:
         return int(n)
 
     def drop_archive(self):
+        if getattr(self, "sharded", False):
+            self.archive = None
+            return
         if getattr(self, "archive_ptr", None):
             self.archive = None
             self.E.load_shim().zpqj_free(C.c_void_p(self.archive_ptr))
             self.archive_ptr = None
 
+    def use_sharded_product(self, names, sizes, gather, gather_dev):
+        """Several ranks: the timed step becomes ONE C-ABI call per rank, zpqj_add_sharded_dev -- this rank's files resident in HBM in,
+        the whole job's archive out on every rank -- with the in-tree RCCL collectives (shim/rccl_gather.cpp) inside it: no torch
+        collective in the timed region.  names / sizes: every file of the job, the same lists on every rank."""
+        self.all_names, self.all_sizes, self.gather, self.gather_dev = names, sizes, gather, gather_dev
+        self.sharded = True
+
+    SECTIONS = 4          # collectives of one zpqj_add_sharded_dev: fragment tables, seam fragments, block sizes, blocks (device form)
+
+    def step_sharded(self, order, idx, keep=True):
+        E = self.E
+
+        def wrap(k, thunk):           # every collective of the call takes its turn in the one order all ranks share
+            order.enter(idx, k)
+            try:
+                return thunk()
+            finally:
+                order.leave()
+        arc, st = E.jidac_add_sharded_dev(self.eng, self.rank, self.world, self.gather, self.gather_dev, None, self.all_names, self.all_sizes,
+                                          self.data.data_ptr(), self.VERSION_DATE, "14", twins=self.use_twins,
+                                          wrap=None if isinstance(order, _NoOrder) else wrap)
+        self.archive = arc if keep else None
+        self.stats = dict(fragments=st["fragments"], unique_fragments=st["new_fragments"], blocks=st["d_blocks"], unique_bytes=st["unique_bytes"],
+                          out_bytes=len(arc), d_bytes=st["d_bytes"])
+        return len(arc)
+
     def step(self, order=None, idx=0, keep=True):
         """keep: hold on to the block inputs / outputs of this step for the verification (costs their memory until the next step)"""
+        if getattr(self, "sharded", False):
+            return self.step_sharded(order or _NoOrder(), idx, keep)
         if getattr(self, "product", False):
             return self.step_product(keep)
         self.keep_outputs = keep
@@ -1429,6 +1462,23 @@ def main():
     # (config 4's archive is 5.7 GB: returned to host memory it turns the step into a PCIe / host-copy measurement, so its timed step stays
     #  the call-by-call one with the d blocks left in HBM; ONE product call is made and verified after the timed region: `product_one_call`)
     product = (a.workload == "silesia_x256_m1" or (a.workload == "dup8_m1" and a.product)) and world == 1 and not a.force_collectives and not a.python_pipeline
+    # several ranks (or --force-collectives): ONE call of the product per rank and step as well -- zpqj_add_sharded_dev, with the
+    # in-tree RCCL collectives inside it (gloo runs, tests only, hand it functional stand-ins over torch.distributed)
+    sharded_product = a.workload == "silesia_x256_m1" and multi and not a.python_pipeline
+    shard_names = shard_sizes = shard_gather = None
+    if sharded_product:
+        # every file of the job, in the order the ranks hold them (rank r: copies [r C, (r + 1) C) of its corpus); names ascend
+        cps = layout["copies"]
+        # (one corpus over the ranks: the names one GPU would use for the whole of it -- the archive is then the single-GPU archive)
+        shard_names = [("c%04d/%s" % (r_ * cps + c_, n_)) if shared else ("r%02d/c%04d/%s" % (r_, c_, n_))
+                       for r_ in range(world) for c_ in range(cps) for n_ in layout["names"]]
+        shard_sizes = [int(z_) for _ in range(world) for _ in range(cps) for z_ in layout["sizes"]]
+        assert shard_names == sorted(shard_names), "the corpus members must be held in name order"
+        if a.dist_backend != "gloo":
+            from zpaqfranz_amd import engine as E_
+            uid = [E_.RcclGather.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            shard_gather = E_.RcclGather(eng, rank, world, uid[0])      # ONE communicator per rank (its collectives take turns: CollectiveOrder)
 
     def add_pipe(e_):
         p_ = Pipeline(e_, dev, layout, rank, world, a.force_collectives)
@@ -1436,6 +1486,12 @@ def main():
         p_.use_twins = a.twins
         p_.balance_blocks = shared and world > 1      # one corpus over several ranks: the d blocks are dealt out, not left to rank 0
         p_.product = product
+        if sharded_product:
+            from zpaqfranz_amd import engine as E_
+            if shard_gather is not None:
+                p_.use_sharded_product(shard_names, shard_sizes, shard_gather, None)
+            else:
+                p_.use_sharded_product(shard_names, shard_sizes, E_.dist_allgather_bytes(), E_.dist_allgather_dev(e_))
         pipes.append(p_)
         return p_
     add_pipe(eng)
@@ -1486,7 +1542,7 @@ def main():
         import threading
         nxt, lock, outs, errs, done = [0], threading.Lock(), [0] * n, [], [0.0] * n
 
-        order = CollectiveOrder(n, depth) if (world > 1 or a.force_collectives) else _NoOrder()
+        order = CollectiveOrder(n, depth, Pipeline.SECTIONS if sharded_product else 3) if (world > 1 or a.force_collectives) else _NoOrder()
 
         def worker(p_, delay):
             try:
@@ -1693,7 +1749,11 @@ def main():
                           **({"corpus": "one Silesia x%d split by file range over %d ranks" % (a.copies, world)} if shared else {}),
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
-               "timed_step": ("one C-ABI call: zpqj_extract_dev (whole journaling archive resident in HBM in -- the call reads the index itself --, restored "
+               "timed_step": ("one C-ABI call per rank: zpqj_add_sharded_dev (this rank's files resident in HBM in, the whole job's archive out on every rank) with "
+                              "the in-tree RCCL collectives inside it (zpqr_allgatherv / zpqr_allgatherv_dev: no torch collective in the timed region)"
+                              if sharded_product and a.dist_backend != "gloo" else
+                              "one C-ABI call per rank: zpqj_add_sharded_dev over functional stand-in collectives (gloo: test only)" if sharded_product else
+                              "one C-ABI call: zpqj_extract_dev (whole journaling archive resident in HBM in -- the call reads the index itself --, restored "
                               "files and their SHA-256 left in HBM) + the digest compare" if (extract and getattr(pipe, "product", False)) else
                               "one C-ABI call: zpqj_add_dev (files resident in HBM in, whole journaling archive -- c, d, h, i blocks -- out to host memory)"
                               if product else "call-by-call orchestration in bench.py (d blocks only)"),
@@ -1825,7 +1885,11 @@ def main():
                 res["cpu_baseline"] = cpu_baseline("extract", [], [blocks_blob, json.dumps(index).encode()])
         print(json.dumps(res))
     if a.dump_archive and rank == 0 and a.workload != "extract_m1":
-        if world > 1:
+        if sharded_product:
+            # the d blocks of the archive every rank got back (between its c block and its first h block)
+            blks = split_archive(pipe.archive, payloads="")
+            parts = [bytes(pipe.archive[b_[2]:b_[3]]) for b_ in blks if b_[0][17:18] == b"d"]
+        elif world > 1:
             parts = [bytes(g.cpu().numpy()) for g in pipe.gathered]
         else:
             parts = [b for _, b in pipe.framed_blocks()]

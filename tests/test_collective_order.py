@@ -34,3 +34,12 @@ def test_every_section_gets_its_turn_in_the_fixed_order(steps, depth):
     for t in th: t.join(20)
     assert not any(t.is_alive() for t in th), "deadlock"
     assert log == o.seq
+
+
+def test_four_sections_per_step_for_the_product_call():
+    """zpqj_add_sharded_dev has two late collectives per add (block sizes as a host string, the blocks through the device form)"""
+    from bench import CollectiveOrder
+    o = CollectiveOrder(5, 3, 4)
+    assert sorted(o.seq) == [(s, k) for s in range(5) for k in range(4)]
+    assert all(o.seq.index((s, 0)) < o.seq.index((s, 1)) < o.seq.index((s, 2)) < o.seq.index((s, 3)) for s in range(5))
+    assert o.seq.index((1, 0)) < o.seq.index((0, 2))          # the next step's tables go out before this one's blocks

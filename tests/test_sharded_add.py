@@ -181,3 +181,83 @@ def test_sharded_add_over_the_in_tree_rccl_collective_world_size_1():
     finally:
         g.close()
         eng.close()
+
+
+def _add_dev_worker(rank, world, port, q, method, flags, with_dev):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zpaqfranz_amd import engine
+    files = sorted(_corpus(), key=lambda f: f[0].encode())
+    names, sizes = [f[0] for f in files], [len(f[1]) for f in files]
+    mine = engine.jidac_shard_files(names, sizes, world, rank)
+    eng = engine.Engine(0)
+    buf = eng.upload(b"".join(b for (n, b), m in zip(files, mine) if m))       # this rank's range, back to back in name order
+    sections = []
+
+    def wrap(k, thunk):                  # (what bench.py orders the collectives of its adds in flight with)
+        sections.append(k)
+        return thunk()
+    arc, st = engine.jidac_add_sharded_dev(eng, rank, world, engine.dist_allgather_bytes(), engine.dist_allgather_dev(eng) if with_dev else None,
+                                           None, names, sizes, buf.ptr, 20260925120000, method, wrap=wrap, **flags)
+    q.put((rank, arc, st, sections))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_dev", [True, False])
+def test_two_processes_with_files_resident_in_hbm_write_the_single_gpu_archive(with_dev):
+    """zpqj_add_sharded_dev: every rank's files already in HBM; with_dev: the compressed d blocks travel through the DEVICE form of
+    the collective (HBM pointers in, HBM pointers out) and only their sizes through the host form."""
+    from zpaqfranz_amd import engine
+    files = sorted(_corpus(), key=lambda f: f[0].encode())
+    eng = engine.Engine(0)
+    flags = {"checksums": True}
+    want, wst = engine.jidac_add(eng, None, files, 20260925120000, "14", **flags)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_add_dev_worker, args=(r, 2, port, q, "14", flags, with_dev)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+    for r in range(2):
+        arc, st, sections = res[r]
+        assert arc == want and st == wst, r
+        assert sections == list(range(4 if with_dev else 3)), sections         # tables, seam fragments, sizes + blocks | blocks
+    assert engine.jidac_extract(eng, want) == dict(files)
+
+
+@pytest.mark.gpu
+def test_sharded_dev_add_over_the_in_tree_rccl_collectives_world_size_1():
+    """zpqj_add_sharded_dev with zpqr_allgatherv + zpqr_allgatherv_dev (RCCL, HBM -> HBM) as its collectives, one rank: the plain
+    add's archive; the device collective returns what was sent."""
+    if os.environ.get("ZPQ_TEST_EMU") == "1":
+        pytest.skip("RCCL needs the device")
+    from zpaqfranz_amd import engine
+    files = sorted(_corpus(nfiles=9), key=lambda f: f[0].encode())
+    names, sizes = [f[0] for f in files], [len(f[1]) for f in files]
+    eng = engine.Engine(0)
+    g = engine.RcclGather(eng, 0, 1, engine.RcclGather.unique_id())
+    buf = eng.upload(b"".join(b for _, b in files))
+    try:
+        payload = bytes(range(256)) * 999 + b"tail"
+        d = eng.upload(payload)
+        (ptr, n), = g.gather_dev(d.ptr, len(payload))
+        import ctypes as C
+        out = C.create_string_buffer(n)
+        assert eng.L.zpq_d2h(eng.ctx, out, C.c_void_p(ptr), n) == 0 and out.raw == payload
+        assert g.gather_dev(0, 0) == [(0, 0)]
+        want, wst = engine.jidac_add(eng, None, files, 20260925120000, "14", checksums=True)
+        for wrap in (None, lambda k, thunk: thunk()):            # the C functions handed over directly / through the ordering hook
+            arc, st = engine.jidac_add_sharded_dev(eng, 0, 1, g, None, None, names, sizes, buf.ptr, 20260925120000, "14", checksums=True, wrap=wrap)
+            assert arc == want and st == wst
+    finally:
+        g.close()
+        eng.close()

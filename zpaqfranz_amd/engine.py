@@ -599,6 +599,9 @@ def load_shim():
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_shard_files.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        S.zpqj_add_sharded_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLGATHERV, ALLGATHERV, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_size_t), C.c_void_p]
         S.zpqj_add_dev.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64,
                                    C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         _shim = S
@@ -631,6 +634,33 @@ def dist_allgather_bytes(group=None):
     return f
 
 
+def dist_allgather_dev(eng, group=None):
+    """The device-memory form of dist_allgather_bytes for jidac_add_sharded_dev over any torch.distributed backend: f(device
+    pointer, length) -> [(device pointer, length) of every rank].  A functional stand-in (D2H, all-gather, H2D) for tests over gloo;
+    the product's device collective is RcclGather (shim/rccl_gather.cpp: zpqr_allgatherv_dev, HBM -> xGMI -> HBM)."""
+    ag = dist_allgather_bytes(group)
+    held = []
+
+    def f(d_ptr, n):
+        mine = b""
+        if n:
+            buf = C.create_string_buffer(n)
+            eng._ck(eng.L.zpq_d2h(eng.ctx, buf, C.c_void_p(d_ptr), n))
+            mine = buf.raw
+        got = ag(mine)
+        for d in held:
+            d.free()
+        del held[:]
+        out = []
+        for g in got:
+            if g:
+                d = eng.upload(g); held.append(d); out.append((d.ptr, len(g)))
+            else:
+                out.append((0, 0))
+        return out
+    return f
+
+
 class RcclGather:
     """The in-tree collective for jidac_add_sharded (shim/rccl_gather.cpp: rccl.h, no torch): an all-gather of byte strings over
     RCCL on the engine's own stream.  `uid`: the 128 bytes RcclGather.unique_id() returned on rank 0, handed to every rank by
@@ -646,6 +676,7 @@ class RcclGather:
         R.zpqr_unique_id.argtypes = [C.c_char_p]
         R.zpqr_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
         R.zpqr_allgatherv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        R.zpqr_allgatherv_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         R.zpqr_last_error.argtypes = [C.c_void_p]
         R.zpqr_last_error.restype = C.c_char_p
         R.zpqr_destroy.argtypes = [C.c_void_p]
@@ -668,6 +699,16 @@ class RcclGather:
         if rc != 0:
             raise ZpqError(rc, "zpqr_create (rank %d of %d)" % (rank, world))
         self.fn = C.cast(self.R.zpqr_allgatherv, ALLGATHERV)      # the C function itself goes to zpqj_add_sharded: no Python in between
+        self.fn_dev = C.cast(self.R.zpqr_allgatherv_dev, ALLGATHERV)   # ... and its device-memory form (same signature, HBM pointers)
+
+    def gather_dev(self, d_send, n):
+        """zpqr_allgatherv_dev from Python: device pointer + length -> [(device pointer, length) of every rank]"""
+        recv = (C.c_void_p * self.world)()
+        rlen = (C.c_size_t * self.world)()
+        rc = self.R.zpqr_allgatherv_dev(self.comm, C.c_void_p(d_send), n, recv, rlen)
+        if rc != 0:
+            raise ZpqError(rc, "zpqr_allgatherv_dev: " + self.R.zpqr_last_error(self.comm).decode())
+        return [(recv[r] or 0, rlen[r]) for r in range(self.world)]
 
     def __call__(self, b):
         """the same collective from Python: bytes -> [bytes of every rank]"""
@@ -731,6 +772,74 @@ def jidac_add_sharded(eng, rank, world, allgather, archive, files, version_date,
                             bytes(archive) if archive else None, len(archive) if archive else 0,
                             names, datas, sizes, dts, n, version_date, method.encode(), (1 if checksums else 0) | (2 if hint else 0),
                             C.byref(out), C.byref(out_len), stats)
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise ZpqError(rc, "%s (%s)" % (eng.L.zpq_strerror(rc).decode(), eng.L.zpq_last_error(eng.ctx).decode()))
+    data = C.string_at(out.value, out_len.value)
+    S.zpqj_free(out)
+    keys = ("fragments", "new_fragments", "d_blocks", "unique_bytes", "d_bytes", "bytes_written")
+    return data, dict(zip(keys, [int(x) for x in stats]))
+
+
+def jidac_add_sharded_dev(eng, rank, world, allgather, allgather_dev, archive, names, sizes, d_base, version_date, method="14", dates=None,
+                          checksums=False, hint=False, twins=True, wrap=None):
+    """zpqj_add_sharded_dev: one PROCESS per GPU, this rank's files (jidac_shard_files) already in HBM back to back at d_base.
+    names / sizes: ALL files of the batch (names ascending), the same on every rank.  allgather: f(bytes) -> [bytes of every
+    rank], or an RcclGather (then the C collectives are called directly: no Python between the engine and RCCL);
+    allgather_dev: None, or f(device pointer, length) -> [(device pointer, length) of every rank] (ignored with an RcclGather:
+    its own device form is used).  wrap: optional f(section, thunk) -> thunk(): every collective of the call goes through it
+    (bench.py keeps several adds in flight and orders their collectives with it).  Every rank returns (archive bytes, stats)."""
+    S = load_shim()
+    n = len(names)
+    c_names = (C.c_char_p * max(1, n))(*[x.encode() for x in names])
+    c_sizes = (C.c_uint64 * max(1, n))(*sizes)
+    dts = (C.c_int64 * max(1, n))(*(dates or [version_date] * n))
+    out, out_len = C.c_void_p(), C.c_size_t(0)
+    stats = (C.c_uint64 * 6)()
+    held, err, sec = [], [], [0]
+    native = isinstance(allgather, RcclGather)
+
+    def run(thunk):
+        k = sec[0]; sec[0] += 1
+        return wrap(k, thunk) if wrap else thunk()
+
+    def cb(user, send, send_len, recv, recv_len):
+        try:
+            if native:
+                return run(lambda: allgather.R.zpqr_allgatherv(allgather.comm, send, send_len, recv, recv_len))
+            got = run(lambda: allgather(C.string_at(send, send_len) if send_len else b""))
+            del held[:]
+            for r in range(world):
+                buf = C.create_string_buffer(got[r], max(1, len(got[r])))
+                held.append(buf)
+                recv[r] = C.cast(buf, C.c_void_p).value
+                recv_len[r] = len(got[r])
+            return 0
+        except Exception as e:          # an exception cannot cross the C frames: report it after the call
+            err.append(e)
+            return 1
+
+    def cb_dev(user, send, send_len, recv, recv_len):
+        try:
+            if native:
+                return run(lambda: allgather.R.zpqr_allgatherv_dev(allgather.comm, send, send_len, recv, recv_len))
+            got = run(lambda: allgather_dev(send or 0, send_len))
+            for r in range(world):
+                recv[r] = got[r][0] or None
+                recv_len[r] = got[r][1]
+            return 0
+        except Exception as e:
+            err.append(e)
+            return 1
+    direct = native and wrap is None          # nothing to order: the C functions themselves
+    fn = allgather.fn if direct else ALLGATHERV(cb)
+    fn_dev = allgather.fn_dev if direct else (ALLGATHERV(cb_dev) if (native or allgather_dev is not None) else C.cast(None, ALLGATHERV))
+    flags = (1 if checksums else 0) | (2 if hint else 0) | (0 if twins else 4)
+    rc = S.zpqj_add_sharded_dev(eng.ctx, rank, world, fn, fn_dev, allgather.comm if direct else None,
+                                bytes(archive) if archive else None, len(archive) if archive else 0,
+                                c_names, C.c_void_p(d_base), c_sizes, dts, n, version_date, method.encode(), flags,
+                                C.byref(out), C.byref(out_len), stats)
     if err:
         raise err[0]
     if rc != 0:

@@ -285,8 +285,12 @@ int shard_fragment(Shard& S, const uint8_t* const* datas, const uint64_t* sizes,
   zpq_ctx* ctx = S.ctx;
   const size_t nfiles = S.f1 - S.f0;
   int rc;
-  if (ext_base) {
+  if (ext_base && ext_off) {
     S.off.assign(ext_off + S.f0, ext_off + S.f1 + 1);
+    S.d_data = (void*)ext_base;
+  } else if (ext_base) {          // (zpqj_add_sharded_dev: this rank's range lies back to back at ext_base, sizes come from the caller)
+    S.off.assign(nfiles + 1, 0);
+    for (size_t k = 0; k < nfiles; ++k) S.off[k + 1] = S.off[k] + sizes[order[S.f0 + k]];
     S.d_data = (void*)ext_base;
   } else {
     S.off.assign(nfiles + 1, 0);
@@ -342,7 +346,7 @@ void shard_plan(const std::vector<size_t>& order, const uint64_t* sizes, size_t 
 // Process-sharded runs: the ranges of the plan above live in `world` processes (one GPU each); what the in-process form
 // reads from its neighbours' Shard objects travels through ONE caller-supplied primitive, an all-gather of byte strings
 // (RCCL / MPI / anything): fragment tables, the few fragments a block needs from another rank, the compressed blocks.
-struct Xchg { int rank, world; zpqj_allgatherv_fn fn; void* user; };
+struct Xchg { int rank, world; zpqj_allgatherv_fn fn; void* user; zpqj_allgatherv_dev_fn dev_fn; };
 int xchg_all(const Xchg& X, const Bytes& send, std::vector<Bytes>& got) {
   std::vector<void*> rp(X.world, nullptr); std::vector<size_t> rl(X.world, 0);
   const int rc = X.fn(X.user, send.data(), send.size(), rp.data(), rl.data());
@@ -358,7 +362,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
              const uint8_t* ext_base = nullptr, const uint64_t* ext_off = nullptr) {
   *out = nullptr; *out_len = 0;
   if (nctx == 0 || !ctxs || !ctxs[0]) return ZPQ_ERR_ARG;
-  if (ext_base && (X || nctx != 1 || !ext_off)) return ZPQ_ERR_ARG;
+  if (ext_base && (X ? (ext_off != nullptr || !sizes) : (nctx != 1 || !ext_off))) return ZPQ_ERR_ARG;
   const size_t me = X ? (size_t)X->rank : 0;
   if (X) { if (X->world < 1 || X->rank < 0 || X->rank >= X->world || !X->fn) return ZPQ_ERR_ARG; nctx = (size_t)X->world; }
   const bool checksums = (flags & ZPQJ_FILE_CHECKSUMS) != 0;
@@ -380,12 +384,14 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     // a base the kernels' 16-byte reads can use (ZPQ_ERR_ARG otherwise)
     if (((uintptr_t)ext_base & 15) != 0) return ZPQ_ERR_ARG;
     for (size_t i = 0; i < nfiles; ++i) {
-      if (!names[i] || ext_off[i + 1] < ext_off[i]) return ZPQ_ERR_ARG;
+      if (!names[i] || (ext_off && ext_off[i + 1] < ext_off[i])) return ZPQ_ERR_ARG;
       if (i && strcmp(names[i - 1], names[i]) >= 0) return ZPQ_ERR_ARG;
     }
-    ext_sizes.resize(nfiles);
-    for (size_t i = 0; i < nfiles; ++i) ext_sizes[i] = ext_off[i + 1] - ext_off[i];
-    sizes = ext_sizes.data();
+    if (ext_off) {
+      ext_sizes.resize(nfiles);
+      for (size_t i = 0; i < nfiles; ++i) ext_sizes[i] = ext_off[i + 1] - ext_off[i];
+      sizes = ext_sizes.data();
+    }
   } else {
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return strcmp(names[a], names[b]) < 0; });
   }
@@ -400,7 +406,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     std::vector<std::thread> th;
     const bool no_twins = (flags & ZPQJ_NO_TWINS) != 0;
     if (nctx == 1) sh[0].rc = shard_fragment(sh[0], datas, sizes, order, checksums, ext_base, ext_off, no_twins);      // (no thread for one range)
-    else for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums, nullptr, nullptr, no_twins); });
+    else for (size_t r = 0; r < nctx; ++r) if (!X || r == me) th.emplace_back([&, r] { sh[r].rc = shard_fragment(sh[r], datas, sizes, order, checksums, X ? ext_base : nullptr, nullptr, no_twins); });
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (sh[r].rc) return sh[r].rc;
   }
@@ -518,8 +524,13 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   // compressed too and the archive's layout is known; then they are packed back to back by one gather and come over in ONE
   // copy, straight to their place in the buffer that is returned (no per-block copies, no intermediate strings).
   const bool one = nctx == 1 && !X;
-  struct Packed { zpq_ctx* c = nullptr; void* d_out = nullptr; std::vector<uint64_t> off; std::vector<uint32_t> len;
+  // ... and with a collective that takes DEVICE memory (zpqj_add_sharded_dev) this rank's compressed blocks stay in HBM as well:
+  // they are packed there and go HBM -> RCCL -> HBM; what the host sees of exchange 3 is the table of sizes
+  const bool xdev = X && X->dev_fn;
+  const bool keep_dev = one || xdev;
+  struct Packed { zpq_ctx* c = nullptr; void* d_out = nullptr; std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<size_t> mine;
                   ~Packed() { if (d_out) zpq_dev_free_pooled(c, d_out); } } packed;
+  packed.c = ctxs[0];
   auto compress_owned = [&](size_t r) -> int {
     zpq_ctx* c = X ? ctxs[0] : ctxs[r];
     std::vector<size_t> mine;
@@ -578,7 +589,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     }
     void* d_out;
     if ((rc = zpq_dev_alloc_pooled(c, opos + 64, &d_out))) return rc;
-    if (one) { packed.c = c; packed.d_out = d_out; } else dev.p.push_back(d_out);
+    if (keep_dev) { packed.c = c; packed.d_out = d_out; } else dev.p.push_back(d_out);
     // "method,R,t" per block (zpaq's add(); ZSFX/libzpaq.h:86-135): R from the order-1 hits of its fragments, t from the
     // text / exe votes -- one lane per fragment over the assembled blocks
     std::vector<std::string> mth(mine.size(), std::string(method));
@@ -615,8 +626,8 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     if (nctx == 1) clk.mark("trailers");
     if ((rc = zpq_compress_blocks_dev(c, jobs.data(), jobs.size()))) return rc;
     if (nctx == 1) clk.mark("compressBlock");
-    if (one) {          // (mine = every block, in order)
-      packed.off = ooff; packed.len.resize(mine.size());
+    if (keep_dev) {          // (one context: mine = every block, in order)
+      packed.off = ooff; packed.len.resize(mine.size()); packed.mine = mine;
       for (size_t m = 0; m < mine.size(); ++m) { if (jobs[m].status) return jobs[m].status; packed.len[m] = jobs[m].out_len; }
       return ZPQ_OK;
     }
@@ -633,7 +644,50 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     for (auto& t : th) t.join();
     for (size_t r = 0; r < nctx; ++r) if (brc[r]) return brc[r];
   }
-  if (X) {
+  std::vector<uint32_t> xsize;                      // (device exchange) compressed size of every d block, whoever owns it
+  std::vector<void*> xrecv; std::vector<size_t> xrlen;
+  struct DevFree { zpq_ctx* c; void* p; ~DevFree() { if (p) zpq_dev_free_pooled(c, p); } } xpack{ctxs[0], nullptr};
+  if (xdev) {
+    // exchange 3, device form.  3a (host, a few bytes): which blocks this rank compressed and how long they came out;
+    // 3b (device): the blocks themselves, packed back to back in HBM, HBM -> collective -> HBM; the archive is assembled from the
+    // receive buffers by one copy per run of blocks of the same owner
+    Bytes snd; std::vector<Bytes> got;
+    uint64_t mylen = 0;
+    for (size_t m = 0; m < packed.mine.size(); ++m) { put32(snd, (uint32_t)packed.mine[m]); put32(snd, packed.len[m]); mylen += packed.len[m]; }
+    if ((rc = xchg_all(*X, snd, got))) return rc;
+    xsize.assign(blocks.size(), 0);
+    std::vector<uint64_t> rtotal(nctx, 0);
+    for (size_t r = 0; r < nctx; ++r) {
+      const Bytes& g = r == me ? snd : got[r];
+      if (g.size() % 8) return ZPQ_ERR_FORMAT;
+      uint32_t prev = 0;
+      for (size_t q = 0; q < g.size(); q += 8) {
+        const uint32_t b = get32(&g[q]), n = get32(&g[q + 4]);
+        if (b >= blocks.size() || shard_of[newfrags[blocks[b].first]] != r || xsize[b] || !n || (q && b <= prev)) return ZPQ_ERR_FORMAT;
+        xsize[b] = n; rtotal[r] += n; prev = b;
+      }
+    }
+    for (size_t b = 0; b < blocks.size(); ++b) if (!xsize[b]) return ZPQ_ERR_FORMAT;
+    zpq_ctx* c = ctxs[0];
+    if (mylen) {
+      struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{c, {}};
+      const size_t nm_ = packed.mine.size();
+      std::vector<uint64_t> dso(nm_); uint64_t q = 0;
+      for (size_t m = 0; m < nm_; ++m) { dso[m] = q; q += packed.len[m]; }
+      void *d_so, *d_sl, *d_dso;
+      if ((rc = zpq_dev_alloc_pooled(c, mylen + 64, &xpack.p))) return rc;
+      if ((rc = zpq_dev_alloc_pooled(c, nm_ * 8, &d_so))) return rc; dev.p.push_back(d_so);
+      if ((rc = zpq_dev_alloc_pooled(c, nm_ * 4, &d_sl))) return rc; dev.p.push_back(d_sl);
+      if ((rc = zpq_dev_alloc_pooled(c, nm_ * 8, &d_dso))) return rc; dev.p.push_back(d_dso);
+      if ((rc = zpq_h2d(c, d_so, packed.off.data(), nm_ * 8)) || (rc = zpq_h2d(c, d_sl, packed.len.data(), nm_ * 4)) ||
+          (rc = zpq_h2d(c, d_dso, dso.data(), nm_ * 8))) return rc;
+      if ((rc = zpq_gather_dev(c, (const uint8_t*)packed.d_out, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, nm_, (uint8_t*)xpack.p))) return rc;
+      if ((rc = zpq_sync(c))) return rc;
+    }
+    xrecv.assign(nctx, nullptr); xrlen.assign(nctx, 0);
+    if (X->dev_fn(X->user, xpack.p, (size_t)mylen, xrecv.data(), xrlen.data())) return ZPQ_ERR_ARG;
+    for (size_t r = 0; r < nctx; ++r) if (xrlen[r] != rtotal[r] || (rtotal[r] && !xrecv[r])) return ZPQ_ERR_FORMAT;
+  } else if (X) {
     // exchange 3: the compressed d blocks; afterwards every rank assembles the same archive
     Bytes snd; std::vector<Bytes> got;
     for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == me) {
@@ -657,9 +711,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   std::vector<uint32_t> dsize(blocks.size());
   uint64_t dtotal = 0;
   for (size_t b = 0; b < blocks.size(); ++b) {
-    dsize[b] = one ? packed.len[b] : (uint32_t)dblock[b].size();
+    dsize[b] = one ? packed.len[b] : xdev ? xsize[b] : (uint32_t)dblock[b].size();
     dtotal += dsize[b];
-    if (!one) dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end());
+    if (!keep_dev) dpart.insert(dpart.end(), dblock[b].begin(), dblock[b].end());
   }
   // 4. c block, d blocks, h blocks, i blocks: the index blocks are put together first and compressed by ONE call
   std::vector<HostBlock> hb;
@@ -736,6 +790,17 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
         (rc = zpq_h2d(c, d_dso, dso.data(), blocks.size() * 8))) return rc;
     if ((rc = zpq_gather_dev(c, (const uint8_t*)packed.d_out, (const uint64_t*)d_so, (const uint32_t*)d_sl, (const uint64_t*)d_dso, blocks.size(), (uint8_t*)d_pack))) return rc;
     if ((rc = zpq_d2h(c, ob + at, d_pack, (size_t)dtotal))) return rc;
+  } else if (xdev && dtotal) {
+    // the d blocks, in block order, out of the ranks' receive buffers: one copy per run of blocks with the same owner
+    std::vector<uint64_t> cur(nctx, 0);
+    size_t w = at;
+    for (size_t b = 0; b < blocks.size();) {
+      const size_t r = shard_of[newfrags[blocks[b].first]];
+      uint64_t run = 0; size_t e = b;
+      while (e < blocks.size() && shard_of[newfrags[blocks[e].first]] == r) run += dsize[e++];
+      if ((rc = zpq_d2h(ctxs[0], ob + w, (const uint8_t*)xrecv[r] + cur[r], (size_t)run))) return rc;
+      cur[r] += run; w += (size_t)run; b = e;
+    }
   } else if (dtotal) memcpy(ob + at, dpart.data(), dpart.size());
   at += (size_t)dtotal;
   for (size_t k = 1; k < hout.size(); ++k) { memcpy(ob + at, hout[k].data(), hout[k].size()); at += hout[k].size(); }
@@ -1004,8 +1069,25 @@ int zpqj_add_multi(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, si
 int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allgatherv, void* user, const uint8_t* archive, size_t archive_len,
                      const char* const* names, const uint8_t* const* datas, const uint64_t* sizes, const int64_t* dates, size_t nfiles,
                      int64_t version_date, const char* method, uint32_t flags, uint8_t** out, size_t* out_len, uint64_t stats[6]) {
-  const Xchg X{rank, world, allgatherv, user};
+  const Xchg X{rank, world, allgatherv, user, nullptr};
   return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, datas, sizes, dates, nfiles, version_date, method, out, out_len, stats, flags, &X); });
+}
+
+// zpqj_add_sharded with this rank's files ALREADY IN HBM: `names` (all files of the batch, every rank the same list) ascend
+// strictly, `sizes` holds every file's size, and the files zpqj_shard_files marks for this rank lie back to back in that order at
+// d_base (16-byte aligned, 64 readable bytes behind the last).  allgatherv_dev (may be NULL): the same collective over DEVICE
+// memory -- send and receive buffers in HBM, receive pointers valid until its next call -- used for the one exchange that is
+// large, the compressed d blocks: they then go HBM -> collective -> HBM and only the finished archive crosses PCIe
+// (shim/rccl_gather.h: zpqr_allgatherv_dev).  Every rank returns the bytes zpqj_add returns for the whole batch on one GPU.
+int zpqj_add_sharded_dev(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allgatherv, zpqj_allgatherv_dev_fn allgatherv_dev, void* user,
+                         const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* d_base, const uint64_t* sizes,
+                         const int64_t* dates, size_t nfiles, int64_t version_date, const char* method, uint32_t flags, uint8_t** out,
+                         size_t* out_len, uint64_t stats[6]) {
+  if (!out || !out_len) return ZPQ_ERR_ARG;
+  if (!ctx || !d_base || !sizes || !names || !dates) { *out = nullptr; *out_len = 0; return ZPQ_ERR_ARG; }
+  const Xchg X{rank, world, allgatherv, user, allgatherv_dev};
+  return guarded([&] { return add_impl(&ctx, 1, archive, archive_len, names, nullptr, sizes, dates, nfiles, version_date, method, out, out_len,
+                                       stats, flags, &X, d_base, nullptr); });
 }
 
 // mine[k] = 1 where rank `rank` of `world` must supply datas[k] to zpqj_add_sharded, else 0.

@@ -47,6 +47,17 @@ int zpqj_add_sharded(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allga
                      size_t archive_len, const char* const* names, const uint8_t* const* datas, const uint64_t* sizes,
                      const int64_t* dates, size_t nfiles, int64_t version_date, const char* method, uint32_t flags,
                      uint8_t** out, size_t* out_len, uint64_t stats[6]);
+/* zpqj_add_sharded with this rank's files ALREADY IN HBM (the sharded counterpart of zpqj_add_dev): `names` ascend strictly (strcmp)
+ * and `sizes` holds every file's size -- the same lists on every rank --, the files zpqj_shard_files marks for this rank lie back
+ * to back in that order at d_base (16-byte aligned, 64 readable bytes behind the last file).  allgatherv_dev (may be NULL) is the
+ * same collective over DEVICE memory: d_send / d_recv[r] are HBM pointers (d_recv[r] valid until its next call).  It carries the one
+ * exchange that is large, the compressed d blocks, HBM -> collective -> HBM; the other exchanges (fragment tables, the sizes of
+ * the blocks) stay host strings.  shim/rccl_gather.h has both collectives over RCCL. */
+typedef int (*zpqj_allgatherv_dev_fn)(void* user, const void* d_send, size_t send_len, void** d_recv, size_t* recv_len);
+int zpqj_add_sharded_dev(zpq_ctx* ctx, int rank, int world, zpqj_allgatherv_fn allgatherv, zpqj_allgatherv_dev_fn allgatherv_dev, void* user,
+                         const uint8_t* archive, size_t archive_len, const char* const* names, const uint8_t* d_base, const uint64_t* sizes,
+                         const int64_t* dates, size_t nfiles, int64_t version_date, const char* method, uint32_t flags, uint8_t** out,
+                         size_t* out_len, uint64_t stats[6]);
 int zpqj_shard_files(const char* const* names, const uint64_t* sizes, size_t nfiles, int world, int rank, uint8_t* mine);
 int zpqj_extract(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8_t** data, uint64_t** sizes,
                  char** names, size_t* nfiles);
