@@ -92,17 +92,24 @@ def _exchange(sends, recvs, device):
 class CollectiveOrder:
     """With several steps in flight on several threads, every rank must still issue its collectives in ONE order.
     A step has three collective sections (0: fragment tables, 1: seam fragments, 2: compressed streams); the order is
-    the software-pipeline order  (k,0) (k,1) (k-depth+1, 2)  for k = 0, 1, ...: a fixed function of (steps, depth),
+    the software-pipeline order  (k,0) (k,1) (k-lag, 2)  for k = 0, 1, ...: a fixed function of (steps, depth),
     hence identical on every rank, and one that lets step k exchange its tables before step k-1 has finished
-    compressing.  A section holds the turn until its transfers have completed."""
+    compressing.  A section holds the turn until its transfers have completed.
+    lag: how many later steps' tables go out before a step's streams.  With F = a step's time to its tables, C = its compress time
+    and P the period between steps, the order costs  P >= C / (lag + 1)  (step k+1's tables wait for step k-lag's streams) and
+    P >= F / (depth - lag)  (a worker is free again only after step k-lag's streams, which wait for step k's tables): lag =
+    depth - 1, the choice until round 6, makes the second bound P >= F -- one step per fragment pass, 297 ms measured through the
+    product call (profiles/r06c) -- depth // 2 balances the two (F ~ C under load)."""
 
-    def __init__(self, steps, depth, sections=3):
+    def __init__(self, steps, depth, sections=3, lag=None):
         import threading
         self.seq = []
+        lag = max(1, depth // 2) if lag is None else lag
+        lag = min(lag, max(0, depth - 1))
         # (sections > 3: the product's zpqj_add_sharded_dev has two late sections -- the sizes of the compressed blocks as a host
         #  string, then the blocks themselves through the device form of the collective)
         for k in range(steps + depth):
-            for st, sec in [(k, 0), (k, 1)] + [(k - (depth - 1), q) for q in range(2, sections)]:
+            for st, sec in [(k, 0), (k, 1)] + [(k - lag, q) for q in range(2, sections)]:
                 if 0 <= st < steps:
                     self.seq.append((st, sec))
         self.head = 0

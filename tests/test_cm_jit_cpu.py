@@ -64,7 +64,8 @@ def test_hcomp_translation_follows_jumps_into_operands_and_bounds_loops(L):
     assert "L4: goto Lend;" in body and "L3:" not in body                 # pc 3 (a= 56) is never reached, pc 4 is the halt
     # jmp to itself: a counted backward jump
     src = source(L, raw_header(2, 4, [(2, 16, 255)], [63, 254]))
-    assert "if (++guard > ZGUARD) goto Lerr; goto L0;" in src
+    # (2^24 backward jumps free per byte + the block's credit: gen_zpaql)
+    assert "if (++guard > zlim) goto Llim; goto L0;" in src and "const u32 zlim = (u32)(ZGUARD) + z.credit;" in src
     # running off the end / invalid opcode -> error exit
     src = source(L, raw_header(2, 4, [(2, 16, 255)], [1, 5]))
     assert "L1: goto Lerr;" in src

@@ -34,7 +34,7 @@ def exe_like(n, seed):
 
 
 METHODS = ["34", "34,200,1", "34,170,2", "34,30,0", "x4,2,12,0,7,25,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x4,3ci1", "x4,7ci1",
-           "x4,4ci1,1,1,1,2a", "44,160,2", "x0,3ci1", "x6,3ci1",
+           "x4,4ci1,1,1,1,2a", "44,160,2", "x0,3ci1", "x6,3ci1", "x5,7ci1",          # (x5,7: BWT + E8E9 above 16 MiB -- the streaming E8E9 stage of round 6)
            "x4,2,8,0,3,22,0c0,0,511i2", "x4,6,6,0,2,20,0c0,0,511", "x4,2,5,0,3,24,0"]     # byte-aligned codes from the HASH-TABLE finder (round 4)
 
 
@@ -51,7 +51,7 @@ def _coded_payload(framed):
 def test_reference_decompresser_restores_and_stream_equals_lzbuffer(eng, method):
     from zpaqfranz_amd import engine as E
     n = 120000
-    exe = ",2" in method[2:] and method[0] in "34" or method.startswith(("x4,6", "x4,7", "x4,4"))
+    exe = ",2" in method[2:] and method[0] in "34" or method.startswith(("x4,6", "x4,7", "x4,4", "x5,7"))
     blocks = [exe_like(n, 3) if exe else datagen.text_like(n, 4), datagen.mixed(n // 2, 5), b"", b"q"]
     res = eng.compress_blocks(blocks, [method] * len(blocks), ["f%d" % i for i in range(len(blocks))], ["c"] * len(blocks), True)
     for b, (st, framed) in zip(blocks, res):

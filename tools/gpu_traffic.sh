@@ -12,6 +12,7 @@ for W in "$@"; do
   W0=$W; W=${W%:notrace}
   case $W in
     headline) SFX=""; ARGS="--workload silesia_x256_m1 --pipeline 1";;
+    cm_m5) SFX="_$W"; ARGS="--workload $W --cm-blocks 2048 --cm-block-bytes 65536";;      # (bench.py scales traffic_cm_m5.json from this size)
     *) SFX="_$W"; ARGS="--workload $W --pipeline 1";;
   esac
   rm -rf $R/gpurun_out/prof_stats$SFX $R/gpurun_out/prof_fetch$SFX $R/gpurun_out/prof_write$SFX

@@ -111,6 +111,10 @@ struct Vm {                       // one ZPAQL machine (HCOMP or PCOMP)
   u8* out; u32 out_cap, out_len;  // OUT instruction target (PCOMP only)
   int err;
   u32 in_lds;                     // bit 0: prog points into LDS, bit 1: H does (set by the kernel that put them there)
+  // interpreted instructions a call may take: `budget` free per call (0: 2^30, a post-processor's one long call at the end of a
+  // segment) plus what is left of `credit`, which the whole block has once (HCOMP: 2^20 per byte + 2^24 once -- a long
+  // initialisation loop passes, an endless loop is refused after ~seven seconds of one lane instead of 2^30 steps = minutes)
+  u32 budget, credit;
 };
 
 struct CmJobDev {
@@ -145,8 +149,11 @@ __device__ void vm_body(Vm& z, u32 input, ProgPtr P, HPtr H) {
   u32 pc = 0, a = input, b = z.b, c = z.c, d = z.d, f = z.f;
   // (2^30 interpreted instructions per call: a program that is still running then is refused -- err = 2, ZPQ_ERR_LIMIT -- where
   //  the reference would go on, ZSFX/libzpaq.cpp:1033-1254 has no limit; until round 6 the call simply ended as if it had halted)
-  for (int guard = 0;; ++guard) {
-    if (guard >= (1 << 30)) { err = 2; break; }
+  const u32 free_steps = z.budget ? z.budget : (1u << 30);
+  const u32 max_steps = free_steps + z.credit;                  // (credit <= 2^24: no wrap)
+  u32 guard = 0;
+  for (;; ++guard) {
+    if (guard >= max_steps) { err = 2; break; }
     // The machine runs on one lane (or on lanes in identical states): telling the compiler that the
     // opcode, the program counter and the flag are wave-uniform turns the dispatch below into scalar
     // branches instead of a tree of exec-mask splits.
@@ -208,6 +215,7 @@ __device__ void vm_body(Vm& z, u32 input, ProgPtr P, HPtr H) {
   }
   z.a = a; z.b = b; z.c = c; z.d = d; z.f = f; z.out_len = out_len;
   if (err) z.err = err;
+  if (guard > free_steps) z.credit = guard - free_steps > z.credit ? 0u : z.credit - (guard - free_steps);
 }
 
 // The wave coder keeps the HCOMP program and a small H[] in LDS: give those the ds_* path (a flat access
@@ -1060,6 +1068,7 @@ int run_cm_batch(zpq_ctx* ctx, zpq_cm_job* jobs, const std::vector<ParsedHeader>
     J.vm.H = (u32*)take_big((size_t)4 << P.hh); J.vm.hmask = (1u << P.hh) - 1;
     J.vm.M = take_big((size_t)1 << P.hm); J.vm.mmask = (1u << P.hm) - 1;
     J.vm.prog = arena + o_prog; J.vm.plen = (u32)P.hcomp.size();
+    J.vm.budget = 1u << 20; J.vm.credit = 1u << 24;
     if (!P.hcomp.empty()) memcpy(hm.data() + o_prog, P.hcomp.data(), P.hcomp.size());
     Comp* hc = (Comp*)(hm.data() + o_comp);
     zpq_spec_comp* sc = (zpq_spec_comp*)(hm.data() + o_scomp);

@@ -303,11 +303,15 @@ std::string lazy2_source(int rb, bool doe8) {
 
 // E8E9 inverse over M[0..b) with output, as the post-processors of levels 2 and 3 run it when the segment ends
 // (mirror of e8e9(), ZSFX/libzpaq.cpp:6117-6126)
+// Only positions i <= n - 5 carry a transformed operand (e8e9() starts at n - 5): the test of byte i + 4 is made only where it
+// lies inside the data (`a=b a<d`).  Until round 6 the program read M[i + 4] behind the data for an E8 / E9 among the last four
+// bytes -- zeros or stale bytes there satisfy the test, and the reference's PostProcessor then "restored" an operand that had
+// never been transformed (found by tests/test_pcomp_variants_cpu.py::test_e8_e9_among_the_last_bytes...).
 std::string e8e9_inverse_source() {
   return "    d=b b=0 do\n      a=b a==d ifnot\n        a=*b a&= 254 a== 232 if\n"
-         "          c=b b++ b++ b++ b++ a=*b a++ a&= 254 a== 0 if\n"
+         "          c=b b++ b++ b++ b++ a=b a<d if\n          a=*b a++ a&= 254 a== 0 if\n"
          "            b-- a=*b\n            b-- a<<= 8 a+=*b\n            b-- a<<= 8 a+=*b\n            a-=b a++\n"
-         "            *b=a a>>= 8 b++\n            *b=a a>>= 8 b++\n            *b=a b++\n          endif\n          b=c\n        endif\n"
+         "            *b=a a>>= 8 b++\n            *b=a a>>= 8 b++\n            *b=a b++\n          endif endif\n          b=c\n        endif\n"
          "        a=*b out b++\n      forever\n    endif\n";
 }
 
@@ -348,7 +352,6 @@ std::string make_config(const char* method, int args[9]) {
     // BWT (LZBuffer level 3, ZSFX/libzpaq.cpp:6225-6226, :6317-6326): the transform with the end-of-string coded
     // as 255 and its position in the last 4 bytes, LSB first.  The program collects it in M, then inverts it through
     // a linked list in H.
-    if (doe8 && args[0] > 4) throw ConfigError("BWT + E8E9 above 16 MiB blocks: post-processor not restated");
     hdr = "comp 9 16 $1+20 $1+20 ";
     pcomp = "pcomp bwtrle c ;\n  a> 255 ifnot\n    *b=a b++\n  elsel\n"
             "    b-- a=*b\n    b-- a<<= 8 a+=*b\n    b-- a<<= 8 a+=*b\n    b-- a<<= 8 a+=*b c=a r=a 1\n"
@@ -364,8 +367,28 @@ std::string make_config(const char* method, int args[9]) {
       pcomp += "      forever\n    endif\n";
       if (doe8) pcomp += e8e9_inverse_source();
       pcomp += "  endif\n  halt\nend\n";
-    } else {
+    } else if (!doe8) {
       pcomp += "    d=r 1 do\n      a=d a== 0 ifnot\n        d=*d b=d a=*b out\n      forever\n    endif\n  endif\n  halt\nend\n";
+    } else {
+      // Above 16 MiB the links fill H's words and the bytes stay in M: there is no room to collect the output for the
+      // whole-buffer E8E9 stage, so the inverse runs as a STREAM behind the walk (round 6; until then this combination was
+      // refused): the last four bytes wait in R3..R6 (R7 = how many, R8 = the position of the oldest); a byte that arrives is
+      // byte i + 4 of the oldest, which is exactly what e8e9()'s test reads (ZSFX/libzpaq.cpp:6117-6126: the operand bytes
+      // i + 1 .. i + 3 are restored in the registers before they leave); what is left when the walk ends goes out untouched --
+      // the last four positions never start an operand.
+      pcomp += "    d=r 1 do\n      a=d a== 0 ifnot\n        d=*d b=d a=*b c=a\n"
+               "        a=r 7 a== 4 if\n"
+               "          a=r 3 a&= 254 a== 232 if\n            a=c a++ a&= 254 a== 0 if\n"
+               "              a=r 6 a<<= 8 b=a a=r 5 a+=b a<<= 8 b=a a=r 4 a+=b\n              b=r 8 a-=b\n"
+               "              b=a a&= 255 r=a 4 a=b a>>= 8 b=a a&= 255 r=a 5 a=b a>>= 8 a&= 255 r=a 6\n"
+               "            endif\n          endif\n"
+               "          a=r 3 out\n          a=r 8 a++ r=a 8\n"
+               "        else\n          a++ r=a 7\n        endif\n"
+               "        a=r 4 r=a 3 a=r 5 r=a 4 a=r 6 r=a 5 a=c r=a 6\n"
+               "      forever\n    endif\n"
+               "    a=r 7 a> 3 if a=r 3 out endif\n    a=r 7 a> 2 if a=r 4 out endif\n"
+               "    a=r 7 a> 1 if a=r 5 out endif\n    a=r 7 a> 0 if a=r 6 out endif\n"
+               "    a=0 r=a 7 r=a 8\n  endif\n  halt\nend\n";
     }
   } else if (doe8) {
     // E8E9 alone in front of a model (what level 4 picks for executable data).  libzpaq 7.15 undoes it with a
@@ -386,8 +409,8 @@ std::string make_config(const char* method, int args[9]) {
   std::string comp, hcomp = "hcomp\nc-- *c=a a+= 255 d=a *d=c\n";
   if (level == 2) {
     // the parse state of the byte-aligned LZ77 codes for the 256..511 context masks: R1 = 1 + bytes until the next
-    // code (starting behind the post-processor preamble: 3 + 108 bytes, 52 more with the E8E9 stage as restated here), R2 = the code
-    hcomp += "a=r 1 a== 0 if\n  a= " + itos(111 + 52 * (doe8 ? 1 : 0)) + "\nelse a== 1 if\n  a=*c r=a 2\n  a> 63 if a>>= 6 a++ a++\n"
+    // code (starting behind the post-processor preamble: 3 + 108 bytes, 56 more with the E8E9 stage as restated here), R2 = the code
+    hcomp += "a=r 1 a== 0 if\n  a= " + itos(111 + 56 * (doe8 ? 1 : 0)) + "\nelse a== 1 if\n  a=*c r=a 2\n  a> 63 if a>>= 6 a++ a++\n"
              "  else a++ a++ endif\nelse\n  a--\nendif endif\nr=a 1\n";
   }
   while (*m && ncomp < 254) {
