@@ -165,11 +165,17 @@ int decompress_host(zpq_ctx* ctx, const uint8_t* blk, size_t n, size_t usize, By
 }
 
 // read_archive (ZSFX/zsfx.cpp:1283-1627), journaling blocks only.
-// fetch != nullptr: `arc` is a host SHADOW of an archive that lies in HBM -- fetch(lo, hi) makes [lo, hi) of it valid -- and the
-// d blocks are never looked at: after a c block the walk jumps over them by the size the c block holds, as the reference's
-// own read_archive does (ZSFX/zsfx.cpp:1432-1461).
-int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix, const std::function<int(size_t, size_t)>* fetch = nullptr) {
-  size_t pos = 0, data_offset = 0;
+// fetch != nullptr: `arc` is a host SHADOW of an archive that lies in HBM at d_arc -- fetch(lo, hi) makes [lo, hi) of it valid --
+// and the d blocks are never looked at: after a c block the walk jumps over them by the size the c block holds, as the
+// reference's own read_archive does (ZSFX/zsfx.cpp:1432-1461).
+// Two passes (round 6): the walk over the framing decodes only the c blocks (eight bytes each: the jump), every h and i block of
+// the archive is then decoded by ONE batched call -- an archive of Silesia x256 has 13 h and ~200 i blocks, and one device call
+// per block (a launch, a sync, two copies each) was 80 ms of every extract -- and the tables are filled in archive order.
+int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix, const std::function<int(size_t, size_t)>* fetch = nullptr,
+               const uint8_t* d_arc = nullptr) {
+  struct Pending { char type; uint32_t num; size_t pos, size, usize, data_offset; };
+  std::vector<Pending> pend;
+  size_t pos = 0;
   bool rest_fetched = false;
   while (pos < n) {
     RawBlock rb;
@@ -186,61 +192,99 @@ int read_index(zpq_ctx* ctx, const uint8_t* arc, size_t n, Index& ix, const std:
     if (usize64 > 0xffffffffull - 4096 || num64 > 0xffffffffull) return ZPQ_ERR_FORMAT;
     const uint32_t num = (uint32_t)num64;
     const size_t usize = (size_t)usize64;
-    if (type == 'c' || type == 'h' || type == 'i') {
+    if (type == 'c') {
       Bytes os;
       int rc = decompress_host(ctx, arc + pos, rb.size, usize, os);
       if (rc) return rc;
-      if (os.size() != usize) return ZPQ_ERR_FORMAT;
-      if (type == 'c') {
-        if (os.size() < 8) return ZPQ_ERR_FORMAT;
-        const int64_t jmp = (int64_t)get64(os.data());
-        if (jmp < 0) break;                       // incomplete transaction: roll back (ZSFX/zsfx.cpp:1436-1443)
-        ++ix.versions;
-        data_offset = pos + rb.size;
-        if (fetch) {
-          if ((uint64_t)jmp > n - pos - rb.size) return ZPQ_ERR_FORMAT;
-          pos += (size_t)jmp;                      // (+ rb.size below): the first h block of this version
-          if (!rest_fetched) {                     // everything behind the first version's d blocks: index blocks (and later versions)
-            const int rc = (*fetch)(pos + rb.size, n); if (rc) return rc;
-            rest_fetched = true;
-          }
-        }
-      } else if (type == 'h') {
-        if (os.size() % 24 != 4) return ZPQ_ERR_FORMAT;
-        const uint32_t nf = (uint32_t)((os.size() - 4) / 24), bsize = get32(os.data());
-        if (num < 1 || (uint64_t)num + nf > 0xffffffffull) return ZPQ_ERR_FORMAT;
-        DBlock b; b.offset = data_offset; b.csize = bsize; b.first_frag = num; b.nfrag = nf; b.usize = 8;
-        if (ix.ht.size() < (size_t)num + nf) ix.ht.resize((size_t)num + nf);
-        for (uint32_t i = 0; i < nf; ++i) {
-          memcpy(ix.ht[num + i].sha1.d, os.data() + 4 + 24 * i, 20);
-          ix.ht[num + i].usize = get32(os.data() + 24 + 24 * i);
-          b.usize += (uint64_t)ix.ht[num + i].usize + 4u;      // 64 bits: a hostile size must not wrap
-        }
-        ix.blocks.push_back(b);
-        data_offset += bsize;
-      } else {
-        const uint8_t* s = os.data(); const uint8_t* end = s + os.size();
-        while (s + 9 <= end) {
-          FileRec fr; fr.date = (int64_t)get64(s); s += 8;
-          const uint8_t* z = (const uint8_t*)memchr(s, 0, end - s);
-          if (!z) return ZPQ_ERR_FORMAT;
-          std::string fn((const char*)s, z - s); s = z + 1;
-          if (fr.date) {
-            if (s + 4 > end) return ZPQ_ERR_FORMAT;
-            const uint32_t na = get32(s); s += 4;
-            if (s + na > end) return ZPQ_ERR_FORMAT;
-            fr.attr.assign((const char*)s, na); s += na;
-            if (s + 4 > end) return ZPQ_ERR_FORMAT;
-            const uint32_t ni = get32(s); s += 4;
-            if ((size_t)(end - s) / 4 < ni) return ZPQ_ERR_FORMAT;
-            fr.ptr.resize(ni);
-            for (uint32_t i = 0; i < ni; ++i) { fr.ptr[i] = get32(s); s += 4; }
-          }
-          ix.files[fn] = fr;
+      if (os.size() != usize || os.size() < 8) return ZPQ_ERR_FORMAT;
+      const int64_t jmp = (int64_t)get64(os.data());
+      if (jmp < 0) break;                       // incomplete transaction: roll back (ZSFX/zsfx.cpp:1436-1443)
+      pend.push_back({'c', num, pos, rb.size, usize, pos + rb.size});
+      if (fetch) {
+        if ((uint64_t)jmp > n - pos - rb.size) return ZPQ_ERR_FORMAT;
+        pos += (size_t)jmp;                      // (+ rb.size below): the first h block of this version
+        if (!rest_fetched) {                     // everything behind the first version's d blocks: index blocks (and later versions)
+          const int rc2 = (*fetch)(pos + rb.size, n); if (rc2) return rc2;
+          rest_fetched = true;
         }
       }
+    } else if (type == 'h' || type == 'i') {
+      pend.push_back({type, num, pos, rb.size, usize, 0});
     }
     pos += rb.size;
+  }
+  // ---- every h and i block in one call
+  std::vector<size_t> off(pend.size(), 0);
+  size_t total = 0, nj = 0;
+  for (size_t k = 0; k < pend.size(); ++k) if (pend[k].type != 'c') { off[k] = total; total += (pend[k].usize + 64 + 63) & ~(size_t)63; ++nj; }
+  Bytes plain(total ? total : 1);
+  if (nj) {
+    std::vector<zpq_unblock_job> jobs(nj);
+    struct DevBuf { zpq_ctx* c; void* p; ~DevBuf() { if (p) zpq_dev_free_pooled(c, p); } } dbuf{ctx, nullptr};
+    if (d_arc) { const int rc = zpq_dev_alloc_pooled(ctx, total + 64, &dbuf.p); if (rc) return rc; }
+    size_t j = 0;
+    for (size_t k = 0; k < pend.size(); ++k) {
+      if (pend[k].type == 'c') continue;
+      memset(&jobs[j], 0, sizeof jobs[j]);
+      jobs[j].in = (d_arc ? d_arc : arc) + pend[k].pos; jobs[j].n = (uint32_t)pend[k].size;
+      jobs[j].out = (d_arc ? (uint8_t*)dbuf.p : plain.data()) + off[k]; jobs[j].out_cap = (uint32_t)pend[k].usize + 64;
+      ++j;
+    }
+    // (device form: the blocks are decoded where they lie in HBM, one copy brings all of them over)
+    int rc = d_arc ? zpq_decompress_blocks_dev(ctx, jobs.data(), nj, 1) : zpq_decompress_blocks(ctx, jobs.data(), nj, 1);
+    j = 0;
+    for (size_t k = 0; k < pend.size(); ++k) {
+      if (pend[k].type == 'c') continue;
+      if (jobs[j].status) return jobs[j].status;
+      if (!rc && jobs[j].out_len != pend[k].usize) return ZPQ_ERR_FORMAT;
+      ++j;
+    }
+    if (rc) return rc;
+    if (d_arc && (rc = zpq_d2h(ctx, plain.data(), dbuf.p, total))) return rc;
+  }
+  // ---- the tables, in archive order
+  size_t data_offset = 0;
+  for (size_t k = 0; k < pend.size(); ++k) {
+    const Pending& P = pend[k];
+    const uint8_t* os = plain.data() + off[k];
+    const size_t osz = P.usize;
+    if (P.type == 'c') {
+      ++ix.versions;
+      data_offset = P.data_offset;
+    } else if (P.type == 'h') {
+      if (osz % 24 != 4) return ZPQ_ERR_FORMAT;
+      const uint32_t nf = (uint32_t)((osz - 4) / 24), bsize = get32(os);
+      if (P.num < 1 || (uint64_t)P.num + nf > 0xffffffffull) return ZPQ_ERR_FORMAT;
+      DBlock b; b.offset = data_offset; b.csize = bsize; b.first_frag = P.num; b.nfrag = nf; b.usize = 8;
+      if (ix.ht.size() < (size_t)P.num + nf) ix.ht.resize((size_t)P.num + nf);
+      for (uint32_t i = 0; i < nf; ++i) {
+        memcpy(ix.ht[P.num + i].sha1.d, os + 4 + 24 * i, 20);
+        ix.ht[P.num + i].usize = get32(os + 24 + 24 * i);
+        b.usize += (uint64_t)ix.ht[P.num + i].usize + 4u;      // 64 bits: a hostile size must not wrap
+      }
+      ix.blocks.push_back(b);
+      data_offset += bsize;
+    } else {
+      const uint8_t* s = os; const uint8_t* end = s + osz;
+      while (s + 9 <= end) {
+        FileRec fr; fr.date = (int64_t)get64(s); s += 8;
+        const uint8_t* z = (const uint8_t*)memchr(s, 0, end - s);
+        if (!z) return ZPQ_ERR_FORMAT;
+        std::string fn((const char*)s, z - s); s = z + 1;
+        if (fr.date) {
+          if (s + 4 > end) return ZPQ_ERR_FORMAT;
+          const uint32_t na = get32(s); s += 4;
+          if (s + na > end) return ZPQ_ERR_FORMAT;
+          fr.attr.assign((const char*)s, na); s += na;
+          if (s + 4 > end) return ZPQ_ERR_FORMAT;
+          const uint32_t ni = get32(s); s += 4;
+          if ((size_t)(end - s) / 4 < ni) return ZPQ_ERR_FORMAT;
+          fr.ptr.resize(ni);
+          for (uint32_t i = 0; i < ni; ++i) { fr.ptr[i] = get32(s); s += 4; }
+        }
+        ix.files[fn] = fr;
+      }
+    }
   }
   return ZPQ_OK;
 }
@@ -859,7 +903,7 @@ int extract_impl(zpq_ctx* ctx, const uint8_t* archive, size_t archive_len, uint8
     shadow.p = (uint8_t*)calloc(archive_len + 64, 1);
     if (!shadow.p) return ZPQ_ERR_NOMEM;
     const std::function<int(size_t, size_t)> fetch = [&](size_t lo, size_t hi) { return hi > lo ? zpq_d2h(ctx, shadow.p + lo, d_archive + lo, hi - lo) : (int)ZPQ_OK; };
-    rc = read_index(ctx, shadow.p, archive_len, ix, &fetch);
+    rc = read_index(ctx, shadow.p, archive_len, ix, &fetch, d_archive);
     archive = shadow.p;
   } else {
     rc = read_index(ctx, archive, archive_len, ix);
