@@ -1433,8 +1433,10 @@ def main():
         return main_text_m2(a, rank, world, local, dev)
     if a.workload == "cm_m5":
         return main_cm_m5(a, rank, world, local, dev)
-    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 48, "dup8_m1": 2, "extract_m1": 6}[a.workload]
-    warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 1}[a.workload]
+    # (extract_m1: twelve timed jobs since round 6 -- with four in flight and six in the window two default runs of one tree gave
+    #  724 and 923 ms per step, profiles/r06d_bench*.json)
+    steps = a.steps if a.steps is not None else {"silesia_x256_m1": 48, "dup8_m1": 2, "extract_m1": 12}[a.workload]
+    warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 2}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, ~140 ms of LZ77 parse per 2 MiB
     # segment) behind the chip-wide kernels of other steps; round 4 (three-wave parse, 2 MiB segments: 12.5 GB of table states
     # per job): 106.8 / 99.5 / 98.0 ms per step at 8 / 10 / 12, 133 at 14 (the tables no longer fit): twelve by default

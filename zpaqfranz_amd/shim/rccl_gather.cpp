@@ -1,5 +1,5 @@
 // rccl_gather.cpp -- an all-gather of byte strings over RCCL (rccl_gather.h): what zpqj_add_sharded[_dev] calls per add.
-// Host code; the bytes travel HBM to HBM over xGMI on the context's stream.  zpqr_allgatherv takes and returns HOST strings
+// Host code; the bytes travel HBM to HBM over xGMI on a stream the communicator owns.  zpqr_allgatherv takes and returns HOST strings
 // (fragment tables, block sizes: staged through pinned memory at both ends); zpqr_allgatherv_dev takes and returns DEVICE
 // memory (the compressed d blocks of zpqj_add_sharded_dev: no staging at all).
 #include <hip/hip_runtime.h>
@@ -65,10 +65,16 @@ int zpqr_create(zpq_ctx* ctx, int rank, int world, const uint8_t id[ZPQR_ID_BYTE
   if (!ctx || !id || world < 1 || world > ZPQR_MAX_RANKS || rank < 0 || rank >= world) return ZPQ_ERR_ARG;
   zpqr_comm* c = new zpqr_comm;
   c->rank = rank; c->world = world;
-  c->stream = (hipStream_t)zpq_stream(ctx);                        // the collectives are ordered with the context's own work
+  // A stream of its own (round 6).  Every call here is synchronous for its caller -- what is sent is complete before the call
+  // (zpqj_add_sharded[_dev] synchronises its context first), what is received is complete when it returns -- so nothing has to
+  // be ordered with the context's stream; on that stream every synchronisation below waited for whatever kernels the context's
+  // CURRENT add had in flight, and with several adds in flight sharing one communicator every collective of every add queued
+  // behind one context's fragment pass: 272 ms per step through the product call at world size 1 against 99 ms without
+  // collectives (profiles/r06d_bench.json / bench_rccl1).
   int rc = ZPQ_OK;
   do {
-    if (hipStreamGetDevice(c->stream, &c->device) != hipSuccess || hipSetDevice(c->device) != hipSuccess) { rc = ZPQ_ERR_HIP; break; }
+    if (hipStreamGetDevice((hipStream_t)zpq_stream(ctx), &c->device) != hipSuccess || hipSetDevice(c->device) != hipSuccess) { rc = ZPQ_ERR_HIP; break; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = nullptr; rc = ZPQ_ERR_HIP; break; }
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     if (ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) { rc = ZPQ_ERR_HIP; break; }
@@ -191,6 +197,7 @@ void zpqr_destroy(zpqr_comm* c) {
   if (c->d_len) (void)hipFree(c->d_len);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
