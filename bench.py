@@ -1483,11 +1483,23 @@ def main():
                        for r_ in range(world) for c_ in range(cps) for n_ in layout["names"]]
         shard_sizes = [int(z_) for _ in range(world) for _ in range(cps) for z_ in layout["sizes"]]
         assert shard_names == sorted(shard_names), "the corpus members must be held in name order"
-        if a.dist_backend != "gloo":
-            from zpaqfranz_amd import engine as E_
-            uid = [E_.RcclGather.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            shard_gather = E_.RcclGather(eng, rank, world, uid[0])      # ONE communicator per rank (its collectives take turns: CollectiveOrder)
+    # RCCL: every add in flight has a communicator of its own (created in the same order on every rank) and the adds are dealt to
+    # the contexts statically -- job i runs on context i mod depth on every rank -- so each communicator sees the same sequence of
+    # calls everywhere and no order between the adds in flight has to be imposed: the C collectives go to the product call as
+    # function pointers, nothing of Python or torch stands between the engine and RCCL.  (With ONE communicator and the fixed
+    # turn order of CollectiveOrder every RCCL launch of every add queued behind the others, and each waits for a free slot on a
+    # chip that is full of chip-filling kernels: 217-221 ms per step at world size 1 against 99 ms without collectives,
+    # profiles/r06e_rccl_world1_own_stream.txt.)  gloo (tests) keeps the one group and the turn order.
+    comm_per_add = sharded_product and a.dist_backend != "gloo"
+    gathers = []
+
+    def new_gather(e_):
+        from zpaqfranz_amd import engine as E_
+        uid = [E_.RcclGather.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        g_ = E_.RcclGather(e_, rank, world, uid[0])
+        gathers.append(g_)
+        return g_
 
     def add_pipe(e_):
         p_ = Pipeline(e_, dev, layout, rank, world, a.force_collectives)
@@ -1497,8 +1509,8 @@ def main():
         p_.product = product
         if sharded_product:
             from zpaqfranz_amd import engine as E_
-            if shard_gather is not None:
-                p_.use_sharded_product(shard_names, shard_sizes, shard_gather, None)
+            if comm_per_add:
+                p_.use_sharded_product(shard_names, shard_sizes, new_gather(e_), None)
             else:
                 p_.use_sharded_product(shard_names, shard_sizes, E_.dist_allgather_bytes(), E_.dist_allgather_dev(e_))
         pipes.append(p_)
@@ -1551,15 +1563,21 @@ def main():
         import threading
         nxt, lock, outs, errs, done = [0], threading.Lock(), [0] * n, [], [0.0] * n
 
-        order = CollectiveOrder(n, depth, Pipeline.SECTIONS if sharded_product else 3) if (world > 1 or a.force_collectives) else _NoOrder()
+        order = (CollectiveOrder(n, depth, Pipeline.SECTIONS if sharded_product else 3)
+                 if ((world > 1 or a.force_collectives) and not comm_per_add) else _NoOrder())
+        nworkers = 1 if (depth == 1 or len(runners) == 1) else len(runners)
 
-        def worker(p_, delay):
+        def worker(p_, delay, wk=0):
             try:
                 torch.cuda.set_device(local)     # the current device is per host thread
                 time.sleep(delay)      # stagger: one step's chip-wide kernels against the other's latency-bound tail
+                mine = wk
                 while True:
-                    with lock:
-                        i = nxt[0]; nxt[0] += 1
+                    if comm_per_add:       # static: job i on context i mod depth, on every rank alike
+                        i = mine; mine += nworkers
+                    else:
+                        with lock:
+                            i = nxt[0]; nxt[0] += 1
                     if i >= n:
                         return
                     outs[i] = p_.step(order, i, i == n - 1) if isinstance(p_, Pipeline) else p_.step(order, i)
@@ -1578,7 +1596,7 @@ def main():
         if depth == 1 or len(runners) == 1:
             worker(runners[0], 0.0)
         else:
-            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth)) for k_, p_ in enumerate(runners)]
+            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth, k_)) for k_, p_ in enumerate(runners)]
             for t in th: t.start()
             for t in th: t.join()
         if errs:
@@ -1759,7 +1777,8 @@ def main():
                           "files": pipe.nfiles * world, "input_bytes": in_bytes,
                           "method": "14 -> x4,1,5,0,3,24", "block_bytes": BLOCK_LIMIT, "fragment": 6, **st},
                "timed_step": ("one C-ABI call per rank: zpqj_add_sharded_dev (this rank's files resident in HBM in, the whole job's archive out on every rank) with "
-                              "the in-tree RCCL collectives inside it (zpqr_allgatherv / zpqr_allgatherv_dev: no torch collective in the timed region)"
+                              "the in-tree RCCL collectives inside it (zpqr_allgatherv / zpqr_allgatherv_dev as C function pointers, one communicator per add in flight: "
+                              "no torch collective and no Python in the timed region's data path)"
                               if sharded_product and a.dist_backend != "gloo" else
                               "one C-ABI call per rank: zpqj_add_sharded_dev over functional stand-in collectives (gloo: test only)" if sharded_product else
                               "one C-ABI call: zpqj_extract_dev (whole journaling archive resident in HBM in -- the call reads the index itself --, restored "
@@ -1910,6 +1929,8 @@ def main():
         dist.destroy_process_group()
     for p_ in pipes:
         p_.drop_archive()
+    for g_ in gathers:
+        g_.close()
     for e_ in engines:
         e_.close()
 
