@@ -816,14 +816,17 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
     ZPQ_HIP(ctx, hipStreamSynchronize(st));              // ord is a local
     // More long extents than SIMDs (an extract's restored files: thousands of megabytes-long chains): several chains per
     // wave, S lanes each (sha256_group_kernel) -- every long extent at (nearly) chain speed from the start, on a fraction
-    // of the chip.  S from how many there are: one wave per SIMD at most where that is possible.  ZPQ_SHA256_GROUP=S forces
-    // it (0 = never: the wave-wide / lane-wise split of before).
+    // of the chip.  S = 8 (4 beyond eight extents per SIMD): measured on config 5 with four extract jobs in flight and twelve
+    // timed jobs (profiles/r06f_extract_lanes_per_chain_twelve_jobs.txt): 827 / 702 / 722 ms per job at S = 16 / 8 / 4 against
+    // 1237 ms for the wave-wide + lane-wise split -- a job alone is fastest at 16 (2.01 / 2.10 / 2.29 s), but the jobs in flight
+    // share the SIMDs' issue slots and fewer waves per job is what they need.  ZPQ_SHA256_GROUP=S forces it (0 = never: the
+    // split of before).
     size_t nl = 0;
     while (nl < n && hl[ord[nl]] >= chain_min) ++nl;
     int S = 0;
     {
       const size_t simds = (size_t)ctx->cu_count * 4;
-      if (nl > simds) S = nl <= simds * 4 ? 16 : nl <= simds * 8 ? 8 : 4;
+      if (nl > simds) S = nl <= simds * 8 ? 8 : 4;
       if (const char* e = getenv("ZPQ_SHA256_GROUP")) { const int v = atoi(e); S = (v == 4 || v == 8 || v == 16 || v == 32) && nl ? v : 0; }
     }
     if (S) {
