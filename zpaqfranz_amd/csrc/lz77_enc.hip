@@ -1103,6 +1103,23 @@ static void launch_spec3(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzSegDev
 }
 template <int NB>
 static void launch_direct4(zpq_ctx* ctx, hipStream_t st, dim3 grid, const LzJobDev* d_jobs, const LzSegDev* d_segs, const u32* jl) {
+#ifdef ZPQ_LZ_ORACLE
+  {   // the experiment of lz77_waves.inc: the first launch records the visited positions, the later ones use them
+    static u32* map = nullptr; static size_t map_jobs = 0; static int launches = 0;
+    const size_t nj = grid.x;
+    if (!map || nj > map_jobs) {
+      if (map) (void)hipFree(map);
+      (void)hipMalloc((void**)&map, nj * kOracleStride * 4); map_jobs = nj; launches = 0;
+    }
+    const u32 mode = launches == 0 ? 1u : 2u;
+    if (mode == 1u) (void)hipMemsetAsync(map, 0, nj * kOracleStride * 4, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz_oracle_map), &map, sizeof map);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz_oracle_mode), &mode, sizeof mode);
+    fprintf(stderr, "[lz oracle] launch %d of %zu blocks: mode %u\n", launches, nj, mode);
+    ++launches;
+  }
+#endif
   ZPQ_LAUNCH(ctx, "lz77_direct_kernel", st, lz77_direct4_kernel<NB>, grid, dim3(256), d_jobs, d_segs, jl);
 }
 
