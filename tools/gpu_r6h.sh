@@ -10,8 +10,10 @@ run() { timeout 600 python $2 bench.py --workload dup8_m1 --no-cpu-baseline --st
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']
 print('$1:', d['value'], 'MB/s', d['ms_per_step'], 'ms; lz77_direct_kernel', k.get('lz77_direct_kernel'), 'ms per launch;', {x:v for x,v in d.items() if x.startswith('verified')})" | tee -a gpurun_out/${T}_dup8_oracle.txt; grep "lz oracle" gpurun_out/${T}_$1.err | tail -4 | tee -a gpurun_out/${T}_dup8_oracle.txt; }
+if [ -z "$ZPQ_R6H_PMC_ONLY" ]; then
 run tree ""
 run oracle_visited_positions_only "tools/run_variant.py oracle"
+fi
 echo "[$(( $(date +%s) - S0 )) s] timing"
 # the traffic of the oracle's second launch
 cd /tmp
@@ -26,7 +28,7 @@ for d, c in (("/tmp/pf", "FETCH_SIZE"), ("/tmp/pw", "WRITE_SIZE")):
     if not f:
         print(c, "no database"); continue
     cur = sqlite3.connect(f[0]).cursor()
-    rows = list(cur.execute("select value from counters_collection where counter_name=? and kernel_name like '%lz77_direct4%' order by rowid", (c,)))
+    rows = list(cur.execute("select value from counters_collection where counter_name=? and kernel_name like '%lz77_direct4%'", (c,)))
     print(c, "KiB per lz77_direct4 launch, in launch order (first = recording pass):", [round(r[0]) for r in rows])
 PY
 echo "[$(( $(date +%s) - S0 )) s] done"
