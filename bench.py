@@ -1439,10 +1439,12 @@ def main():
     warm = a.warmup if a.warmup is not None else {"silesia_x256_m1": 3, "dup8_m1": 1, "extract_m1": 2}[a.workload]
     # steps in flight: the add path hides its serial tails (216 ms of block checksum chain, ~140 ms of LZ77 parse per 2 MiB
     # segment) behind the chip-wide kernels of other steps; round 4 (three-wave parse, 2 MiB segments: 12.5 GB of table states
-    # per job): 106.8 / 99.5 / 98.0 ms per step at 8 / 10 / 12, 133 at 14 (the tables no longer fit): twelve by default
+    # per job): 106.8 / 99.5 / 98.0 ms per step at 8 / 10 / 12, 133 at 14 (the tables no longer fit): twelve by default until round 6
     # (multi-rank runs too: every step in flight adds three collective sections to the one fixed order, CollectiveOrder)
     multi = world > 1 or a.force_collectives
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 12, "dup8_m1": 1, "extract_m1": 4}[a.workload])
+    # (round 6, steady-state window, three interleaved runs each -- profiles/r06k_sweep_jobs_in_flight_steady_state.txt: 9 / 10 / 11 / 12 in
+    #  flight = 97.4 / 92.5 / 90.9 / 99.4 ms per step: eleven)
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 11, "dup8_m1": 1, "extract_m1": 4}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
