@@ -1444,7 +1444,9 @@ def main():
     multi = world > 1 or a.force_collectives
     # (round 6, steady-state window, three interleaved runs each -- profiles/r06k_sweep_jobs_in_flight_steady_state.txt: 9 / 10 / 11 / 12 in
     #  flight = 97.4 / 92.5 / 90.9 / 99.4 ms per step: eleven)
-    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 11, "dup8_m1": 1, "extract_m1": 4}[a.workload])
+    # (extract_m1: five since round 6 -- the MI355X's 288 GiB hold five sets of restored files, 54 GB each; 757 / 711 ms per job at four in
+    #  flight, 627 at five: profiles/r06m_extract_chain_priority_and_five_in_flight.txt; capped by free HBM below)
+    depth = max(1, a.pipeline if a.pipeline is not None else {"silesia_x256_m1": 11, "dup8_m1": 1, "extract_m1": 5}[a.workload])
     import datagen
     from zpaqfranz_amd import Engine
     eng = Engine(local)
@@ -1540,6 +1542,12 @@ def main():
         # several extract jobs in flight (own context, own output): a job is as long as its longest serial chain -- the
         # SHA-256 of the 51 MB member on one wave, the SHA-1 of a 16 MiB block -- and leaves most of the chip idle
         runners = [ex_pipe]
+        if a.pipeline is None:
+            # every further job in flight holds its own restored files and decoded blocks; 16 GB stay free for the scratch arenas
+            # of the contexts (BLAKE3 chaining values, LZ77 decode records) and the verification's copies
+            per_job = ex_pipe.out.numel() + ex_pipe.plain.numel() + (1 << 30)
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            depth = max(1, min(depth, 1 + int((free_b - (16 << 30)) // per_job)))
     else:
         runners = pipes
 

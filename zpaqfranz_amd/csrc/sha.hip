@@ -515,7 +515,10 @@ __global__ __launch_bounds__(256) void sha256_chain_kernel(const u8* __restrict_
 template <int S>
 __global__ __launch_bounds__(256) void sha256_group_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                                                            const u64* __restrict__ len, u32 n, u8* __restrict__ digests,
-                                                           const u32* __restrict__ list, u32* __restrict__ queue) {
+                                                           const u32* __restrict__ list, u32* __restrict__ queue, const u32 prio) {
+  // (a job is as long as its longest chain: the chains ask for issue priority over whatever else shares their SIMDs, as the
+  //  block checksum chains do)
+  if (prio) __builtin_amdgcn_s_setprio(3);
   const int lane = lane_id();
   const int g0 = lane & ~(S - 1), j = lane & (S - 1);          // first lane of my group, my block slot
   bool have = false, done = false;
@@ -835,11 +838,12 @@ int zpq_sha256_extents_dev(zpq_ctx* ctx, const uint8_t* d_base, const uint64_t* 
       ZPQ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev2, 0));
       const size_t groups = 64 / (size_t)S, waves = (nl + groups - 1) / groups;
       const dim3 grid((unsigned)std::min<size_t>((waves + 3) / 4, (size_t)ctx->cu_count * 2));
+      static const u32 prio = [] { const char* e = getenv("ZPQ_SHA256_PRIO"); return e ? (u32)atoi(e) : 0u; }();
       switch (S) {
-        case 4: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<4>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
-        case 8: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<8>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
-        case 16: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<16>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
-        default: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<32>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1); break;
+        case 4: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<4>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1, prio); break;
+        case 8: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<8>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1, prio); break;
+        case 16: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<16>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1, prio); break;
+        default: ZPQ_LAUNCH(ctx, "sha256_group_kernel", ctx->stream2, sha256_group_kernel<32>, grid, dim3(256), d_base, d_off, d_len, (u32)nl, d_digests, (const u32*)d_ord, counter + 1, prio); break;
       }
       ZPQ_HIP(ctx, hipGetLastError());
       ZPQ_HIP(ctx, hipEventRecord(ctx->ev, ctx->stream2));
