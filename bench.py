@@ -1542,12 +1542,19 @@ def main():
         # several extract jobs in flight (own context, own output): a job is as long as its longest serial chain -- the
         # SHA-256 of the 51 MB member on one wave, the SHA-1 of a 16 MiB block -- and leaves most of the chip idle
         runners = [ex_pipe]
+        # the context that wrote the archive keeps ~20 GB of grow-only scratch (the LZ77 table states of the add): the extract jobs
+        # get fresh contexts, that one is closed
+        eng.close()
+        eng = Engine(local)
+        engines[0] = eng
+        ex_pipe.eng = eng
+        torch.cuda.empty_cache()
         if a.pipeline is None:
-            # every further job in flight holds its own restored files and decoded blocks; 16 GB stay free for the scratch arenas
+            # every further job in flight holds its own restored files and decoded blocks; 12 GB stay free for the scratch arenas
             # of the contexts (BLAKE3 chaining values, LZ77 decode records) and the verification's copies
-            per_job = ex_pipe.out.numel() + ex_pipe.plain.numel() + (1 << 30)
+            per_job = ex_pipe.out.numel() + ex_pipe.plain.numel() + (1 << 28)
             free_b = torch.cuda.mem_get_info(dev)[0]
-            depth = max(1, min(depth, 1 + int((free_b - (16 << 30)) // per_job)))
+            depth = max(1, min(depth, 1 + int((free_b - (12 << 30)) // per_job)))
     else:
         runners = pipes
 
