@@ -1613,7 +1613,10 @@ def main():
         if depth == 1 or len(runners) == 1:
             worker(runners[0], 0.0)
         else:
-            th = [threading.Thread(target=worker, args=(p_, k_ * stagger[0] / depth, k_)) for k_, p_ in enumerate(runners)]
+            # the jobs start `spacing` apart: single / depth by default; ZPQ_BENCH_SPACING_MS: experiment (the steady period, so that the
+            # pipeline starts spread over one in-flight latency instead of bunched)
+            spacing = float(os.environ["ZPQ_BENCH_SPACING_MS"]) / 1e3 if os.environ.get("ZPQ_BENCH_SPACING_MS") else stagger[0] / depth
+            th = [threading.Thread(target=worker, args=(p_, k_ * spacing, k_)) for k_, p_ in enumerate(runners)]
             for t in th: t.start()
             for t in th: t.join()
         if errs:
