@@ -261,3 +261,67 @@ def test_sharded_dev_add_over_the_in_tree_rccl_collectives_world_size_1():
     finally:
         g.close()
         eng.close()
+
+
+def _tree_of_copies():
+    """two directories with the same files (every fragment of the second is a duplicate of one in the first) + a few files of
+    its own in each: the d blocks are dealt out, the context dealt to reads its own copies"""
+    base = sorted(_corpus(seed=23, nfiles=30), key=lambda f: f[0].encode())
+    extra = _corpus(seed=29, nfiles=4)
+    # (b/ has two files of its own at its END: the last block then starts on rank 1 and mixes fragments of both ranks)
+    files = [("a/" + n, b) for n, b in base]
+    files += [("b/" + n, b) for n, b in base] + [("b/zz_own_%d" % i, b[:150000]) for i, (_, b) in enumerate(extra[2:])]
+    return sorted(files, key=lambda f: f[0].encode())
+
+
+def _copies_worker(rank, world, port, q, with_dev):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zpaqfranz_amd import engine
+    files = _tree_of_copies()
+    names, sizes = [f[0] for f in files], [len(f[1]) for f in files]
+    mine = engine.jidac_shard_files(names, sizes, world, rank)
+    eng = engine.Engine(0)
+    buf = eng.upload(b"".join(b for (n, b), m in zip(files, mine) if m))
+    arc, st = engine.jidac_add_sharded_dev(eng, rank, world, engine.dist_allgather_bytes(), engine.dist_allgather_dev(eng) if with_dev else None,
+                                           None, names, sizes, buf.ptr, 20260925120000, "10")
+    q.put((rank, arc, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_dev", [True, False])
+def test_blocks_of_a_tree_of_copies_are_dealt_out_and_the_archive_stays_the_same(with_dev):
+    """One tree of copies over two ranks (the BASELINE metric's shape): every new fragment first occurs on rank 0, the d blocks
+    (method "10": 1 MiB blocks, several of them) are dealt out and rank 1 compresses its share from its OWN copies; the archive is
+    the single-GPU archive, and so is what several contexts in one process write (zpqj_add_multi)."""
+    from zpaqfranz_amd import engine
+    files = _tree_of_copies()
+    eng = engine.Engine(0)
+    want, wst = engine.jidac_add(eng, None, files, 20260925120000, "10")
+    assert wst["d_blocks"] >= 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_copies_worker, args=(r, 2, port, q, with_dev)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+    for r in range(2):
+        assert res[r][0] == want and res[r][1] == wst, r
+    if with_dev:
+        e2, e3 = engine.Engine(0), engine.Engine(0)
+        try:
+            for engs in ([eng, e2], [eng, e2, e3]):
+                got, gst = engine.jidac_add(engs, None, files, 20260925120000, "10")
+                assert got == want and gst == wst, len(engs)
+        finally:
+            e2.close(); e3.close()
+    assert engine.jidac_extract(eng, want) == dict(files)

@@ -528,6 +528,48 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   }
   std::vector<Bytes> dblock(blocks.size());
   std::vector<int> brc(nctx, ZPQ_OK);
+  // Who compresses a d block, and where it reads the block's fragments (round 6).  Until now: the context that holds the block's
+  // FIRST fragment, every fragment read where it first occurred.  With ONE tree of copies over several GPUs -- the shape of
+  // the BASELINE metric -- every new fragment first occurs on the first GPU, which then compressed every block while the others
+  // only fragmented and hashed.  Now the blocks are DEALT OUT in equal contiguous ranges (block b to context b n / B) wherever
+  // the context dealt to holds the whole block, and a context reads a fragment from its OWN data whenever it holds a copy of it -- the global table says which of a context's fragments have that
+  // first occurrence, every rank derives the same answer for every rank -- so only fragments a context really lacks travel
+  // (exchange 2 / peer copies).  The archive's bytes do not depend on any of this.
+  const size_t nnew = newfrags.size();
+  std::vector<uint32_t> owner_of(blocks.size(), 0);
+  for (size_t b = 0; b < blocks.size(); ++b) owner_of[b] = shard_of[newfrags[blocks[b].first]];
+  // copy_at[r * nnew + k]: a fragment of context r with the content of new fragment k (its global index), or ~0
+  std::vector<uint32_t> copy_at;
+  if (nctx > 1) {
+    std::vector<uint32_t> new_rank(nf, 0xffffffffu);
+    for (size_t k = 0; k < nnew; ++k) new_rank[newfrags[k]] = (uint32_t)k;
+    copy_at.assign(nctx * nnew, 0xffffffffu);
+    for (size_t i = 0; i < nf; ++i) {
+      const uint32_t k = new_rank[first[i]];
+      if (k == 0xffffffffu) continue;                       // (known from an earlier version: not stored again)
+      uint32_t& c = copy_at[(size_t)shard_of[i] * nnew + k];
+      if (c == 0xffffffffu) c = (uint32_t)i;
+    }
+    // a block goes to the context it is dealt to only if that context holds EVERY fragment of it (then nothing of the block
+    // travels); otherwise it stays with the context of its first fragment, as before (a tree of different files per GPU:
+    // shipping whole blocks' worth of fragments would cost more than the compressor it spreads)
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const size_t dealt = b * nctx / blocks.size();
+      bool all = true;
+      for (size_t k = blocks[b].first; k < blocks[b].second && all; ++k) all = copy_at[dealt * nnew + k] != 0xffffffffu;
+      if (all) owner_of[b] = (uint32_t)dealt;
+    }
+    if (getenv("ZPQJ_TRACE_OWNERS")) {        // debugging aid: who compresses which block
+      std::string line;
+      for (size_t b = 0; b < blocks.size(); ++b) line += " " + std::to_string(owner_of[b]) + (owner_of[b] == shard_of[newfrags[blocks[b].first]] ? "" : "*");
+      fprintf(stderr, "[zpqj add] %zu contexts, d block owners (* = dealt away from its first fragment's context):%s\n", nctx, line.c_str());
+    }
+  }
+  // the global index fragment k of a block is read from by context r: its own copy if it has one, else the first occurrence
+  auto source_of = [&](size_t r, size_t k) -> uint32_t {
+    if (nctx > 1) { const uint32_t c = copy_at[r * nnew + k]; if (c != 0xffffffffu) return c; }
+    return newfrags[k];
+  };
   clk.mark("ids+pack");
   // exchange 2 (process-sharded): the fragments a block takes from a rank other than its owner (the packing crosses a range
   // edge at most once per edge, so this is a few fragments per rank).  Every rank derives the same list from the global
@@ -538,9 +580,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     xoff.assign(newfrags.size(), 0);
     std::vector<uint64_t> cur(nctx, 0), so, dso; std::vector<uint32_t> sl;
     for (size_t b = 0; b < blocks.size(); ++b) {
-      const size_t owner = shard_of[newfrags[blocks[b].first]];
+      const size_t owner = owner_of[b];
       for (size_t k = blocks[b].first; k < blocks[b].second; ++k) {
-        const uint32_t f = newfrags[k]; const size_t src = shard_of[f];
+        const uint32_t f = source_of(owner, k); const size_t src = shard_of[f];
         if (src == owner) continue;
         xoff[k] = cur[src];
         if (src == me) { so.push_back(sh[me].foff[f - base[me]]); sl.push_back(flen[f]); dso.push_back(cur[src]); }
@@ -578,7 +620,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   auto compress_owned = [&](size_t r) -> int {
     zpq_ctx* c = X ? ctxs[0] : ctxs[r];
     std::vector<size_t> mine;
-    for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == r) mine.push_back(b);
+    for (size_t b = 0; b < blocks.size(); ++b) if (owner_of[b] == r) mine.push_back(b);
     if (mine.empty()) return ZPQ_OK;
     struct Dev { zpq_ctx* c; std::vector<void*> p; ~Dev() { for (void* q : p) zpq_dev_free_pooled(c, q); } } dev{c, {}};
     std::vector<uint64_t> so, dso; std::vector<uint32_t> sl; std::vector<uint64_t> boff(mine.size()); std::vector<uint32_t> bn(mine.size());
@@ -589,7 +631,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       const size_t b = mine[m];
       boff[m] = pos; uint64_t q = pos;
       for (size_t k = blocks[b].first; k < blocks[b].second; ++k) {
-        const uint32_t f = newfrags[k]; const size_t s = shard_of[f];
+        const uint32_t f = source_of(r, k); const size_t s = shard_of[f];
         const uint64_t src = (X && s != r) ? xoff[k] : sh[s].foff[f - base[s]];
         if (s == r) { so.push_back(src); sl.push_back(flen[f]); dso.push_back(q); }
         else remote.push_back({s, src, q, flen[f]});
@@ -707,7 +749,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       uint32_t prev = 0;
       for (size_t q = 0; q < g.size(); q += 8) {
         const uint32_t b = get32(&g[q]), n = get32(&g[q + 4]);
-        if (b >= blocks.size() || shard_of[newfrags[blocks[b].first]] != r || xsize[b] || !n || (q && b <= prev)) return ZPQ_ERR_FORMAT;
+        if (b >= blocks.size() || owner_of[b] != r || xsize[b] || !n || (q && b <= prev)) return ZPQ_ERR_FORMAT;
         xsize[b] = n; rtotal[r] += n; prev = b;
       }
     }
@@ -734,7 +776,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
   } else if (X) {
     // exchange 3: the compressed d blocks; afterwards every rank assembles the same archive
     Bytes snd; std::vector<Bytes> got;
-    for (size_t b = 0; b < blocks.size(); ++b) if (shard_of[newfrags[blocks[b].first]] == me) {
+    for (size_t b = 0; b < blocks.size(); ++b) if (owner_of[b] == me) {
       put32(snd, (uint32_t)b); put32(snd, (uint32_t)dblock[b].size()); snd.insert(snd.end(), dblock[b].begin(), dblock[b].end());
     }
     if ((rc = xchg_all(*X, snd, got))) return rc;
@@ -744,7 +786,7 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
       for (size_t q = 0; q < g.size();) {
         if (g.size() - q < 8) return ZPQ_ERR_FORMAT;
         const uint32_t b = get32(&g[q]), n = get32(&g[q + 4]); q += 8;
-        if (b >= blocks.size() || shard_of[newfrags[blocks[b].first]] != r || g.size() - q < n) return ZPQ_ERR_FORMAT;
+        if (b >= blocks.size() || owner_of[b] != r || g.size() - q < n) return ZPQ_ERR_FORMAT;
         dblock[b].assign(g.begin() + q, g.begin() + q + n); q += n;
       }
     }
@@ -839,9 +881,9 @@ int add_impl(zpq_ctx* const* ctxs, size_t nctx, const uint8_t* archive, size_t a
     std::vector<uint64_t> cur(nctx, 0);
     size_t w = at;
     for (size_t b = 0; b < blocks.size();) {
-      const size_t r = shard_of[newfrags[blocks[b].first]];
+      const size_t r = owner_of[b];
       uint64_t run = 0; size_t e = b;
-      while (e < blocks.size() && shard_of[newfrags[blocks[e].first]] == r) run += dsize[e++];
+      while (e < blocks.size() && owner_of[e] == r) run += dsize[e++];
       if ((rc = zpq_d2h(ctxs[0], ob + w, (const uint8_t*)xrecv[r] + cur[r], (size_t)run))) return rc;
       cur[r] += run; w += (size_t)run; b = e;
     }
