@@ -1080,19 +1080,49 @@ def main_cm_m5(a, rank, world, local, dev):
     HCOMP per byte, one wave per block, all blocks resident at once (90 MB of model state each).  Blocks are independent:
     no collective on the data path; weak scaling."""
     from zpaqfranz_amd import Engine, engine as E
-    nb, bs = a.cm_blocks, a.cm_block_bytes
+    bs = a.cm_block_bytes
+    # blocks resident at once: as many as HBM holds (84 MiB of model state each at this block size) -- 3072 = three waves per SIMD
+    # where they fit, else fewer (round 6: 2048 / 2560 blocks = 113 / 125 MB/s in, profiles/r06s_cm_blocks_resident.txt)
+    candidates = [a.cm_blocks] if a.cm_blocks else [3072, 2816, 2560, 2048]
     eng = Engine(local)
-    blocks = text_blocks_dev(dev, nb * bs, rank, block=bs)
-    assert len(blocks) == nb
+    blocks_all = text_blocks_dev(dev, candidates[0] * bs, rank, block=bs)
+    assert len(blocks_all) == candidates[0]
+    first = bytes(blocks_all[0][0][: blocks_all[0][1]].cpu().numpy())
+    xm = E.expand_method("50", first)
+    method = xm.encode()
+    torch.cuda.empty_cache()
+    nb = 0
+    for cand in candidates:
+        probe = (E.BlockJob * cand)()
+        cap1 = (eng.block_bound(bs, b"", b"") + 63) & ~63
+        scratch = torch.empty(cand * cap1, dtype=torch.uint8, device=dev)
+        for k, (t, n) in enumerate(blocks_all[:cand]):
+            probe[k].in_ = t.data_ptr(); probe[k].n = n; probe[k].method = method
+            probe[k].filename = b""; probe[k].comment = b""; probe[k].dosha1 = 1
+            probe[k].out = scratch.data_ptr() + k * cap1; probe[k].out_cap = cap1
+        try:
+            eng.compress_blocks_dev(probe, cand)            # (the sizing step: the model arena of this many blocks)
+            ok = all(probe[k].status == 0 for k in range(cand))
+        except E.ZpqError as ex:
+            ok = False
+            if ex.status != -8:                             # anything but ZPQ_ERR_NOMEM is an error
+                raise
+        del scratch
+        torch.cuda.empty_cache()
+        if ok:
+            nb = cand
+            break
+        eng.close(); eng = Engine(local)                     # (the context that failed keeps nothing)
+    if not nb:
+        raise SystemExit("cm_m5: not even %d blocks fit" % candidates[-1])
+    blocks = blocks_all[:nb]
+    del blocks_all
     total = sum(n for _, n in blocks)
     # what compressBlock's "50" (level 5, blocks up to 1 MiB) expands to for this data (level 5 looks at the data to add
     # models for periodic structure: text has none, checked for every block outside the timed region); passing the
     # expansion itself keeps that host-side analysis out of the measured step
-    first = bytes(blocks[0][0][: blocks[0][1]].cpu().numpy())
-    xm = E.expand_method("50", first)
     src, args = E.make_config(xm)
     header = E.compile_config(src, args)[0]
-    method = xm.encode()
     caps = [(eng.block_bound(n, b"", b"") + 63) & ~63 for _, n in blocks]
     outs = torch.zeros(sum(caps), dtype=torch.uint8, device=dev)
     jobs = (E.BlockJob * nb)()
@@ -1308,7 +1338,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=["all", "silesia_x256_m1", "dup8_m1", "extract_m1", "text_m2", "cm_m5"],
                     help="default: silesia_x256_m1 (BASELINE config 2) as the headline, then -- single GPU only -- every other workload "
                          "in its own process, nested under 'workloads' in the one JSON line")
-    ap.add_argument("--cm-blocks", type=int, default=2048, help="cm_m5: blocks per GPU (one wave each, all resident at once)")
+    ap.add_argument("--cm-blocks", type=int, default=None, help="cm_m5: blocks per GPU (one wave each, all resident at once); default: 3072 / 2816 / 2560 / 2048, the most that fit HBM")
     ap.add_argument("--cm-block-bytes", type=int, default=256 << 10, help="cm_m5: bytes per block")
     ap.add_argument("--cm-cpu-sample", type=int, default=192, help="cm_m5: blocks the CPU baseline codes (and compares)")
     ap.add_argument("--text-bytes", type=int, default=10 ** 9, help="text_m2: bytes of text per GPU (enwik9 is 10^9)")

@@ -61,7 +61,10 @@ void* zpq_scratch(zpq_ctx* ctx, int slot, size_t bytes) {
   if (ctx) (void)hipSetDevice(ctx->device);      // calls may come from any host thread: make the context's device current
   if (bytes <= ctx->scratch_cap[slot] && ctx->scratch[slot]) return ctx->scratch[slot];
   if (ctx->scratch[slot]) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->stream2); (void)hipFree(ctx->scratch[slot]); }
-  size_t cap = bytes + bytes / 4 + 4096;
+  // grow-only with some slack against re-allocating for every slightly larger request -- a quarter, but never more than 256 MiB:
+  // the context-mixing models of a batch are sized to what HBM holds (hundreds of GB), and a quarter on top of that was what
+  // failed, not the request (round 6: 2816 blocks x 84 MiB = 248 GB asked for 310)
+  size_t cap = bytes + std::min<size_t>(bytes / 4, (size_t)256 << 20) + 4096;
   void* p = nullptr;
   if (zpq_device_malloc(ctx, &p, cap) != hipSuccess) { ctx->scratch[slot] = nullptr; ctx->scratch_cap[slot] = 0; return nullptr; }
   ctx->scratch[slot] = p;
