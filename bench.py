@@ -939,7 +939,9 @@ def main_text_m2(a, rank, world, local, dev):
         torch.cuda.synchronize()
         for e_ in engines:
             e_.sync()
-    steps = a.steps if a.steps is not None else 6
+    # (twelve timed jobs since round 6: with three in flight a six-job window scattered by 9 % between runs of one tree; three, four
+    #  and five jobs in flight are the same 670-690 ms per job: profiles/r06v_sweep_text_m2_jobs_in_flight.txt)
+    steps = a.steps if a.steps is not None else 12
     warm = a.warmup if a.warmup is not None else 1
     # one job alone with one context alive (sizing step, warm step, two timed ones): the one-archive figure, and the kernel
     # durations the roofline is computed from

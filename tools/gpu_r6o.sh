@@ -1,7 +1,7 @@
 # Round 6, the record runs on the final bench.py (eleven adds / five extracts in flight): the driver's command line and the default run
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-T=${1:-r06o}
+T=${1:-r06w}
 S0=$(date +%s)
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_driver_cmd.json 2> gpurun_out/${T}_bench_driver_cmd.err; echo "driver-cmd bench rc=$?"
 timeout 900 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; echo "bench rc=$?"
