@@ -1,6 +1,6 @@
 # Round 6, last GPU call: the whole -m gpu suite and smoke() on the final tree (no -x: every failure is listed)
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-T=${1:-r06p}
+T=${1:-r06x}
 timeout 1800 python -m pytest tests -m gpu -q --durations=5 -p no:cacheprovider > gpurun_out/${T}_tests_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${T}_tests_gpu.log; tail -10 gpurun_out/${T}_tests_gpu.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
